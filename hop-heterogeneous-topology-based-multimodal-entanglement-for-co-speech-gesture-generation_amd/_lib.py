@@ -1,0 +1,54 @@
+"""ctypes binding of libhopmi.so (C ABI: include/hopmi.h).
+
+There is no fallback: if the shared library is missing or a call fails, the op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libhopmi.so")
+_lib = None
+
+_F = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.c_int
+_VP = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/hopmi.h declares
+SIGNATURES = {
+    "hopmi_version": (ctypes.c_char_p, []),
+    "hopmi_last_error": (ctypes.c_char_p, []),
+    "hopmi_gcn_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "hopmi_gcn_bwd_ws_floats": (ctypes.c_size_t, [_I, _I]),
+    "hopmi_gcn_bwd": (_I, [_VP] * 11 + [_I, _I, _VP]),
+}
+
+
+class HopmiError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises HopmiError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HopmiError(
+                f"hopmi: {_LIB_PATH} is missing -- the HIP kernels are not built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no CPU / eager fallback for the hot path.")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HopmiError(f"hopmi: {what} failed (code {rc}): {lib().hopmi_last_error().decode()}")
+
+
+def version() -> str:
+    return lib().hopmi_version().decode()

@@ -1,0 +1,167 @@
+"""Spatio-temporal graph-wavenet block of HOP, MI355X-native.
+
+Drop-in for the reference's `model/gwnet.py` (`nconv`, `linear`, `gcn`, `gwnet`): same
+constructor arguments, same `state_dict` keys and shapes, same call signatures
+(`gwnet.forward(input[B,173,V,16]) -> [B,173,V,4]`, gwnet.py:143-249).
+
+Inside, activations are channels-last `[B][T][V][64]` (a slab = one (clip, frame) pair of
+V x 64 floats, contiguous), the layout the HIP kernels stream; the NCHW tensors of the
+reference exist only at the module boundary.  The graph convolution runs in
+`libhopmi.so` (ops.gcn); nothing here falls back to an eager implementation of it.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+DILATIONS = (1, 2, 1, 2, 1, 2, 1, 2)            # gwnet.py:98-121 with blocks=4, layers=2
+
+
+class nconv(nn.Module):
+    """gwnet.py:8-14 -- einsum('ncvl,vw->ncwl'); kept for API parity (tiny, torch)."""
+
+    def forward(self, x, A):
+        return torch.einsum("ncvl,vw->ncwl", (x, A)).contiguous()
+
+
+class linear(nn.Module):
+    """gwnet.py:16-22 -- 1x1 Conv2d container (`mlp`)."""
+
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.mlp = nn.Conv2d(c_in, c_out, kernel_size=(1, 1), padding=(0, 0), stride=(1, 1), bias=True)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class gcn(nn.Module):
+    """gwnet.py:24-46.  `forward(x[B,C,V,T], [adp])` runs the HIP kernel."""
+
+    def __init__(self, c_in, c_out, dropout, support_len=3, order=2):
+        super().__init__()
+        self.nconv = nconv()
+        self.c_in, self.c_out = c_in, c_out
+        self.mlp = linear((order * support_len + 1) * c_in, c_out)
+        self.dropout = dropout
+        self.order = order
+        self.support_len = support_len
+
+    def _check(self):
+        if not (self.c_in == 64 and self.c_out == 64 and self.order == 2 and self.support_len == 1):
+            raise NotImplementedError("hopmi gcn kernel: only c_in=c_out=64, order=2, one support (the HOP.py:143 "
+                                      "configuration) is built")
+
+    def forward_cl(self, x_cl, A1, A2):
+        """x_cl (B,T,V,64) channels-last -> (B,T,V,64)."""
+        self._check()
+        h = ops.gcn(x_cl, A1, A2, self.mlp.mlp.weight, self.mlp.mlp.bias)
+        return F.dropout(h, self.dropout, training=self.training) if self.dropout > 0 else h
+
+    def forward(self, x, support):
+        if len(support) != 1:
+            raise NotImplementedError("hopmi gcn kernel: exactly one support matrix (the adaptive adjacency)")
+        A = support[0]
+        h = self.forward_cl(x.permute(0, 3, 2, 1), A, A @ A)
+        return h.permute(0, 3, 2, 1).contiguous()
+
+
+class gwnet(nn.Module):
+    """gwnet.py:49-249 with the arguments HOP.py:143 passes."""
+
+    def __init__(self, device, num_nodes, dropout=0.3, supports=None, gcn_bool=True, addaptadj=True, aptinit=None,
+                 in_dim=2, out_dim=12, residual_channels=32, dilation_channels=32, skip_channels=256,
+                 end_channels=512, kernel_size=2, blocks=4, layers=2):
+        super().__init__()
+        if not (gcn_bool and addaptadj and supports is None and aptinit is None and kernel_size == 2
+                and blocks * layers == len(DILATIONS) and residual_channels == 64 and dilation_channels == 64):
+            raise NotImplementedError("hopmi gwnet: only the HOP.py:143 configuration (adaptive adjacency only, "
+                                      "64 residual/dilation channels, 4x2 layers, kernel 2) is built")
+        self.dropout, self.blocks, self.layers = dropout, blocks, layers
+        self.gcn_bool, self.addaptadj = gcn_bool, addaptadj
+        self.filter_convs, self.gate_convs = nn.ModuleList(), nn.ModuleList()
+        self.residual_convs, self.skip_convs = nn.ModuleList(), nn.ModuleList()
+        self.bn, self.gconv = nn.ModuleList(), nn.ModuleList()
+        self.start_conv = nn.Conv2d(in_dim, residual_channels, kernel_size=(1, 1))
+        self.supports = []
+        self.supports_len = 1
+        self.nodevec1 = nn.Parameter(torch.randn(num_nodes, 10))
+        self.nodevec2 = nn.Parameter(torch.randn(10, num_nodes))
+        receptive_field = 1
+        for _b in range(blocks):
+            additional_scope, new_dilation = kernel_size - 1, 1
+            for _l in range(layers):
+                self.filter_convs.append(nn.Conv2d(residual_channels, dilation_channels, (1, kernel_size), dilation=new_dilation))
+                self.gate_convs.append(nn.Conv2d(residual_channels, dilation_channels, (1, kernel_size), dilation=new_dilation))
+                self.residual_convs.append(nn.Conv2d(dilation_channels, residual_channels, (1, 1)))   # never used (gwnet.py:224-231)
+                self.skip_convs.append(nn.Conv2d(dilation_channels, skip_channels, (1, 1)))
+                self.bn.append(nn.BatchNorm2d(residual_channels))
+                new_dilation *= 2
+                receptive_field += additional_scope
+                additional_scope *= 2
+                self.gconv.append(gcn(dilation_channels, residual_channels, dropout, support_len=self.supports_len))
+        self.end_conv_1 = nn.Conv2d(skip_channels, end_channels, (1, 1), bias=True)
+        self.end_conv_2 = nn.Conv2d(end_channels, out_dim, (1, 1), bias=True)
+        self.receptive_field = receptive_field
+        self.num_nodes, self.in_dim, self.out_dim = num_nodes, in_dim, out_dim
+        self.skip_channels, self.end_channels = skip_channels, end_channels
+
+    # -- pieces -----------------------------------------------------------------------------
+    def adjacency(self):
+        """gwnet.py:161-164; A2 = A @ A re-associates (xA)A for the kernel (V x V, torch)."""
+        A1 = F.softmax(F.relu(torch.mm(self.nodevec1, self.nodevec2)), dim=1)
+        return A1, A1 @ A1
+
+    def _batchnorm(self, i, y):
+        """bn[i] on channels-last y (B,T,V,64): gwnet.py:237 (training: batch statistics over
+        (B,V,T), running stats updated with momentum 0.1 / unbiased variance)."""
+        bn = self.bn[i]
+        if self.training:
+            var, mean = torch.var_mean(y, dim=(0, 1, 2), unbiased=False)
+            with torch.no_grad():
+                n = y.numel() // y.shape[-1]
+                bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+                bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+                bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        scale = bn.weight * torch.rsqrt(var + bn.eps)
+        return y * scale + (bn.bias - mean * scale)
+
+    def forward_cl(self, x):
+        """x (B,T>=13,V,in_dim) channels-last -> (B,4,V,out_dim) channels-last."""
+        if x.shape[1] < self.receptive_field:
+            x = F.pad(x, (0, 0, 0, 0, self.receptive_field - x.shape[1], 0))          # gwnet.py:145-146
+        x = F.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias)        # gwnet.py:149
+        A1, A2 = self.adjacency()
+        T_out = x.shape[1] - sum(DILATIONS)
+        tails = []
+        last = len(DILATIONS) - 1
+        for i, d in enumerate(DILATIONS):
+            Tn = x.shape[1] - d
+            lo, hi = x[:, :Tn], x[:, d:]                    # Conv2d (1,2) taps: t and t+d (gwnet.py:186-200)
+            wf, wg = self.filter_convs[i].weight, self.gate_convs[i].weight
+            w0 = torch.cat([wf[:, :, 0, 0], wg[:, :, 0, 0]], 0)
+            w1 = torch.cat([wf[:, :, 0, 1], wg[:, :, 0, 1]], 0)
+            fg = F.linear(lo, w0) + F.linear(hi, w1, torch.cat([self.filter_convs[i].bias, self.gate_convs[i].bias]))
+            u = torch.tanh(fg[..., :64]) * torch.sigmoid(fg[..., 64:])
+            # only the last T_out frames of every layer's skip reach the output (crop-adds, gwnet.py:213-220)
+            tails.append(u[:, Tn - T_out:])
+            if i == last:
+                # gcn/bn of the last layer never reach the output (gwnet.py:240); the reference still
+                # advances bn[7]'s running statistics in training mode, so do that (no autograd).
+                if self.training:
+                    with torch.no_grad():
+                        self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2) + hi)
+                break
+            x = self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2) + hi)           # gwnet.py:226-237
+        ws = torch.cat([c.weight.flatten(1) for c in self.skip_convs], 1)               # (256, 8*64)
+        bs = torch.stack([c.bias for c in self.skip_convs]).sum(0)
+        s = F.relu(F.linear(torch.cat(tails, -1), ws, bs))                              # gwnet.py:209-220,240
+        s = F.relu(F.linear(s, self.end_conv_1.weight.flatten(1), self.end_conv_1.bias))
+        return F.linear(s, self.end_conv_2.weight.flatten(1), self.end_conv_2.bias)     # gwnet.py:243-246
+
+    def forward(self, input):
+        """input (B,in_dim,V,T) NCHW (any strides) -> (B,out_dim,V,T-12) NCHW contiguous."""
+        return self.forward_cl(input.permute(0, 3, 2, 1)).permute(0, 3, 2, 1).contiguous()

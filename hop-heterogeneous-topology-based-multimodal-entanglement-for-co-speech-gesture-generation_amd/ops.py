@@ -1,0 +1,115 @@
+"""torch.autograd bindings of the hand-written gfx950 kernels (through the C ABI).
+
+Every op requires ROCm device tensors and the built libhopmi.so; there is deliberately
+no eager / CPU implementation here (the CPU oracle lives in oracle/, test-only).
+"""
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class KernelTimer:
+    """HIP events around every launch of the named kernels, recorded on the stream the kernel is
+    launched on (torch's current stream), so bench.py can report algorithmic bytes / kernel time
+    live.  Enable with `ops.TIMER = KernelTimer()`; read with `.summary()` after a synchronize."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def launch(self, name, nbytes, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.spans.setdefault(name, []).append((e0, e1, nbytes, flops))
+        return rc
+
+    def summary(self):
+        out = {}
+        for name, spans in self.spans.items():
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in spans)
+            out[name] = dict(launches=len(spans), total_ms=ms, bytes=sum(s[2] for s in spans),
+                             flops=sum(s[3] for s in spans))
+        return out
+
+
+TIMER = None
+
+
+def _timed(name, nbytes, flops, fn):
+    return fn() if TIMER is None else TIMER.launch(name, nbytes, flops, fn)
+
+
+def gcn_algorithmic_bytes(n_slabs: int, V: int) -> int:
+    """read x' + write h = 2*64*V*4 B per slab, plus the per-launch constants
+    (A: V*V*4 B twice, Wm+bm: 49 408 B)."""
+    return n_slabs * 2 * 64 * V * 4 + 2 * V * V * 4 + 64 * 192 * 4 + 64 * 4
+
+
+def gcn_flops(n_slabs: int, V: int) -> int:
+    """per slab V*(2*192*64) + 2*(2*64*V*V)."""
+    return n_slabs * (V * 2 * 192 * 64 + 4 * 64 * V * V)
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.HopmiError(f"hopmi: `{name}` is on {t.device}; the hot path only runs on a ROCm device "
+                              "(no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.HopmiError(f"hopmi: `{name}` must be float32, got {t.dtype}")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+class _GcnFn(torch.autograd.Function):
+    """h = Wm.[x ; xA1 ; xA2] + bm on channels-last slabs (gwnet.py:24-46)."""
+
+    @staticmethod
+    def forward(ctx, x, A1, A2, Wm, bm):
+        x, A1, A2, Wm, bm = (_dev_f32(t, n) for t, n in ((x, "x"), (A1, "A1"), (A2, "A2"), (Wm, "Wm"), (bm, "bm")))
+        V = A1.shape[0]
+        if x.shape[-1] != 64 or x.shape[-2] != V or A1.shape != (V, V) or A2.shape != (V, V):
+            raise _lib.HopmiError(f"hopmi gcn: bad shapes x{tuple(x.shape)} A1{tuple(A1.shape)} A2{tuple(A2.shape)}")
+        if Wm.numel() != 64 * 192 or bm.numel() != 64:
+            raise _lib.HopmiError(f"hopmi gcn: Wm must have 64*192 elements, bm 64 (got {Wm.numel()}, {bm.numel()})")
+        n_slabs = x.numel() // (V * 64)
+        h = torch.empty_like(x)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("gcn_fwd", gcn_algorithmic_bytes(n_slabs, V), gcn_flops(n_slabs, V),
+                          lambda: L.hopmi_gcn_fwd(x.data_ptr(), A1.data_ptr(), A2.data_ptr(), Wm.data_ptr(),
+                                                  bm.data_ptr(), h.data_ptr(), n_slabs, V, st)), "hopmi_gcn_fwd")
+        ctx.save_for_backward(x, A1, A2, Wm)
+        ctx.wm_shape = Wm.shape
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, A1, A2, Wm = ctx.saved_tensors
+        dh = _dev_f32(dh, "dh")
+        V = A1.shape[0]
+        n_slabs = x.numel() // (V * 64)
+        L = _lib.lib()
+        ws = torch.empty(L.hopmi_gcn_bwd_ws_floats(n_slabs, V), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        dA1, dA2 = torch.empty_like(A1), torch.empty_like(A2)
+        dWm = torch.empty(ctx.wm_shape, dtype=torch.float32, device=x.device)
+        dbm = torch.empty(64, dtype=torch.float32, device=x.device)
+        st = _stream()
+        # backward: read x', dh, write dx' (+ tiny dA, dWm, dbm) = 1.5x forward bytes, ~2x forward FLOPs
+        _lib.check(_timed("gcn_bwd", n_slabs * 3 * 64 * V * 4, 2 * gcn_flops(n_slabs, V),
+                          lambda: L.hopmi_gcn_bwd(x.data_ptr(), dh.data_ptr(), A1.data_ptr(), A2.data_ptr(),
+                                                  Wm.data_ptr(), dx.data_ptr(), dA1.data_ptr(), dA2.data_ptr(),
+                                                  dWm.data_ptr(), dbm.data_ptr(), ws.data_ptr(), n_slabs, V, st)),
+                   "hopmi_gcn_bwd")
+        return dx, dA1, dA2, dWm, dbm
+
+
+def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, bm: torch.Tensor) -> torch.Tensor:
+    """x (..., V, 64) channels-last; A1 = adp, A2 = adp @ adp (V,V); Wm (64,192[,1,1]); bm (64,)."""
+    return _GcnFn.apply(x, A1, A2, Wm, bm)

@@ -1,0 +1,147 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce over RCCL/xGMI.
+
+The reference gets its data parallelism implicitly from HF accelerate (DDP with
+`find_unused_parameters=True`, run_ted.py:110-112,363-364); there is no explicit collective
+in its source.  Replicas are arithmetically independent (per-replica BatchNorm statistics, no
+SyncBN), so the only exchange per step is the gradient mean of the parameters that receive a
+gradient (65.6 M fp32 for TED; 34 tensors never do: audio_encoder.*, gwnet.residual_convs.*,
+gwnet.bn.7.*, gwnet.gconv.7.* -- they are left out of the buckets, which is what
+find_unused_parameters achieves in the reference).
+
+Design for xGMI (7 point-to-point links per GPU, ring collectives are per-link bound):
+few, large buckets (default 64 MB) launched from autograd hooks as soon as their last gradient
+is produced, on RCCL's own stream, so the 183 MB `mapping_layer.weight` all-reduce overlaps with
+the rest of backward (the model issues its gwnet branch first in forward, which puts the
+mapping-layer branch early in backward).  `GradSync.backward(loss)` has the
+`accelerator.backward` shape that `train_llm` expects.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter], dtype):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat = torch.empty(self.numel, dtype=dtype or params[0].dtype, device=params[0].device)
+        self.pending = len(params)
+        self.handle = None
+
+
+class _Group:
+    """The trainable parameters of one module (generator / discriminator); buckets never span
+    groups, so a backward that only reaches the discriminator only exchanges its 1 MB."""
+
+    def __init__(self, params):
+        self.params = params
+        self.buckets: Optional[List[_Bucket]] = None
+
+
+class GradSync:
+    """Bucketed, overlapped gradient all-reduce (mean) for a set of modules.
+
+    Usage:  sync = GradSync([model, discriminator]);  train_llm(..., accelerator=sync)
+    With world_size == 1 (or torch.distributed not initialised) it is a plain backward.
+    """
+
+    def __init__(self, modules, bucket_mb: float = 64.0, grad_dtype: Optional[torch.dtype] = None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.grad_dtype = grad_dtype                 # e.g. torch.bfloat16 halves the xGMI bytes
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.groups: List[_Group] = []
+        seen = set()
+        for m in modules:
+            ps = []
+            for p in m.parameters():
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    ps.append(p)
+            if ps:
+                self.groups.append(_Group(ps))
+        self._bucket_of = {}
+        self._in_backward = False
+        self.bytes_reduced = 0                       # for tests / reporting
+
+    # -- bucket plan of a group: built from the first backward that reaches it -----------------------
+    def _plan(self, g: _Group):
+        live = [p for p in g.params if p.grad is not None]
+        if self.world > 1:                                        # same plan on every rank, or hang
+            n = torch.tensor([len(live), sum(p.numel() for p in live)], device=g.params[0].device)
+            lo, hi = n.clone(), n.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                raise RuntimeError("GradSync: ranks disagree on which parameters receive gradients")
+        g.buckets = []
+        cur, cur_bytes = [], 0
+        for p in reversed(live):                 # reverse registration order ~ autograd's production order
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > self.bucket_bytes:
+                g.buckets.append(_Bucket(cur, self.grad_dtype))
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            g.buckets.append(_Bucket(cur, self.grad_dtype))
+        for b in g.buckets:
+            for p in b.params:
+                self._bucket_of[id(p)] = b
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _launch(self, b: _Bucket):
+        off = 0
+        for p in b.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.bytes_reduced += b.flat.numel() * b.flat.element_size()
+
+    def _on_grad(self, p):
+        if not self._in_backward:
+            return
+        b = self._bucket_of[id(p)]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _collect(self, b: _Bucket):
+        b.handle.wait()
+        inv = 1.0 / self.world
+        off = 0
+        for p in b.params:
+            p.grad.copy_((b.flat[off:off + p.numel()] * inv).view_as(p.grad))
+            off += p.numel()
+        b.handle = None
+
+    # -- accelerator.backward shape (train_llm.py:34,85) -----------------------------------------------
+    def backward(self, loss):
+        if self.world == 1:
+            loss.backward()
+            return
+        for g in self.groups:
+            for b in g.buckets or ():
+                b.pending = len(b.params)
+        self._in_backward = True
+        try:
+            loss.backward()
+        finally:
+            self._in_backward = False
+        for g in self.groups:
+            if g.buckets is None:                # not planned yet: did this backward reach the group?
+                if any(p.grad is not None for p in g.params):
+                    self._plan(g)
+                    for b in g.buckets:
+                        self._launch(b)
+                        self._collect(b)
+                continue
+            for b in g.buckets:
+                if b.pending == len(b.params):   # untouched by this backward (e.g. G buckets in the D step)
+                    continue
+                if b.handle is None:             # partially produced: reduce what is there
+                    self._launch(b)
+                self._collect(b)

@@ -1,0 +1,161 @@
+"""Training-step API of the reference, kept call-compatible:
+
+  train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,
+            model, discriminator, model_optim, dis_optimizer, accelerator) -> dict      (train_llm.py:9-98)
+  train_iter_gan(args, epoch, in_text, in_audio, target_poses, vid_indices,
+                 pose_decoder, discriminator, pose_dec_optim, dis_optim) -> dict         (train_gan.py:13-103)
+
+Same order and count of generator / discriminator forwards (BatchNorm running statistics
+and RNG draws are side effects the reference's training trajectory depends on), same loss
+recipe (literal `epoch > 10` gate, `+1e-8` terms, beta = 0.05 / 0.1), same dict keys.
+What differs (numerics-preserving): the two generator forwards whose outputs
+the reference only ever uses detached run under `no_grad` (still in training mode), the
+batch-independent prototype branch is computed once per step, and the scalar losses are
+fetched with one device->host copy instead of up to five `.item()` syncs.
+"""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+
+# random draws go through these three so tests can replay the reference's CPU stream on the GPU
+def _randn_like(t):
+    return torch.randn_like(t)
+
+
+def _randperm(n, device):
+    return torch.randperm(n, device=device)
+
+
+def add_noise(data):
+    """train_llm.py:5-7."""
+    return data + _randn_like(data) * 0.1
+
+
+def _unwrap(m):
+    return m.module if hasattr(m, "module") and not hasattr(m, "step_cache") else m
+
+
+def _step_cache(model):
+    m = _unwrap(model)
+    return m.step_cache() if hasattr(m, "step_cache") else contextlib.nullcontext()
+
+
+def _regularisers(args, outputs, z_context, z_mu, z_logvar, out_rand, z_rand):
+    """train_llm.py:59-73 / train_gan.py:68-81."""
+    beta = 0.05
+    pose_l1 = F.smooth_l1_loss(outputs / beta, out_rand.detach() / beta, reduction="none") * beta
+    pose_l1 = pose_l1.sum(dim=1).sum(dim=1)
+    pose_l1 = pose_l1.view(pose_l1.shape[0], -1).mean(1)
+    z_l1 = F.l1_loss(z_context.detach(), z_rand.detach(), reduction="none")
+    z_l1 = z_l1.view(z_l1.shape[0], -1).mean(1)
+    div_reg = torch.clamp(-(pose_l1 / (z_l1 + 1.0e-5)), min=-1000).mean()
+    kld = None
+    if args.z_type == "speaker":
+        kld = -0.5 * torch.mean(1 + z_logvar - z_mu.pow(2) - z_logvar.exp())
+    return div_reg, kld
+
+
+def _ret_dict(args, gan, huber, kld, div_reg, gen_error, dis_error):
+    """train_llm.py:88-98 with a single host sync.  `if kld:` / `if div_reg:` in the reference
+    are truthiness tests on the tensors: a term that is exactly 0.0 is left out."""
+    terms = [("loss", args.loss_regression_weight, huber)]
+    if kld is not None:
+        terms.append(("KLD", args.loss_kld_weight, kld))
+    if div_reg is not None:
+        terms.append(("DIV_REG", args.loss_reg_weight, div_reg))
+    if gan:
+        terms += [("gen", args.loss_gan_weight, gen_error), ("dis", 1.0, dis_error)]
+    vals = torch.stack([t.detach().float() for _, _, t in terms]).cpu().tolist()
+    ret = {}
+    for (k, wgt, _), v in zip(terms, vals):
+        if k in ("KLD", "DIV_REG") and v == 0.0:
+            continue
+        ret[k] = wgt * v
+    return ret
+
+
+def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,
+              model, discriminator, model_optim, dis_optimizer, accelerator):
+    pre_seq = target_dir_vec[:, 0:16]
+    dis_error = None
+    gan = epoch > 10 and args.loss_gan_weight > 0.0
+    with _step_cache(model):
+        if gan:                                                                # train_llm.py:15-36
+            dis_optimizer.zero_grad()
+            with torch.no_grad():                                              # only used detached (:24)
+                outputs, *_ = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
+            dis_real = discriminator(add_noise(target_dir_vec), text_token_padded)
+            dis_fake = discriminator(add_noise(outputs.detach()), text_token_padded)
+            dis_error = torch.sum(-torch.mean(torch.log(dis_real + 1e-8) + torch.log(1 - dis_fake + 1e-8)))
+            accelerator.backward(dis_error)
+            dis_optimizer.step()
+
+        model_optim.zero_grad()
+        outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
+        dis_output = discriminator(outputs, text_token_padded)
+        gen_error = -torch.mean(torch.log(dis_output + 1e-8))
+        huber_loss = F.smooth_l1_loss(outputs / 0.1, target_dir_vec / 0.1) * 0.1
+        kld = div_reg = None
+        if (args.z_type == "speaker" or args.z_type == "random") and args.loss_reg_weight > 0.0:
+            rand_vids = None
+            if args.z_type == "speaker":
+                rand_vids = vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)]
+            with torch.no_grad():                                              # only used detached (:60,65)
+                out_rand, z_rand, _, _ = model(in_audio, log_melspec, text_token_padded, pre_seq, rand_vids)
+            div_reg, kld = _regularisers(args, outputs, z_context, z_mu, z_logvar, out_rand, z_rand)
+            loss = huber_loss * args.loss_regression_weight + div_reg * args.loss_reg_weight
+            if kld is not None:
+                loss = loss + kld * args.loss_kld_weight
+        else:
+            loss = huber_loss * args.loss_regression_weight
+        if epoch > 10:                                                         # literal gate, train_llm.py:81
+            loss = loss + gen_error * args.loss_gan_weight
+        accelerator.backward(loss)
+        model_optim.step()
+    return _ret_dict(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)
+
+
+def train_iter_gan(args, epoch, in_text, in_audio, target_poses, vid_indices,
+                   pose_decoder, discriminator, pose_dec_optim, dis_optim):
+    warm_up_epochs = args.loss_warmup
+    pre_seq = target_poses.new_zeros((target_poses.shape[0], target_poses.shape[1], target_poses.shape[2] + 1))
+    pre_seq[:, 0:args.n_pre_poses, :-1] = target_poses[:, 0:args.n_pre_poses]
+    pre_seq[:, 0:args.n_pre_poses, -1] = 1
+    dis_error = None
+    gan = epoch > warm_up_epochs and args.loss_gan_weight > 0.0
+    if gan:                                                                    # train_gan.py:27-43 (no noise)
+        dis_optim.zero_grad()
+        with torch.no_grad():
+            out_dir_vec, *_ = pose_decoder(pre_seq, in_text, in_audio, vid_indices)
+        dis_real = discriminator(target_poses, in_text)
+        dis_fake = discriminator(out_dir_vec.detach(), in_text)
+        dis_error = torch.sum(-torch.mean(torch.log(dis_real + 1e-8) + torch.log(1 - dis_fake + 1e-8)))
+        dis_error.backward()
+        dis_optim.step()
+
+    pose_dec_optim.zero_grad()
+    out_dir_vec, z, z_mu, z_logvar = pose_decoder(pre_seq, in_text, in_audio, vid_indices)
+    beta = 0.1
+    huber_loss = F.smooth_l1_loss(out_dir_vec / beta, target_poses / beta) * beta
+    dis_output = discriminator(out_dir_vec, in_text)
+    gen_error = -torch.mean(torch.log(dis_output + 1e-8))
+    kld = div_reg = None
+    if (args.z_type == "speaker" or args.z_type == "random") and args.loss_reg_weight > 0.0:
+        rand_vids = None
+        if args.z_type == "speaker":
+            rand_vids = vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)]
+        with torch.no_grad():
+            out_rand, z_rand, _, _ = pose_decoder(pre_seq, in_text, in_audio, rand_vids)
+        div_reg, kld = _regularisers(args, out_dir_vec, z, z_mu, z_logvar, out_rand, z_rand)
+        loss = args.loss_regression_weight * huber_loss + args.loss_reg_weight * div_reg
+        if kld is not None:
+            loss = loss + args.loss_kld_weight * kld
+    else:
+        loss = args.loss_regression_weight * huber_loss
+    if epoch > warm_up_epochs:
+        loss = loss + args.loss_gan_weight * gen_error
+    loss.backward()
+    pose_dec_optim.step()
+    return _ret_dict(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)

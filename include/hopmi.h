@@ -1,0 +1,67 @@
+/*
+ * hopmi.h -- C ABI of libhopmi.so: hand-written gfx950 (MI355X) kernels for the HOP
+ * generator hot path.
+ *
+ * The reference (Chenghyyy/HOP-...) is pure Python/PyTorch and has no FFI of its own;
+ * each entry point below replaces a run of aten ops inside a reference Python function
+ * and cites it.  The host side (Python, ctypes) lives in
+ * hop-..._amd/{_lib,ops}.py; INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions (every entry point):
+ *   - plain device pointers borrowed for the call; the caller (PyTorch) owns all
+ *     memory including workspaces; no allocation, no host sync, no exceptions;
+ *   - asynchronous, ordered on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream); safe to capture into a hipGraph;
+ *   - returns 0 on success, a negative HOPMI_E* code otherwise; hopmi_last_error()
+ *     returns a thread-local message for the last failure;
+ *   - all tensors fp32, dense, "channels-last" activations: x[n_slabs][V][64] where a
+ *     slab is one (clip b, frame t) pair, i.e. row (b*T + t)*V + v, channel c innermost.
+ */
+#ifndef HOPMI_H
+#define HOPMI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOPMI_OK 0
+#define HOPMI_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define HOPMI_ELAUNCH (-2)  /* HIP launch or runtime error */
+
+#define HOPMI_C 64          /* residual = dilation channels (HOP.py:143) */
+#define HOPMI_MAX_NODES 48  /* 9 (TED) and 42 (TED-Expressive) are what the reference uses */
+
+const char* hopmi_version(void);
+const char* hopmi_last_error(void);
+
+/* ---- graph convolution: model/gwnet.py:24-46 (gcn.forward) + :8-14 (nconv) + :16-22 (linear)
+ *
+ *   h = Wm . [x ; x A1 ; x A2] + bm        with A1 = adp, A2 = adp @ adp
+ *
+ * i.e. per slab s:  h[s] = X[s] W0^T + (A1^T X[s]) W1^T + (A2^T X[s]) W2^T + bm,
+ * X[s] is V x 64, Wm is the reference's mlp.mlp.weight viewed [64][192] = [W0|W1|W2].
+ * The reference computes x2 = (x A) A; passing A2 = A @ A (a V x V product done by the
+ * caller, so autograd sees it) is the same contraction re-associated.
+ */
+int hopmi_gcn_fwd(const float* x, const float* A1, const float* A2, const float* Wm, const float* bm,
+                  float* h, int n_slabs, int V, void* stream);
+
+/* Backward of the above w.r.t. everything (autograd of gwnet.py:33-46):
+ *   dx[s]  = G0 + A1 G1 + A2 G2,  [G0|G1|G2] = dh[s] Wm
+ *   dAk    = sum_s X[s] Gk[s]^T          (the V x V "joint" reduction)
+ *   dWm    = sum_rows dh^T [x ; xA1 ; xA2]     dbm = sum_rows dh
+ * `ws` must hold hopmi_gcn_bwd_ws_floats(n_slabs, V) floats; it receives per-workgroup
+ * partials that a second, fixed-order pass sums (bitwise reproducible, no atomics).
+ */
+size_t hopmi_gcn_bwd_ws_floats(int n_slabs, int V);
+int hopmi_gcn_bwd(const float* x, const float* dh, const float* A1, const float* A2, const float* Wm,
+                  float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
+                  int n_slabs, int V, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOPMI_H */

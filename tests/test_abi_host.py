@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads and exports what include/hopmi.h declares; host-side module
+logic (state_dict layout, loud failure without a GPU).  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import hopmi
+from hopmi import _lib
+from oracle import spec
+from oracle.golden_util import SynthTok, SynthVocab, hop_cfg, tiny_bert_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "hopmi.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hopmi_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert "hopmi_gcn_fwd" in syms and "hopmi_gcn_bwd" in syms
+    handle = ctypes.CDLL(_lib._LIB_PATH)
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in hopmi.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.version().startswith("hopmi")
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    L = _lib.lib()
+    assert L.hopmi_gcn_fwd(None, None, None, None, None, None, 4, 9, None) == -1
+    assert b"null pointer" in L.hopmi_last_error()
+    assert L.hopmi_gcn_bwd_ws_floats(4, 9) == 4 // 4 * 0 + 1 * (64 * 192 + 64 + 2 * 81)
+    assert L.hopmi_gcn_bwd_ws_floats(4, 49) == 0
+
+
+@pytest.mark.parametrize("V", [9, 42])
+def test_state_dict_layout_matches_reference(golden, V):
+    from transformers import BertModel
+    g = golden(f"model_V{V}")
+    bcfg = tiny_bert_config()
+    m = hopmi.Model(hop_cfg(V, bcfg.hidden_size), BertModel(bcfg), SynthTok(), SynthVocab(11))
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["state_shapes"]]
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert not any(n.startswith("llm_model.") or n == "word_embeddings" for n in trainable)
+    assert set(spec.model_spec(V, bcfg, 11).keys()) == set(sd.keys())
+
+
+def test_hot_path_refuses_cpu_tensors():
+    x = torch.zeros(2, 3, 9, 64)
+    A = torch.eye(9)
+    with pytest.raises(_lib.HopmiError, match="no CPU fallback"):
+        hopmi.ops.gcn(x, A, A, torch.zeros(64, 192), torch.zeros(64))
+
+
+def test_discriminator_cpu_matches_golden(golden):
+    """ConvDiscriminator stays on stock torch ops, so it can be checked on CPU too."""
+    from oracle import fill
+    g = golden("disc_P27")
+    d = hopmi.ConvDiscriminator(27)
+    d.gru.dropout = 0.0
+    fill.fill_state_(d)
+    d.train()
+    y = d(fill.normal("disc.poses", (3, 34, 27), 0.3))
+    assert torch.allclose(y, torch.from_numpy(g["out"]), rtol=1e-4, atol=1e-6)

@@ -1,0 +1,234 @@
+"""GPU (-m gpu): the HIP product path, called through the C ABI, against the CPU oracle and
+the golden vectors of the reference.  Bar: <= 1e-3 relative (fp32), BASELINE.json north_star."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3          # north_star tolerance: 1e-3 relative, fp32
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_err(got, want):
+    got = got.detach().cpu().double()
+    want = torch.as_tensor(np.asarray(want)).double() if not torch.is_tensor(want) else want.detach().cpu().double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+def assert_close(got, want, rtol=RTOL, what=""):
+    e = rel_err(got, want)
+    assert e <= rtol, f"{what} rel err {e:.3e} > {rtol}"
+
+
+# ------------------------------------------------------------------------------------ gcn kernel
+@pytest.mark.parametrize("V,B,T", [(9, 2, 5), (42, 2, 5), (9, 1, 1), (42, 1, 1), (9, 5, 13), (42, 3, 7), (9, 128, 15), (17, 3, 4)])
+def test_gcn_fwd_bwd_vs_oracle(V, B, T):
+    from hopmi import ops
+    from oracle import fill, ref_cpu, spec
+    dev = _dev()
+    sd = spec.build_sd(spec.gcn_spec())
+    x = fill.uniform("gcn.x", (B, 64, V, T))
+    A = ref_cpu.adjacency(fill.uniform("gcn.nodevec1", (V, 10)), fill.uniform("gcn.nodevec2", (10, V)))
+    gout = fill.uniform("gcn.gout", (B, 64, V, T))
+    # oracle (NCHW, CPU)
+    xo, Ao = x.clone().requires_grad_(), A.clone().requires_grad_()
+    wo, bo = sd["mlp.mlp.weight"].clone().requires_grad_(), sd["mlp.mlp.bias"].clone().requires_grad_()
+    ho = ref_cpu.gcn(xo, Ao, wo, bo)
+    (ho * gout).sum().backward()
+    # HIP (channels-last, through the C ABI)
+    xg = x.permute(0, 3, 2, 1).contiguous().to(dev).requires_grad_()
+    Ag = A.to(dev).requires_grad_()
+    wg, bg = sd["mlp.mlp.weight"].to(dev).requires_grad_(), sd["mlp.mlp.bias"].to(dev).requires_grad_()
+    hg = ops.gcn(xg, Ag, Ag @ Ag, wg, bg)
+    (hg * gout.permute(0, 3, 2, 1).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(hg.permute(0, 3, 2, 1), ho, what="h")
+    assert_close(xg.grad.permute(0, 3, 2, 1), xo.grad, what="dx")
+    assert_close(Ag.grad, Ao.grad, what="dA")
+    assert_close(wg.grad, wo.grad, what="dW")
+    assert_close(bg.grad, bo.grad, what="db")
+
+
+@pytest.mark.parametrize("V", [9, 42])
+def test_gcn_vs_reference_golden(golden, V):
+    from hopmi import ops
+    from oracle import fill, ref_cpu, spec
+    dev = _dev()
+    g = golden(f"gcn_V{V}")
+    sd = spec.build_sd(spec.gcn_spec())
+    x = fill.uniform("gcn.x", (2, 64, V, 5)).permute(0, 3, 2, 1).contiguous().to(dev).requires_grad_()
+    A = ref_cpu.adjacency(fill.uniform("gcn.nodevec1", (V, 10)), fill.uniform("gcn.nodevec2", (10, V))).to(dev).requires_grad_()
+    w, b = sd["mlp.mlp.weight"].to(dev).requires_grad_(), sd["mlp.mlp.bias"].to(dev).requires_grad_()
+    h = ops.gcn(x, A, A @ A, w, b)
+    (h * fill.uniform("gcn.gout", (2, 64, V, 5)).permute(0, 3, 2, 1).to(dev)).sum().backward()
+    assert_close(h.permute(0, 3, 2, 1), g["h"], what="h")
+    assert_close(x.grad.permute(0, 3, 2, 1), g["dx"], what="dx")
+    assert_close(A.grad, g["dA"], what="dA")
+    assert_close(w.grad, g["dW"], what="dW")
+    assert_close(b.grad, g["db"], what="db")
+
+
+@pytest.mark.parametrize("V,B", [(9, 128), (42, 64)])
+def test_gcn_full_size_properties(V, B):
+    """BASELINE.json sizes: linearity in x (h(a x1 + x2) - bias part), determinism, and a plain
+    torch fp32 reference of the same contraction on the GPU."""
+    from hopmi import ops
+    dev = _dev()
+    T = 15
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x1 = torch.randn(B, T, V, 64, generator=g).to(dev)
+    x2 = torch.randn(B, T, V, 64, generator=g).to(dev)
+    A = torch.softmax(torch.randn(V, V, generator=g), 1).to(dev)
+    W = (torch.randn(64, 192, generator=g) / 14).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    A2 = A @ A
+    f = lambda x: ops.gcn(x, A, A2, W, b)
+    h1, h2, h12 = f(x1), f(x2), f(2.5 * x1 + x2)
+    assert_close(h12 - b, 2.5 * (h1 - b) + (h2 - b), 1e-4, "linearity")
+    assert torch.equal(f(x1), h1), "run-to-run determinism"
+    xa = torch.einsum("btvc,vw->btwc", x1, A)
+    ref = torch.cat([x1, xa, torch.einsum("btvc,vw->btwc", xa, A)], -1) @ W.t() + b
+    assert_close(h1, ref, 1e-4, "torch fp32 reference")
+    # backward determinism (fixed-order partial sums, no atomics)
+    xg = x1.clone().requires_grad_(); Wg = W.clone().requires_grad_()
+    f2 = lambda: torch.autograd.grad((ops.gcn(xg, A, A2, Wg, b) * x2).sum(), [xg, Wg])
+    (dx_a, dw_a), (dx_b, dw_b) = f2(), f2()
+    assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b)
+
+
+# --------------------------------------------------------------------------------- gwnet module
+@pytest.mark.parametrize("V", [9, 42])
+@pytest.mark.parametrize("training", [True, False])
+def test_gwnet_vs_reference_golden(golden, V, training):
+    import hopmi
+    from oracle import fill
+    from oracle.golden_util import checksum, checksum_close
+    dev = _dev()
+    g = golden(f"gwnet_V{V}_{'train' if training else 'eval'}")
+    m = hopmi.gwnet(None, V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173,
+                    out_dim=173, residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512)
+    fill.fill_state_(m)
+    m.to(dev).train(training)
+    x0 = fill.uniform("gwnet.x0", (2, 173, V, 16)).to(dev).requires_grad_()
+    out = m(x0)
+    assert out.shape == (2, 173, V, 4) and out.is_contiguous()
+    assert_close(out, g["out"], what="out")
+    (out * fill.uniform("gwnet.gout", out.shape).to(dev)).sum().backward()
+    assert checksum_close(checksum(x0.grad), g["dx0_cs"], RTOL)
+    assert_close(x0.grad.flatten()[::97], g["dx0_sample"], what="dx0")
+    params = dict(m.named_parameters())
+    for n, want in zip(g["grad_names"], g["grad_cs"]):
+        assert checksum_close(checksum(params[str(n)].grad), want, RTOL), n
+    for n in g["nograd_names"]:
+        assert params[str(n)].grad is None, n
+    for i in range(8):
+        assert_close(m.bn[i].running_mean, g[f"bn{i}_rm"], what=f"bn{i} running_mean")
+        assert_close(m.bn[i].running_var, g[f"bn{i}_rv"], what=f"bn{i} running_var")
+
+
+# ---------------------------------------------------------------------------------- full model
+def _make_model(V, dev):
+    import hopmi
+    from transformers import BertModel
+    from oracle import fill
+    from oracle.golden_util import SynthTok, SynthVocab, hop_cfg, tiny_bert_config
+    bcfg = tiny_bert_config()
+    m = hopmi.Model(hop_cfg(V, bcfg.hidden_size), BertModel(bcfg), SynthTok(), SynthVocab(11)).float()
+    m.reprogramming_layer.dropout.p = 0.0
+    fill.fill_state_(m)
+    m._randn_like = lambda t: torch.randn(t.shape).to(t.device)      # replay the reference's CPU RNG stream
+    return m.to(dev), bcfg
+
+
+def _inputs(V, bcfg, dev):
+    from oracle import fill
+    inp = fill.hot_path_inputs(2, V, bcfg.vocab_size, 11)
+    return {k: v.to(dev) for k, v in inp.items()}
+
+
+@pytest.mark.parametrize("V", [9, 42])
+def test_model_vs_reference_golden(golden, V):
+    from oracle import fill
+    from oracle.golden_util import checksum, checksum_close
+    dev = _dev()
+    g = golden(f"model_V{V}")
+    m, bcfg = _make_model(V, dev)
+    m.train()
+    inp = _inputs(V, bcfg, dev)
+    torch.manual_seed(4321)
+    out, z, mu, lv = m(inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"][:, :16], inp["vid_indices"])
+    assert_close(out, g["out"], what="out"); assert_close(z, g["z"], what="z")
+    assert_close(mu, g["z_mu"], what="mu"); assert_close(lv, g["z_logvar"], what="logvar")
+    ((out * fill.uniform("model.gout", out.shape).to(dev)).sum() + 0.3 * z.sum() + 0.1 * (mu * mu).sum() + 0.2 * lv.exp().sum()).backward()
+    params = dict(m.named_parameters())
+    for n, want in zip(g["grad_names"], g["grad_cs"]):
+        assert checksum_close(checksum(params[str(n)].grad), want, RTOL), n
+    for n in g["nograd_names"]:
+        assert params[str(n)].grad is None, n
+    for i in range(8):
+        assert_close(m.gwnet.bn[i].running_mean, g[f"bn{i}_rm"], what=f"bn{i} rm")
+        assert_close(m.gwnet.bn[i].running_var, g[f"bn{i}_rv"], what=f"bn{i} rv")
+
+
+@pytest.mark.parametrize("V", [9, 42])
+def test_model_eval_vs_reference_golden(golden, V):
+    dev = _dev()
+    g = golden(f"model_V{V}_eval")
+    m, bcfg = _make_model(V, dev)
+    m.train(False)
+    inp = _inputs(V, bcfg, dev)
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        out, *_ = m(inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"][:, :16], inp["vid_indices"])
+    assert_close(out, g["out"], what="eval out")
+
+
+# ---------------------------------------------------------------------------------- train step
+def _zero_grad_param(name):
+    return name.endswith("mlp.mlp.bias") or name in ("pre_conv.0.bias", "pre_conv.3.bias")
+
+
+@pytest.mark.parametrize("V", [9, 42])
+@pytest.mark.parametrize("epoch", [0, 11])
+def test_train_llm_vs_reference_golden(golden, V, epoch, monkeypatch):
+    import hopmi
+    from hopmi import steps
+    from oracle import fill
+    from oracle.golden_util import Accel, checksum, checksum_close, step_args
+    dev = _dev()
+    g = golden(f"train_llm_V{V}_e{epoch}")
+    m, bcfg = _make_model(V, dev)
+    d = hopmi.ConvDiscriminator(3 * V)
+    d.gru.dropout = 0.0
+    fill.fill_state_(d, salt=1)
+    d.to(dev)
+    m.train(); d.train()
+    monkeypatch.setattr(steps, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
+    monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    inp = _inputs(V, bcfg, dev)
+    torch.manual_seed(777)
+    ret = hopmi.train_llm(step_args(V), epoch, inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"],
+                          inp["vid_indices"], m, d, g_opt, d_opt, Accel())
+    assert sorted(ret.keys()) == [str(k) for k in g["ret_keys"]]
+    for k, want in zip(g["ret_keys"], g["ret_vals"]):
+        assert abs(ret[str(k)] - want) <= RTOL * max(abs(want), 1e-6), (k, ret[str(k)], want)
+    for names, table, sd, lr in ((g["g_names"], g["g_cs"], m.state_dict(), 1e-3), (g["d_names"], g["d_cs"], d.state_dict(), 1e-4)):
+        for n, want in zip(names, table):
+            atol = 2.5 * lr * sd[str(n)].numel() if _zero_grad_param(str(n)) else 1e-4
+            assert checksum_close(checksum(sd[str(n)]), want, RTOL, atol), (n, checksum(sd[str(n)]), want)
+
+
+def test_native_library_is_loaded():
+    """The driver records which in-tree .so the GPU tests loaded: make sure it is ours."""
+    from hopmi import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libhopmi.so" in maps
