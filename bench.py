@@ -47,6 +47,9 @@ def cpu_baseline(args, V):
     from hopmi import synth
     from oracle import ref_cpu, spec
     B = args.cpu_batch
+    # the box's CPU share for one GPU is 16 cores; torch's default (all 128 hardware threads)
+    # oversubscribes it 8x
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     bcfg = BertConfig(num_hidden_layers=6)
     g_sd = spec.build_sd(spec.model_spec(V, bcfg, 1370))
     d_sd = spec.build_sd(spec.disc_spec(3 * V), salt=1)

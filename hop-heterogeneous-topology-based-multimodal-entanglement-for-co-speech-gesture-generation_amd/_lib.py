@@ -17,9 +17,11 @@ _VP = ctypes.c_void_p
 SIGNATURES = {
     "hopmi_version": (ctypes.c_char_p, []),
     "hopmi_last_error": (ctypes.c_char_p, []),
-    "hopmi_gcn_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "hopmi_gcn_prep_floats": (ctypes.c_size_t, [_I]),
+    "hopmi_gcn_prepare": (_I, [_VP, _VP, _VP, _I, _VP]),
+    "hopmi_gcn_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hopmi_gcn_bwd_ws_floats": (ctypes.c_size_t, [_I, _I]),
-    "hopmi_gcn_bwd": (_I, [_VP] * 11 + [_I, _I, _VP]),
+    "hopmi_gcn_bwd": (_I, [_VP] * 10 + [_I, _I, _VP]),
 }
 
 

@@ -18,9 +18,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 constexpr int C = HOPMI_C;        // 64 channels
 constexpr int K3 = 3 * C;         // 192 = [x | xA1 | xA2]
-constexpr int LDH = K3 + 1;       // LDS row stride of an [rows][192] tile: odd => the
-                                  // row-per-lane MFMA operand reads hit 32 distinct banks
-constexpr int LDD = C + 1;        // same for a [rows][64] tile
+constexpr int LDH = K3 + 4;       // LDS row stride of an [rows][192] tile: 16-B aligned rows (b128 operand
+                                  // reads), 196 = 4 (mod 64) so 16 consecutive rows land on 16 distinct
+                                  // 16-B bank slots
+constexpr int LDD = C + 4;        // same for a [rows][64] tile (68 = 4 mod 64)
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

@@ -20,6 +20,22 @@
 
 namespace hopmi {
 
+// Diagnostic build only (-DHOPMI_STAMPS, tools/probes/gcn_stamps.py): per-phase s_memtime stamps of
+// wave 0 of every block go to a side buffer that nothing else reads.  The product build has none.
+#ifdef HOPMI_STAMPS
+__device__ long long* g_stamps = nullptr;
+#define HOPMI_STAMP(slot)                                                                     \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    unsigned long long t_;                                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if (g_stamps && threadIdx.x == 0) g_stamps[blockIdx.x * 8 + (slot)] = (long long)t_;      \
+  } while (0)
+#else
+#define HOPMI_STAMP(slot) do { } while (0)
+#endif
+
 struct GcnGeom {
   int V;         // graph nodes
   int S;         // slabs per tile
@@ -56,39 +72,139 @@ static GcnGeom make_geom(int n_slabs, int V, int S) {
 // shared device pieces
 // ------------------------------------------------------------------------------------------
 
-// AT[k = v][m]: m < V -> A1[v][m] (row m of A1^T), V <= m < 2V -> A2[v][m-V]; zero padded.
-__device__ __forceinline__ void load_mix_matrix(float* AT, const float* __restrict__ A1, const float* __restrict__ A2,
-                                                const GcnGeom& g, int tid) {
+// Phase 0 is split into "issue every global load" and "write LDS" so that a block pays ONE memory
+// round trip.  Every load is UNCONDITIONAL (clamped address, value selected afterwards): a load under
+// a runtime guard makes hipcc branch around it and wait vmcnt(0) per element.
+
+// The node-mix matrices are tiny (V x V) and the same for every workgroup and every WaveNet layer of
+// a forward pass, so their zero-padded LDS images are built ONCE per pass by hopmi_gcn_prepare:
+//   prep = [ AT[KP][ldA] | AB[K2P][ldB] ]
+//   AT[k = v][m]: m < V -> A1[v][m] (row m of A1^T), V <= m < 2V -> A2[v][m-V]       (forward mix)
+//   AB[k][v]   : k < V -> A1[v][k],                 V <= k < 2V -> A2[v][k-V]       (dX mix, backward)
+// and a workgroup copies an image with at most PREP_IT coalesced 16-B loads per thread.
+constexpr int PREP_IT = 6;                          // V <= 48: 48*112/4 = 1344 float4 <= 6*256
+struct PrepRegs { float4 v[PREP_IT]; };
+
+__device__ __forceinline__ void prep_issue(PrepRegs& r, const float* __restrict__ img, int nfloats, int tid) {
+  const float4* src = reinterpret_cast<const float4*>(img);
+  const int n4 = nfloats >> 2;
+#pragma unroll
+  for (int it = 0; it < PREP_IT; ++it) {
+    const int idx = tid + 256 * it;
+    if (idx < n4) r.v[it] = src[idx];
+  }
+}
+
+__device__ __forceinline__ void prep_commit(float* dst, const PrepRegs& r, int nfloats, int tid) {
+  const int n4 = nfloats >> 2;
+#pragma unroll
+  for (int it = 0; it < PREP_IT; ++it) {
+    const int idx = tid + 256 * it;
+    if (idx < n4) reinterpret_cast<float4*>(dst)[idx] = r.v[it];
+  }
+}
+
+__global__ __launch_bounds__(256) void gcn_prepare_kernel(const float* __restrict__ A1, const float* __restrict__ A2,
+                                                          float* __restrict__ prep, GcnGeom g) {
   const int V = g.V;
-  for (int idx = tid; idx < g.KP * g.ldA; idx += 256) {
+  float* AT = prep;
+  float* AB = prep + g.KP * g.ldA;
+  for (int idx = threadIdx.x; idx < g.KP * g.ldA; idx += 256) {
     const int k = idx / g.ldA, m = idx - k * g.ldA;
     float v = 0.f;
     if (k < V && m < 2 * V) v = (m < V) ? A1[k * V + m] : A2[k * V + (m - V)];
     AT[idx] = v;
   }
-}
-
-// Stream `R` rows x 64 floats from `src` into dst[row*ld + c]; rows in [R, rows_total) zeroed.
-__device__ __forceinline__ void load_rows(float* dst, int ld, const float* __restrict__ src, int R, int rows_total, int tid) {
-  const float4* src4 = reinterpret_cast<const float4*>(src);
-  for (int idx = tid; idx < rows_total * (C / 4); idx += 256) {
-    const int row = idx >> 4, c4 = idx & 15;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < R) v = src4[(size_t)row * (C / 4) + c4];
-    float* d = dst + row * ld + 4 * c4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  for (int idx = threadIdx.x; idx < g.K2P * g.ldB; idx += 256) {
+    const int k = idx / g.ldB, v = idx - k * g.ldB;
+    float a = 0.f;
+    if (v < V && k < 2 * V) a = (k < V) ? A1[v * V + k] : A2[v * V + (k - V)];
+    AB[idx] = a;
   }
 }
 
+// `R` (>= 1) rows x 64 floats of `src` -> registers (NIT float4 per thread), rows >= R read as zero.
+template <int NIT>
+struct RowRegs { float4 v[NIT]; };
+
+template <int NIT>
+__device__ __forceinline__ void rows_issue(RowRegs<NIT>& r, const float* __restrict__ src, int R, int tid) {
+  const float4* src4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = tid + 256 * it;
+    const int row = idx >> 4, c4 = idx & 15;
+    const float4 v = src4[min(row, R - 1) * 16 + c4];
+    r.v[it] = (row < R) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int NIT>
+__device__ __forceinline__ void rows_commit(float* dst, int ld, const RowRegs<NIT>& r, int rows_total, int tid) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = tid + 256 * it;
+    const int row = idx >> 4, c4 = idx & 15;
+    if (row < rows_total) *reinterpret_cast<float4*>(dst + row * ld + 4 * c4) = r.v[it];
+  }
+}
+
+constexpr int rows_nit(int mt) { return ((16 * mt + 4) * 16 + 255) / 256; }
+
 // Node mix of the `nsl` slabs of a tile, wave `w` doing channels [16w, 16w+16):
 // Hc[s*V + node][64*(1+blk) + c] = sum_v A{blk+1}[v][node] * Hc[s*V + v][c].
-__device__ __forceinline__ void node_mix(float* Hc, const float* AT, const GcnGeom& g, int nsl, int w, int q, int j) {
+// KS = K steps ceil(V/4), MTN = row tiles ceil(2V/16) of the stacked mix matrix: the matrix stays
+// in registers for all slabs and the result rows are stored unconditionally (rows m >= 2V of the
+// padded M go to a dump row in the tile's padding: columns >= 64 of row `dump_row` are never read).
+template <int KS, int MTN>
+__device__ __forceinline__ void node_mix(float* Hc, const float* AT, const GcnGeom& g, int nsl, int dump_row,
+                                         int w, int q, int j) {
+  const int V = g.V;
+  float am[MTN][KS];
+  int woff[MTN][4];
+#pragma unroll
+  for (int mt = 0; mt < MTN; ++mt) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) am[mt][ks] = AT[(4 * ks + q) * g.ldA + 16 * mt + j];   // A[i = m][k]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * mt + 4 * q + r;
+      const int blk = (m >= V) ? 1 : 0;
+      woff[mt][r] = (m < 2 * V) ? ((m - blk * V) * LDH + C * (1 + blk) + 16 * w + j)
+                                : (dump_row * LDH + C + 16 * w + j);
+    }
+  }
+  for (int s = 0; s < nsl; ++s) {
+    float* hs = Hc + s * V * LDH;
+    float xb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[ks] = hs[(4 * ks + q) * LDH + 16 * w + j];           // B[k][n = c]
+    f32x4 acc[MTN];
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MTN; ++mt) acc[mt] = mfma16(am[mt][ks], xb[ks], acc[mt]);
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int off = woff[mt][r];
+        // a dump-row write of slab s must not land inside slab s+1.. : the dump row is beyond the tile
+        ((16 * mt + 4 * q + r) < 2 * V ? hs : Hc)[off] = acc[mt][r];
+      }
+  }
+}
+
+// generic V (runtime loops)
+__device__ __forceinline__ void node_mix_generic(float* Hc, const float* AT, const GcnGeom& g, int nsl, int w, int q, int j) {
   const int V = g.V;
   const int ksteps = g.KP >> 2, mt_n = g.MP >> 4;
   for (int s = 0; s < nsl; ++s) {
-    const float* xs = Hc + (s * V + q) * LDH + 16 * w + j;       // B[k = 4ks+q][n = c]
+    const float* xs = Hc + (s * V + q) * LDH + 16 * w + j;
     for (int mt = 0; mt < mt_n; ++mt) {
-      const float* at = AT + q * g.ldA + 16 * mt + j;            // A[i = m][k = 4ks+q]
+      const float* at = AT + q * g.ldA + 16 * mt + j;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       for (int ks = 0; ks < ksteps; ++ks) acc = mfma16(at[4 * ks * g.ldA], xs[4 * ks * LDH], acc);
 #pragma unroll
@@ -103,12 +219,19 @@ __device__ __forceinline__ void node_mix(float* Hc, const float* AT, const GcnGe
   }
 }
 
+__device__ __forceinline__ void node_mix_dispatch(float* Hc, const float* AT, const GcnGeom& g, int nsl, int w, int q, int j) {
+  const int dump_row = g.rows_lds - 1;
+  if (g.V == 9) node_mix<3, 2>(Hc, AT, g, nsl, dump_row, w, q, j);            // TED
+  else if (g.V == 42) node_mix<11, 6>(Hc, AT, g, nsl, dump_row, w, q, j);     // TED-Expressive
+  else node_mix_generic(Hc, AT, g, nsl, w, q, j);
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void gcn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ A1,
-                                                      const float* __restrict__ A2, const float* __restrict__ Wm,
+__global__ __launch_bounds__(256) void gcn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prep,
+                                                      const float* __restrict__ Wm,
                                                       const float* __restrict__ bm, float* __restrict__ h,
                                                       int n_slabs, GcnGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -121,55 +244,124 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(const float* __restrict__ 
   const int R = nsl * V;
   const size_t row0 = (size_t)slab0 * V;
 
-  // this wave's 192 x 16 slice of Wm^T: wreg[ks] = Wm[o = 16w + j][k = 48q + ks]
-  float wreg[48];
+  HOPMI_STAMP(0);
+  // this wave's 192 x 16 slice of Wm^T, K permuted so that MFMA step (i, e) pairs lane quad q with
+  // k = 16i + 4q + e:  wreg[i] = Wm[o = 16w + j][16i + 4q .. +3]   (one 16-B load each)
+  float4 wreg[12];
   {
-    const float4* wp = reinterpret_cast<const float4*>(Wm + (size_t)(16 * w + j) * K3 + 48 * q);
+    const float4* wp = reinterpret_cast<const float4*>(Wm + (size_t)(16 * w + j) * K3 + 4 * q);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const float4 v = wp[i];
-      wreg[4 * i] = v.x; wreg[4 * i + 1] = v.y; wreg[4 * i + 2] = v.z; wreg[4 * i + 3] = v.w;
-    }
+    for (int i = 0; i < 12; ++i) wreg[i] = wp[4 * i];
   }
   const float bias = bm[16 * w + j];
 
-  load_mix_matrix(AT, A1, A2, g, tid);
-  load_rows(Hc, LDH, x + row0 * C, R, g.rows_lds, tid);
+  {
+    PrepRegs mr;
+    RowRegs<rows_nit(MT)> xr;
+    rows_issue(xr, x + row0 * C, R, tid);
+    prep_issue(mr, prep, g.KP * g.ldA, tid);
+    HOPMI_STAMP(1);
+    rows_commit(Hc, LDH, xr, g.rows_lds, tid);
+    prep_commit(AT, mr, g.KP * g.ldA, tid);
+  }
   __syncthreads();
-  node_mix(Hc, AT, g, nsl, w, q, j);
+  HOPMI_STAMP(2);
+  node_mix_dispatch(Hc, AT, g, nsl, w, q, j);
   __syncthreads();
+  HOPMI_STAMP(3);
 
+  // MT == g.mtiles exactly (host dispatch): no guards in the MFMA stream
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
-  const float* ha = Hc + j * LDH + 48 * q;        // A[i = row][k = 48q + ks]
+  const float* ha = Hc + j * LDH + 4 * q;         // A[i = row][k = 16i + 4q + e]: one b128 per (mt, i)
 #pragma unroll
-  for (int ks = 0; ks < 48; ++ks) {
+  for (int i = 0; i < 12; ++i) {
+    float4 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      if (mt < g.mtiles) acc[mt] = mfma16(ha[16 * mt * LDH + ks], wreg[ks], acc[mt]);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(ha + 16 * mt * LDH + 16 * i);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt] = mfma16(a[mt].x, wreg[i].x, acc[mt]);
+      acc[mt] = mfma16(a[mt].y, wreg[i].y, acc[mt]);
+      acc[mt] = mfma16(a[mt].z, wreg[i].z, acc[mt]);
+      acc[mt] = mfma16(a[mt].w, wreg[i].w, acc[mt]);
+    }
   }
+  HOPMI_STAMP(4);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * mt + 4 * q + r;
-      if (mt < g.mtiles && row < R) h[(row0 + row) * C + 16 * w + j] = acc[mt][r] + bias;
+      if (row < R) h[(row0 + row) * C + 16 * w + j] = acc[mt][r] + bias;
     }
   }
+  HOPMI_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
-constexpr int BWD_MT = 4;          // <= 64 rows per tile
+constexpr int BWD_ROWS = 64;       // <= 64 rows per backward tile (LDS: two [rows][196] images + dH)
 constexpr int DA_SLOTS = 5;        // ceil(3*6/4): dA accumulator tiles per wave at V <= 48
+
+// dX[s] = G0 + A1 G1 + A2 G2 for the slabs of a tile; wave w owns channels 16w + [0,16).
+// KS = K steps (ceil(2V/4)) when known at compile time (0 = runtime loop).
+template <int KS>
+__device__ __forceinline__ void dx_mix(const float* Gs, const float* AB, float* __restrict__ dx, size_t row0,
+                                       const GcnGeom& g, int nsl, int w, int q, int j) {
+  const int V = g.V;
+  const int ksteps = KS ? KS : (g.K2P >> 2), mt_n = g.VP >> 4;
+  // lane-constant part of the B-operand address for every k step: row (node) and column block
+  for (int s = 0; s < nsl; ++s) {
+    float gb[KS ? KS : 1];
+    if (KS) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + q;
+        const int blk = (k >= V) ? 1 : 0;
+        const int wn = (k < 2 * V) ? (k - blk * V) : 0;          // padded k: AB is zero there
+        gb[ks] = Gs[(s * V + wn) * LDH + C * (1 + blk) + 16 * w + j];
+      }
+    }
+    for (int mt = 0; mt < mt_n; ++mt) {
+      f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int v = 16 * mt + 4 * q + r;
+        acc[r] = (v < V) ? Gs[(s * V + v) * LDH + 16 * w + j] : 0.f;
+      }
+      const float* ab = AB + q * g.ldB + 16 * mt + j;            // A[i = v][k = 4ks + q]
+      if (KS) {
+        float aa[KS ? KS : 1];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) aa[ks] = ab[4 * ks * g.ldB];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma16(aa[ks], gb[ks], acc);
+      } else {
+        for (int ks = 0; ks < ksteps; ++ks) {
+          const int k = 4 * ks + q;
+          const int blk = (k >= V) ? 1 : 0;
+          const int wn = (k < 2 * V) ? (k - blk * V) : 0;
+          acc = mfma16(ab[4 * ks * g.ldB], Gs[(s * V + wn) * LDH + C * (1 + blk) + 16 * w + j], acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int v = 16 * mt + 4 * q + r;
+        if (v < V) dx[(row0 + s * V + v) * C + 16 * w + j] = acc[r];
+      }
+    }
+  }
+}
 
 // Persistent over tiles: dWm / dbm / dA partial sums stay in registers across the block's
 // tiles and are written once to part[blockIdx.x][...] (summed by gcn_bwd_reduce_kernel in a
-// fixed order: reproducible, no atomics).
+// fixed order: reproducible, no atomics).  MT = 16-row MFMA tiles per block tile (exact).
+template <int MT>
 __global__ __launch_bounds__(256) void gcn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dh,
-                                                      const float* __restrict__ A1, const float* __restrict__ A2,
+                                                      const float* __restrict__ prep,
                                                       const float* __restrict__ Wm, float* __restrict__ dx,
                                                       float* __restrict__ part, int n_slabs, GcnGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -181,19 +373,23 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(const float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int V = g.V;
 
-  load_mix_matrix(AT, A1, A2, g, tid);
-  for (int idx = tid; idx < g.K2P * g.ldB; idx += 256) {
-    const int k = idx / g.ldB, v = idx - k * g.ldB;
-    float a = 0.f;
-    if (v < V && k < 2 * V) a = (k < V) ? A1[v * V + k] : A2[v * V + (k - V)];
-    AB[idx] = a;
+  {
+    PrepRegs mr, br;
+    prep_issue(mr, prep, g.KP * g.ldA, tid);
+    prep_issue(br, prep + g.KP * g.ldA, g.K2P * g.ldB, tid);
+    prep_commit(AT, mr, g.KP * g.ldA, tid);
+    prep_commit(AB, br, g.K2P * g.ldB, tid);
   }
-  // Wm slice for G = dH Wm: wreg[b][ks] = Wm[o = 16q + ks][64b + 16w + j]
-  float wreg[3][16];
+  // Wm slice for G = dH Wm, K (= o) permuted as o = 16i + 4q + e:
+  // wreg[b][i] = Wm[o = 16i + 4q + (0..3)][64b + 16w + j]
+  float4 wreg[3][4];
 #pragma unroll
   for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) wreg[b][ks] = Wm[(size_t)(16 * q + ks) * K3 + C * b + 16 * w + j];
+    for (int i = 0; i < 4; ++i) {
+      const float* wp = Wm + (size_t)(16 * i + 4 * q) * K3 + C * b + 16 * w + j;
+      wreg[b][i] = make_float4(wp[0], wp[K3], wp[2 * K3], wp[3 * K3]);
+    }
 
   f32x4 acc_dW[4][3];
 #pragma unroll
@@ -212,94 +408,85 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(const float* __restrict__ 
     const int nsl = min(g.S, n_slabs - slab0);
     const int R = nsl * V;
     const size_t row0 = (size_t)slab0 * V;
-    const int mtiles = (R + 15) >> 4;
 
-    __syncthreads();                               // previous tile fully consumed
-    load_rows(Hc, LDH, x + row0 * C, R, g.rows_lds, tid);
-    load_rows(DH, LDD, dh + row0 * C, R, g.rows_lds, tid);
+    {
+      RowRegs<rows_nit(MT)> xr, dr;
+      rows_issue(xr, x + row0 * C, R, tid);
+      rows_issue(dr, dh + row0 * C, R, tid);
+      __syncthreads();                             // previous tile fully consumed
+      rows_commit(Hc, LDH, xr, g.rows_lds, tid);
+      rows_commit(DH, LDD, dr, g.rows_lds, tid);
+    }
     // rows >= R of the mixed columns feed the dWm contraction (times dH = 0): keep them finite
     for (int idx = tid; idx < (g.rows_lds - R) * 2 * C; idx += 256) {
       const int row = R + idx / (2 * C), c = idx % (2 * C);
       Hc[row * LDH + C + c] = 0.f;
     }
-    for (int idx = tid; idx < 4 * K3; idx += 256) Gs[(16 * mtiles + idx / K3) * LDH + idx % K3] = 0.f;
     __syncthreads();
 
     // (1) recompute the forward node mix -> Hcat
-    node_mix(Hc, AT, g, nsl, w, q, j);
+    node_mix_dispatch(Hc, AT, g, nsl, w, q, j);
 
     // (2) G = dH (rows x 64) Wm (64 x 192); wave w owns columns 64b + 16w + [0,16)
     {
-      f32x4 acc[BWD_MT][3];
+      f32x4 acc[MT][3];
 #pragma unroll
-      for (int mt = 0; mt < BWD_MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[mt][b] = {0.f, 0.f, 0.f, 0.f};
-      const float* da = DH + j * LDD + 16 * q;     // A[i = row][k = o = 16q + ks]
+      const float* da = DH + j * LDD + 4 * q;      // A[i = row][k = o = 16i + 4q + e]
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
+      for (int i = 0; i < 4; ++i) {
+        float4 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < BWD_MT; ++mt) {
-          if (mt < mtiles) {
-            const float a = da[16 * mt * LDD + ks];
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(da + 16 * mt * LDD + 16 * i);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) acc[mt][b] = mfma16(a, wreg[b][ks], acc[mt][b]);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            acc[mt][b] = mfma16(a[mt].x, wreg[b][i].x, acc[mt][b]);
+            acc[mt][b] = mfma16(a[mt].y, wreg[b][i].y, acc[mt][b]);
+            acc[mt][b] = mfma16(a[mt].z, wreg[b][i].z, acc[mt][b]);
+            acc[mt][b] = mfma16(a[mt].w, wreg[b][i].w, acc[mt][b]);
           }
-        }
       }
 #pragma unroll
-      for (int mt = 0; mt < BWD_MT; ++mt)
-        if (mt < mtiles) {
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < 3; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Gs[(16 * mt + 4 * q + r) * LDH + C * b + 16 * w + j] = acc[mt][b][r];
-        }
+          for (int r = 0; r < 4; ++r) Gs[(16 * mt + 4 * q + r) * LDH + C * b + 16 * w + j] = acc[mt][b][r];
     }
     __syncthreads();
 
-    // (3) dX[s] = G0 + A1 G1 + A2 G2 ; wave w owns channels 16w + [0,16)
-    {
-      const int ksteps = g.K2P >> 2, mt_n = g.VP >> 4;
-      for (int s = 0; s < nsl; ++s) {
-        for (int mt = 0; mt < mt_n; ++mt) {
-          f32x4 acc;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int v = 16 * mt + 4 * q + r;
-            acc[r] = (v < V) ? Gs[(s * V + v) * LDH + 16 * w + j] : 0.f;
-          }
-          for (int ks = 0; ks < ksteps; ++ks) {
-            const int k = 4 * ks + q;
-            const int blk = (k >= V) ? 1 : 0;
-            const int wn = (k < 2 * V) ? (k - blk * V) : 0;     // padded k: AB is zero there
-            acc = mfma16(AB[k * g.ldB + 16 * mt + j], Gs[(s * V + wn) * LDH + C * (1 + blk) + 16 * w + j], acc);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int v = 16 * mt + 4 * q + r;
-            if (v < V) dx[(row0 + s * V + v) * C + 16 * w + j] = acc[r];
-          }
-        }
-      }
-    }
+    // (3) dX[s] = G0 + A1 G1 + A2 G2
+    if (g.K2P == 20) dx_mix<5>(Gs, AB, dx, row0, g, nsl, w, q, j);          // V = 9
+    else if (g.K2P == 84) dx_mix<21>(Gs, AB, dx, row0, g, nsl, w, q, j);    // V = 42
+    else dx_mix<0>(Gs, AB, dx, row0, g, nsl, w, q, j);
 
-    // (4) dA{1,2}[v][w'] += sum_{s,c} X[s,v,c] G{1,2}[s,w',c]; output tiles dealt round-robin to waves
+    // (4) dA{1,2}[v][w'] += sum_{s,c} X[s,v,c] G{1,2}[s,w',c]; output tiles dealt round-robin to waves;
+    //     K (= c) permuted as c = 16i + 4q + e -> b128 operand reads
 #pragma unroll
     for (int sl = 0; sl < DA_SLOTS; ++sl) {
       const int t = w + 4 * sl;
       if (t < ntiles_dA) {
         const int mtA = t / nt_dA, ntA = t - mtA * nt_dA;
         const int v = min(16 * mtA + j, V - 1);                  // rows >= V are discarded
-        int m = 16 * ntA + j;                                    // column of [dA1 | dA2]
-        m = min(m, 2 * V - 1);                                   // columns >= 2V are discarded
+        const int m = min(16 * ntA + j, 2 * V - 1);              // columns >= 2V of [dA1 | dA2] are discarded
         const int blk = (m >= V) ? 1 : 0;
-        const float* xa = Hc + v * LDH + q;                      // A[i = v][k = c = 4ks + q]
-        const float* gb = Gs + (m - blk * V) * LDH + C * (1 + blk) + q;   // B[k = c][n = m]
+        const float* xa = Hc + v * LDH + 4 * q;                              // A[i = v][k = c]
+        const float* gb = Gs + (m - blk * V) * LDH + C * (1 + blk) + 4 * q;  // B[k = c][n = m]
         f32x4 acc = acc_dA[sl];
         for (int s = 0; s < nsl; ++s) {
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) acc = mfma16(xa[s * V * LDH + 4 * ks], gb[s * V * LDH + 4 * ks], acc);
+          for (int i = 0; i < 4; ++i) {
+            const float4 a = *reinterpret_cast<const float4*>(xa + s * V * LDH + 16 * i);
+            const float4 b = *reinterpret_cast<const float4*>(gb + s * V * LDH + 16 * i);
+            acc = mfma16(a.x, b.x, acc);
+            acc = mfma16(a.y, b.y, acc);
+            acc = mfma16(a.z, b.z, acc);
+            acc = mfma16(a.w, b.w, acc);
+          }
         }
         acc_dA[sl] = acc;
       }
@@ -309,7 +496,8 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(const float* __restrict__ 
     {
       const float* da = DH + q * LDD + j;          // A[i = o][k = row = 4ks + q]
       const float* hb = Hc + q * LDH + 48 * w + j; // B[k = row][n = kk]
-      for (int ks = 0; ks < 4 * mtiles; ++ks) {
+#pragma unroll 4
+      for (int ks = 0; ks < 4 * MT; ++ks) {
         float a[4], b[3];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) a[mt] = da[4 * ks * LDD + 16 * mt];
@@ -394,7 +582,7 @@ static int pick_fwd_slabs(int n_slabs, int V) {
   return best;
 }
 
-static int bwd_slabs(int V) { return (16 * BWD_MT) / V > 0 ? (16 * BWD_MT) / V : 1; }
+static int bwd_slabs(int V) { return BWD_ROWS / V > 0 ? BWD_ROWS / V : 1; }
 
 static int bwd_grid(int ntiles) { return ntiles < env_int("HOPMI_GCN_BWD_GRID", 256) ? ntiles : env_int("HOPMI_GCN_BWD_GRID", 256); }
 
@@ -407,32 +595,73 @@ static int validate(const void* const* ptrs, int nptr, int n_slabs, int V) {
 }
 
 template <int MT>
-static int launch_fwd(const float* x, const float* A1, const float* A2, const float* Wm, const float* bm, float* h,
+static int launch_fwd(const float* x, const float* prep, const float* Wm, const float* bm, float* h,
                       int n_slabs, const GcnGeom& g, hipStream_t st) {
   const size_t lds = (size_t)(g.rows_lds * LDH + g.KP * g.ldA) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_fwd_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+  // only raise the dynamic-LDS cap when a launch needs it, and only to what it needs
+  static size_t attr_lds = 64 * 1024;
+  if (lds > attr_lds && env_int("HOPMI_NO_LDS_ATTR", 0) == 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_fwd_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
   }
-  hipLaunchKernelGGL(gcn_fwd_kernel<MT>, dim3(g.ntiles), dim3(256), lds, st, x, A1, A2, Wm, bm, h, n_slabs, g);
+  hipLaunchKernelGGL(gcn_fwd_kernel<MT>, dim3(g.ntiles), dim3(256), lds, st, x, prep, Wm, bm, h, n_slabs, g);
   return check_launch("hopmi_gcn_fwd");
+}
+
+template <int MT>
+static void launch_bwd(const float* x, const float* dh, const float* prep, const float* Wm, float* dx,
+                       float* ws, int n_slabs, const GcnGeom& g, int grid, size_t lds, hipStream_t st) {
+  static size_t attr_lds = 64 * 1024;
+  if (lds > attr_lds && env_int("HOPMI_NO_LDS_ATTR", 0) == 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_bwd_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(gcn_bwd_kernel<MT>, dim3(grid), dim3(256), lds, st, x, dh, prep, Wm, dx, ws, n_slabs, g);
 }
 
 }  // namespace hopmi
 
 using namespace hopmi;
 
-extern "C" int hopmi_gcn_fwd(const float* x, const float* A1, const float* A2, const float* Wm, const float* bm,
+extern "C" size_t hopmi_gcn_prep_floats(int V) {
+  if (V < 1 || V > HOPMI_MAX_NODES) return 0;
+  const GcnGeom g = make_geom(1, V, 1);
+  return (size_t)g.KP * g.ldA + (size_t)g.K2P * g.ldB;
+}
+
+extern "C" int hopmi_gcn_prepare(const float* A1, const float* A2, float* prep, int V, void* stream) {
+  const void* ptrs[] = {A1, A2, prep};
+  if (int e = validate(ptrs, 3, 1, V)) return e;
+  hipLaunchKernelGGL(gcn_prepare_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), A1, A2, prep,
+                     make_geom(1, V, 1));
+  return check_launch("hopmi_gcn_prepare");
+}
+
+extern "C" int hopmi_gcn_fwd(const float* x, const float* prep, const float* Wm, const float* bm,
                              float* h, int n_slabs, int V, void* stream) {
-  const void* ptrs[] = {x, A1, A2, Wm, bm, h};
-  if (int e = validate(ptrs, 6, n_slabs, V)) return e;
+  const void* ptrs[] = {x, prep, Wm, bm, h};
+  if (int e = validate(ptrs, 5, n_slabs, V)) return e;
   const GcnGeom g = make_geom(n_slabs, V, pick_fwd_slabs(n_slabs, V));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (g.mtiles <= 2) return launch_fwd<2>(x, A1, A2, Wm, bm, h, n_slabs, g, st);
-  if (g.mtiles <= 4) return launch_fwd<4>(x, A1, A2, Wm, bm, h, n_slabs, g, st);
-  return launch_fwd<8>(x, A1, A2, Wm, bm, h, n_slabs, g, st);
+  switch (g.mtiles) {
+    case 1: return launch_fwd<1>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 2: return launch_fwd<2>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 3: return launch_fwd<3>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 4: return launch_fwd<4>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 5: return launch_fwd<5>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 6: return launch_fwd<6>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 7: return launch_fwd<7>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 8: return launch_fwd<8>(x, prep, Wm, bm, h, n_slabs, g, st);
+  }
+  set_error("hopmi_gcn_fwd: internal: %d m-tiles", g.mtiles);
+  return HOPMI_EINVAL;
 }
+
+#ifdef HOPMI_STAMPS
+extern "C" int hopmi_debug_set_stamps(long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" size_t hopmi_gcn_bwd_ws_floats(int n_slabs, int V) {
   if (n_slabs <= 0 || V < 1 || V > HOPMI_MAX_NODES) return 0;
@@ -440,22 +669,23 @@ extern "C" size_t hopmi_gcn_bwd_ws_floats(int n_slabs, int V) {
   return (size_t)bwd_grid(g.ntiles) * (C * K3 + C + 2 * V * V);
 }
 
-extern "C" int hopmi_gcn_bwd(const float* x, const float* dh, const float* A1, const float* A2, const float* Wm,
+extern "C" int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const float* Wm,
                              float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
                              int n_slabs, int V, void* stream) {
-  const void* ptrs[] = {x, dh, A1, A2, Wm, dx, dA1, dA2, dWm, dbm, ws};
-  if (int e = validate(ptrs, 11, n_slabs, V)) return e;
+  const void* ptrs[] = {x, dh, prep, Wm, dx, dA1, dA2, dWm, dbm, ws};
+  if (int e = validate(ptrs, 10, n_slabs, V)) return e;
   const GcnGeom g = make_geom(n_slabs, V, bwd_slabs(V));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = bwd_grid(g.ntiles);
   const size_t lds = (size_t)(2 * g.rows_lds * LDH + g.rows_lds * LDD + g.KP * g.ldA + g.K2P * g.ldB) * sizeof(float);
   if (lds > 160 * 1024) { set_error("hopmi_gcn_bwd: LDS footprint %zu exceeds 160 KiB", lds); return HOPMI_EINVAL; }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+  switch (g.mtiles) {
+    case 1: launch_bwd<1>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    case 2: launch_bwd<2>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    case 3: launch_bwd<3>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    case 4: launch_bwd<4>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    default: set_error("hopmi_gcn_bwd: internal: %d m-tiles", g.mtiles); return HOPMI_EINVAL;
   }
-  hipLaunchKernelGGL(gcn_bwd_kernel, dim3(grid), dim3(256), lds, st, x, dh, A1, A2, Wm, dx, ws, n_slabs, g);
   if (int e = check_launch("hopmi_gcn_bwd")) return e;
   const int psz = C * K3 + C + 2 * V * V;
   hipLaunchKernelGGL(gcn_bwd_reduce_kernel, dim3((psz + 255) / 256), dim3(256), 0, st, ws, grid, V, dWm, dbm, dA1, dA2);

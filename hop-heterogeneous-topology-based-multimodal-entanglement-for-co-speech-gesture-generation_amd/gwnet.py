@@ -53,10 +53,10 @@ class gcn(nn.Module):
             raise NotImplementedError("hopmi gcn kernel: only c_in=c_out=64, order=2, one support (the HOP.py:143 "
                                       "configuration) is built")
 
-    def forward_cl(self, x_cl, A1, A2):
+    def forward_cl(self, x_cl, A1, A2, prep=None):
         """x_cl (B,T,V,64) channels-last -> (B,T,V,64)."""
         self._check()
-        h = ops.gcn(x_cl, A1, A2, self.mlp.mlp.weight, self.mlp.mlp.bias)
+        h = ops.gcn(x_cl, A1, A2, self.mlp.mlp.weight, self.mlp.mlp.bias, prep)
         return F.dropout(h, self.dropout, training=self.training) if self.dropout > 0 else h
 
     def forward(self, x, support):
@@ -135,6 +135,7 @@ class gwnet(nn.Module):
             x = F.pad(x, (0, 0, 0, 0, self.receptive_field - x.shape[1], 0))          # gwnet.py:145-146
         x = F.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias)        # gwnet.py:149
         A1, A2 = self.adjacency()
+        prep = ops.gcn_prepare(A1, A2)          # on-chip images of the mix matrices, shared by all layers
         T_out = x.shape[1] - sum(DILATIONS)
         tails = []
         last = len(DILATIONS) - 1
@@ -153,9 +154,9 @@ class gwnet(nn.Module):
                 # advances bn[7]'s running statistics in training mode, so do that (no autograd).
                 if self.training:
                     with torch.no_grad():
-                        self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2) + hi)
+                        self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2, prep) + hi)
                 break
-            x = self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2) + hi)           # gwnet.py:226-237
+            x = self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2, prep) + hi)           # gwnet.py:226-237
         ws = torch.cat([c.weight.flatten(1) for c in self.skip_convs], 1)               # (256, 8*64)
         bs = torch.stack([c.bias for c in self.skip_convs]).sum(0)
         s = F.relu(F.linear(torch.cat(tails, -1), ws, bs))                              # gwnet.py:209-220,240

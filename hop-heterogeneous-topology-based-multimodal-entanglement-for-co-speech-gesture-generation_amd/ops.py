@@ -67,49 +67,73 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def gcn_prepare(A1: torch.Tensor, A2: torch.Tensor) -> torch.Tensor:
+    """Padded on-chip images of the node-mix matrices (hopmi_gcn_prepare); build once per forward
+    pass and hand to every `gcn(..., prep=...)` call of that pass.  Not differentiable: gradients
+    w.r.t. A1 / A2 come out of the gcn backward kernel."""
+    A1, A2 = _dev_f32(A1.detach(), "A1"), _dev_f32(A2.detach(), "A2")
+    V = A1.shape[0]
+    if A1.shape != (V, V) or A2.shape != (V, V):
+        raise _lib.HopmiError(f"hopmi gcn_prepare: A1{tuple(A1.shape)} A2{tuple(A2.shape)} must both be (V,V)")
+    L = _lib.lib()
+    n = L.hopmi_gcn_prep_floats(V)
+    if n == 0:
+        raise _lib.HopmiError(f"hopmi gcn_prepare: V={V} unsupported (1..48)")
+    prep = torch.empty(n, dtype=torch.float32, device=A1.device)
+    _lib.check(L.hopmi_gcn_prepare(A1.data_ptr(), A2.data_ptr(), prep.data_ptr(), V, _stream()), "hopmi_gcn_prepare")
+    return prep
+
+
 class _GcnFn(torch.autograd.Function):
     """h = Wm.[x ; xA1 ; xA2] + bm on channels-last slabs (gwnet.py:24-46)."""
 
     @staticmethod
-    def forward(ctx, x, A1, A2, Wm, bm):
-        x, A1, A2, Wm, bm = (_dev_f32(t, n) for t, n in ((x, "x"), (A1, "A1"), (A2, "A2"), (Wm, "Wm"), (bm, "bm")))
+    def forward(ctx, x, A1, A2, Wm, bm, prep):
+        x, Wm, bm = (_dev_f32(t, n) for t, n in ((x, "x"), (Wm, "Wm"), (bm, "bm")))
         V = A1.shape[0]
         if x.shape[-1] != 64 or x.shape[-2] != V or A1.shape != (V, V) or A2.shape != (V, V):
             raise _lib.HopmiError(f"hopmi gcn: bad shapes x{tuple(x.shape)} A1{tuple(A1.shape)} A2{tuple(A2.shape)}")
         if Wm.numel() != 64 * 192 or bm.numel() != 64:
             raise _lib.HopmiError(f"hopmi gcn: Wm must have 64*192 elements, bm 64 (got {Wm.numel()}, {bm.numel()})")
+        L, st = _lib.lib(), _stream()
+        if prep.numel() != L.hopmi_gcn_prep_floats(V) or not prep.is_cuda:
+            raise _lib.HopmiError("hopmi gcn: `prep` does not come from gcn_prepare for this V")
         n_slabs = x.numel() // (V * 64)
         h = torch.empty_like(x)
-        L, st = _lib.lib(), _stream()
         _lib.check(_timed("gcn_fwd", gcn_algorithmic_bytes(n_slabs, V), gcn_flops(n_slabs, V),
-                          lambda: L.hopmi_gcn_fwd(x.data_ptr(), A1.data_ptr(), A2.data_ptr(), Wm.data_ptr(),
-                                                  bm.data_ptr(), h.data_ptr(), n_slabs, V, st)), "hopmi_gcn_fwd")
-        ctx.save_for_backward(x, A1, A2, Wm)
-        ctx.wm_shape = Wm.shape
+                          lambda: L.hopmi_gcn_fwd(x.data_ptr(), prep.data_ptr(), Wm.data_ptr(), bm.data_ptr(),
+                                                  h.data_ptr(), n_slabs, V, st)), "hopmi_gcn_fwd")
+        ctx.save_for_backward(x, prep, Wm)
+        ctx.wm_shape, ctx.V = Wm.shape, V
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        x, A1, A2, Wm = ctx.saved_tensors
+        x, prep, Wm = ctx.saved_tensors
         dh = _dev_f32(dh, "dh")
-        V = A1.shape[0]
+        V = ctx.V
         n_slabs = x.numel() // (V * 64)
         L = _lib.lib()
         ws = torch.empty(L.hopmi_gcn_bwd_ws_floats(n_slabs, V), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
-        dA1, dA2 = torch.empty_like(A1), torch.empty_like(A2)
+        dA1 = torch.empty(V, V, dtype=torch.float32, device=x.device)
+        dA2 = torch.empty_like(dA1)
         dWm = torch.empty(ctx.wm_shape, dtype=torch.float32, device=x.device)
         dbm = torch.empty(64, dtype=torch.float32, device=x.device)
         st = _stream()
         # backward: read x', dh, write dx' (+ tiny dA, dWm, dbm) = 1.5x forward bytes, ~2x forward FLOPs
         _lib.check(_timed("gcn_bwd", n_slabs * 3 * 64 * V * 4, 2 * gcn_flops(n_slabs, V),
-                          lambda: L.hopmi_gcn_bwd(x.data_ptr(), dh.data_ptr(), A1.data_ptr(), A2.data_ptr(),
-                                                  Wm.data_ptr(), dx.data_ptr(), dA1.data_ptr(), dA2.data_ptr(),
+                          lambda: L.hopmi_gcn_bwd(x.data_ptr(), dh.data_ptr(), prep.data_ptr(), Wm.data_ptr(),
+                                                  dx.data_ptr(), dA1.data_ptr(), dA2.data_ptr(),
                                                   dWm.data_ptr(), dbm.data_ptr(), ws.data_ptr(), n_slabs, V, st)),
                    "hopmi_gcn_bwd")
-        return dx, dA1, dA2, dWm, dbm
+        return dx, dA1, dA2, dWm, dbm, None
 
 
-def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, bm: torch.Tensor) -> torch.Tensor:
-    """x (..., V, 64) channels-last; A1 = adp, A2 = adp @ adp (V,V); Wm (64,192[,1,1]); bm (64,)."""
-    return _GcnFn.apply(x, A1, A2, Wm, bm)
+def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, bm: torch.Tensor,
+        prep: torch.Tensor = None) -> torch.Tensor:
+    """x (..., V, 64) channels-last; A1 = adp, A2 = adp @ adp (V,V); Wm (64,192[,1,1]); bm (64,).
+    `prep` = gcn_prepare(A1, A2), shared by all calls of one forward pass (built here if absent)."""
+    if prep is None:
+        prep = gcn_prepare(A1, A2)
+    return _GcnFn.apply(x, A1, A2, Wm, bm, prep)

@@ -46,7 +46,12 @@ const char* hopmi_last_error(void);
  * The reference computes x2 = (x A) A; passing A2 = A @ A (a V x V product done by the
  * caller, so autograd sees it) is the same contraction re-associated.
  */
-int hopmi_gcn_fwd(const float* x, const float* A1, const float* A2, const float* Wm, const float* bm,
+/* The V x V matrices are the same for all workgroups and all 8 WaveNet layers of a forward pass
+ * (gwnet.py:161-164 computes adp once per forward): hopmi_gcn_prepare writes their zero-padded
+ * on-chip images into `prep` (hopmi_gcn_prep_floats(V) floats) once; fwd/bwd take `prep`. */
+size_t hopmi_gcn_prep_floats(int V);
+int hopmi_gcn_prepare(const float* A1, const float* A2, float* prep, int V, void* stream);
+int hopmi_gcn_fwd(const float* x, const float* prep, const float* Wm, const float* bm,
                   float* h, int n_slabs, int V, void* stream);
 
 /* Backward of the above w.r.t. everything (autograd of gwnet.py:33-46):
@@ -57,7 +62,7 @@ int hopmi_gcn_fwd(const float* x, const float* A1, const float* A2, const float*
  * partials that a second, fixed-order pass sums (bitwise reproducible, no atomics).
  */
 size_t hopmi_gcn_bwd_ws_floats(int n_slabs, int V);
-int hopmi_gcn_bwd(const float* x, const float* dh, const float* A1, const float* A2, const float* Wm,
+int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const float* Wm,
                   float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
                   int n_slabs, int V, void* stream);
 

@@ -34,10 +34,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_bad_arguments_are_rejected_without_a_gpu():
     L = _lib.lib()
-    assert L.hopmi_gcn_fwd(None, None, None, None, None, None, 4, 9, None) == -1
+    assert L.hopmi_gcn_fwd(None, None, None, None, None, 4, 9, None) == -1
     assert b"null pointer" in L.hopmi_last_error()
-    assert L.hopmi_gcn_bwd_ws_floats(4, 9) == 4 // 4 * 0 + 1 * (64 * 192 + 64 + 2 * 81)
+    assert L.hopmi_gcn_bwd_ws_floats(4, 9) == 64 * 192 + 64 + 2 * 81        # one workgroup tile
     assert L.hopmi_gcn_bwd_ws_floats(4, 49) == 0
+    assert L.hopmi_gcn_prep_floats(9) == 12 * 48 + 20 * 16 and L.hopmi_gcn_prep_floats(49) == 0
 
 
 @pytest.mark.parametrize("V", [9, 42])
@@ -59,6 +60,8 @@ def test_hot_path_refuses_cpu_tensors():
     A = torch.eye(9)
     with pytest.raises(_lib.HopmiError, match="no CPU fallback"):
         hopmi.ops.gcn(x, A, A, torch.zeros(64, 192), torch.zeros(64))
+    with pytest.raises(_lib.HopmiError, match="no CPU fallback"):
+        hopmi.ops.gcn_prepare(A, A)
 
 
 def test_discriminator_cpu_matches_golden(golden):
