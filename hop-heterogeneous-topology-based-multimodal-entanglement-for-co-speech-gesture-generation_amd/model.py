@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import gwnet as _gwnet
+from . import ops
 
 
 def reparameterize(mu, logvar, randn_like=torch.randn_like):
@@ -204,6 +205,6 @@ class Model(nn.Module):
         if z_context is not None:
             parts.append(z_context.unsqueeze(1).expand(B, 34, z_context.shape[1]))
         dec_in = torch.cat(parts, dim=2).to(torch.float32).contiguous()
-        dec_out, _ = self.gru(dec_in, None)                                     # HOP.py:248
+        dec_out = ops.gru_bidirectional(dec_in, self.gru)                       # HOP.py:248 (h0 = 0)
         dec_out = dec_out[:, :, :self.hidden_size] + dec_out[:, :, self.hidden_size:]
         return self.out(dec_out), z_context, z_mu, z_logvar

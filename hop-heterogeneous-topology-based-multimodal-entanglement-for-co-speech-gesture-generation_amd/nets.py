@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 from torch.nn.utils import weight_norm
 
+from . import ops
 from .model import WavEncoder, reparameterize
 
 
@@ -168,7 +169,10 @@ class ConvDiscriminator(nn.Module):
 
     def forward(self, poses, in_text=None):
         feat = self.pre_conv(poses.transpose(1, 2)).transpose(1, 2)
-        output, _ = self.gru(feat, None)
+        if feat.is_cuda:        # same cell as the decoder: hand-written recurrence (multimodal_context_net.py:257)
+            output = ops.gru_bidirectional(feat, self.gru, self.gru.dropout, self.training)
+        else:                   # host-side use (CPU unit test of the stock-op part); never on the GPU path
+            output, _ = self.gru(feat, None)
         output = output[:, :, :self.hidden_size] + output[:, :, self.hidden_size:]
         output = self.out(output.contiguous().view(-1, output.shape[2])).view(poses.shape[0], -1)
         return torch.sigmoid(self.out2(output))

@@ -137,3 +137,76 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
     if prep is None:
         prep = gcn_prepare(A1, A2)
     return _GcnFn.apply(x, A1, A2, Wm, bm, prep)
+
+
+# ------------------------------------------------------------------------------------------- GRU
+class _GruLayerFn(torch.autograd.Function):
+    """Recurrence of one bidirectional GRU layer (hopmi_gru_fwd / hopmi_gru_bwd).
+
+    gi (B,T,2,3H) = input projections of both directions; whh (2,3H,H); bhh (2,3H) -> y (B,T,2H)."""
+
+    @staticmethod
+    def forward(ctx, gi, whh, bhh):
+        gi, whh, bhh = _dev_f32(gi, "gi"), _dev_f32(whh, "whh"), _dev_f32(bhh, "bhh")
+        B, T, two, H3 = gi.shape
+        H = H3 // 3
+        if two != 2 or whh.shape != (2, 3 * H, H) or bhh.shape != (2, 3 * H):
+            raise _lib.HopmiError(f"hopmi gru: bad shapes gi{tuple(gi.shape)} whh{tuple(whh.shape)} bhh{tuple(bhh.shape)}")
+        y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=gi.device)
+        gates = torch.empty(B, T, 2, 4 * H, dtype=torch.float32, device=gi.device)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("gru_fwd", 0, 2 * T * B * 2 * 3 * H * H,
+                          lambda: L.hopmi_gru_fwd(gi.data_ptr(), whh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
+                                                  gates.data_ptr(), B, T, H, st)), "hopmi_gru_fwd")
+        ctx.save_for_backward(y, gates, whh)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, gates, whh = ctx.saved_tensors
+        dy = _dev_f32(dy, "dy")
+        B, T, H2 = y.shape
+        H = H2 // 2
+        L, st = _lib.lib(), _stream()
+        whhT = whh.transpose(1, 2).contiguous()
+        dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
+        dgh = torch.empty_like(dgi)
+        ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
+        _lib.check(_timed("gru_bwd", 0, 2 * T * B * 2 * 3 * H * H,
+                          lambda: L.hopmi_gru_bwd(dy.data_ptr(), y.data_ptr(), gates.data_ptr(), whhT.data_ptr(),
+                                                  dgi.data_ptr(), dgh.data_ptr(), ws.data_ptr(), B, T, H, st)),
+                   "hopmi_gru_bwd")
+        # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
+        # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
+        yv = y.view(B, T, 2, H)
+        hprev = torch.zeros_like(yv)
+        hprev[:, 1:, 0] = yv[:, :-1, 0]
+        hprev[:, :-1, 1] = yv[:, 1:, 1]
+        dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
+        dbhh = dgh.sum(dim=(0, 1))
+        return dgi, dwhh, dbhh
+
+
+def gru_layer(gi: torch.Tensor, whh: torch.Tensor, bhh: torch.Tensor) -> torch.Tensor:
+    return _GruLayerFn.apply(gi, whh, bhh)
+
+
+def gru_bidirectional(x: torch.Tensor, gru: torch.nn.GRU, dropout_p: float = 0.0, training: bool = False) -> torch.Tensor:
+    """torch.nn.GRU(batch_first=True, bidirectional=True) forward with h0 = 0 on the HIP recurrence.
+
+    x (B,T,in) -> (B,T,2H).  The input projections of all time steps and both directions are one GEMM
+    (hipBLASLt); inter-layer dropout follows nn.GRU (on every layer's output but the last)."""
+    if not (gru.bidirectional and gru.batch_first and gru.bias):
+        raise _lib.HopmiError("hopmi gru: only batch_first, bidirectional, biased nn.GRU modules are supported")
+    H = gru.hidden_size
+    inp = x
+    for layer in range(gru.num_layers):
+        p = lambda n: getattr(gru, f"{n}_l{layer}")
+        pr = lambda n: getattr(gru, f"{n}_l{layer}_reverse")
+        w_ih = torch.cat([p("weight_ih"), pr("weight_ih")], 0)
+        b_ih = torch.cat([p("bias_ih"), pr("bias_ih")], 0)
+        gi = torch.nn.functional.linear(inp, w_ih, b_ih).view(inp.shape[0], inp.shape[1], 2, 3 * H)
+        inp = gru_layer(gi, torch.stack([p("weight_hh"), pr("weight_hh")]), torch.stack([p("bias_hh"), pr("bias_hh")]))
+        if dropout_p > 0 and training and layer < gru.num_layers - 1:
+            inp = torch.nn.functional.dropout(inp, dropout_p, True)
+    return inp

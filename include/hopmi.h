@@ -66,6 +66,27 @@ int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const floa
                   float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
                   int n_slabs, int V, void* stream);
 
+/* ---- bidirectional GRU layer recurrence: model/HOP.py:166-167,248 (decoder nn.GRU, hidden 350) and
+ *      model/multimodal_context_net.py:236-237,257 (discriminator nn.GRU, hidden 64); torch.nn.GRU
+ *      semantics, gate order r,z,n, h0 = 0.
+ *
+ *   gi    [B][T][2][3H]  input projections x W_ih^T + b_ih of both directions (one GEMM by the caller)
+ *   whh   [2][3H][H], bhh [2][3H]
+ *   y     [B][T][2H]     layer output, forward direction in [:H], reverse in [H:]  (torch layout)
+ *   gates [B][T][2][4H]  saved for the backward: r, z, n and (W_hn h + b_hn)
+ * One launch per time step is enqueued on `stream` (both directions per launch).
+ */
+int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates,
+                  int B, int T, int H, void* stream);
+
+/* Back-propagation through time of the above.  dy [B][T][2H] -> dgi [B][T][2][3H] (gradient w.r.t. the
+ * input projections) and dgh [B][T][2][3H] (w.r.t. the recurrent pre-activations); the caller turns them
+ * into dx, dW_ih, db_ih, dW_hh, db_hh with four GEMMs / reductions.  whhT [2][H][3H] is W_hh transposed
+ * per direction; ws holds hopmi_gru_bwd_ws_floats(B, H) floats. */
+size_t hopmi_gru_bwd_ws_floats(int B, int H);
+int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
+                  float* dgi, float* dgh, float* ws, int B, int T, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,6 +102,35 @@ def test_gcn_full_size_properties(V, B):
     assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b)
 
 
+# ------------------------------------------------------------------------------------ GRU kernels
+@pytest.mark.parametrize("B,T,I,H,L", [(3, 5, 7, 6, 2), (37, 34, 20, 350, 2), (5, 28, 8, 64, 4), (130, 9, 12, 18, 1)])
+def test_gru_fwd_bwd_vs_oracle(B, T, I, H, L):
+    """hopmi_gru_fwd / hopmi_gru_bwd (through ops.gru_bidirectional) vs the oracle's explicit GRU cell."""
+    from hopmi import ops
+    from oracle import fill, ref_cpu, spec
+    dev = _dev()
+    sd = spec.build_sd(spec.gru_spec("", I, H, L), gains={"weight_hh": 2.0, "weight_ih": 2.0})
+    x = fill.normal("gru.x", (B, T, I))
+    gout = fill.uniform("gru.gout", (B, T, 2 * H))
+    # oracle
+    xo = x.clone().requires_grad_()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    yo = ref_cpu.gru_bidir(sdo, xo, "", L, H)
+    (yo * gout).sum().backward()
+    # HIP
+    gru = torch.nn.GRU(I, H, num_layers=L, batch_first=True, bidirectional=True)
+    gru.load_state_dict(sd)
+    gru.to(dev)
+    xg = x.to(dev).requires_grad_()
+    yg = ops.gru_bidirectional(xg, gru)
+    (yg * gout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(yg, yo, what="y")
+    assert_close(xg.grad, xo.grad, what="dx")
+    for n, p in gru.named_parameters():
+        assert_close(p.grad, sdo[n].grad, what=n)
+
+
 # --------------------------------------------------------------------------------- gwnet module
 @pytest.mark.parametrize("V", [9, 42])
 @pytest.mark.parametrize("training", [True, False])
