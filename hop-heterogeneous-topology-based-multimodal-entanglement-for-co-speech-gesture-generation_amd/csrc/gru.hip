@@ -10,10 +10,12 @@
 //     MI355X, cheaper and safer than an in-kernel grid barrier, and the T launches of a layer are
 //     enqueued from C in one ABI call (capturable into a hipGraph).
 // Decomposition of a step: workgroup (jb, bb, dir) owns hidden units [16 jb, 16 jb + 16) of batch rows
-// [32 bb, 32 bb + 32): out[32 x (3 gates x 16)] = h_prev[32 x H] W_slice^T, exact-fp32 MFMA 16x16x4 with
-// K = H split over the 4 waves (lane quad q of wave w owns the contiguous k range
-// [(4w+q) KQ, (4w+q+1) KQ): 8-B loads straight to registers, no LDS staging), partial tiles summed
-// through LDS, then the gate math as the epilogue.  h_prev is read from the layer output y itself.
+// [32 bb, 32 bb + 32): out[32 x (3 gates x 16)] = h_prev[32 x H] W_slice^T on exact-fp32 MFMA 16x16x4.
+// Both operand panels (32 rows of h_prev, 48 rows of W_hh) are streamed HBM/L2 -> LDS with row-contiguous
+// 8-B loads (512 B per wave instruction; per-lane fragment loads would touch 64 cache lines each), K is
+// zero-padded to a multiple of 64 and split over the 4 waves in 16-wide chunks read back as ds_read_b128
+// MFMA operands; the 4 partial tiles are summed through LDS and the gate math is the epilogue.
+// h_prev is read from the layer output y itself.
 #include "common.h"
 
 namespace hopmi {
@@ -24,71 +26,130 @@ constexpr int RED_LD = 49;     // LDS stride of the [32][48] partial tiles
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-// acc[mt][g] += A[rows 16mt..][k] * W[unit rows of gate g][k] over this lane's k range.
-// a_ptr[mt] / w_ptr[g] point at this lane's row and first k.  The trip count `nk2` (float2 steps) is
-// wave-uniform -- MFMA needs every lane -- and a lane whose range ends early (the K padding) re-reads its
-// last valid pair and contributes zeros.
+// XCD-aware work mapping (speed only; any placement is correct).  Workgroups are dealt round-robin over
+// the 8 XCDs by linear id, and each XCD has a private 4 MiB L2.  A "slice" = (unit block jb, direction):
+// its 67 KB of recurrent weights are needed by all batch groups of that slice at EVERY time step, so all
+// workgroups of a slice get the same id % 8: an XCD then touches only ~1/8 of W_hh and keeps it in its L2
+// across the T launches of a layer instead of re-fetching all 2.9 MB per step.
+struct GruWork { int jb, bb, d; bool valid; };
+__device__ __forceinline__ GruWork gru_decode(int nJ, int nbb) {
+  const int lin = blockIdx.x, xcd = lin & 7, sidx = lin >> 3;
+  const int slice = xcd + 8 * (sidx / nbb);
+  GruWork wk;
+  wk.bb = sidx % nbb;
+  wk.valid = slice < 2 * nJ;
+  wk.jb = slice % nJ;
+  wk.d = slice / nJ;
+  return wk;
+}
+
+// Stage `nrows` rows of K (even) floats into LDS rows of stride ldk (floats), zero-padding [K, KP).
+// Row r of the panel comes from src_of(r) (nullptr -> all-zero row).  One wave per row at a time,
+// lane l takes the float2 at k = 2l, 2l + 128, ...: every load instruction covers 512 contiguous bytes.
+// All loads of a wave's rows are issued before the first LDS store (one memory round trip).
+template <int MAXROWS_PER_WAVE, int MAXK2, typename SrcOf>
+__device__ __forceinline__ void stage_rows(float* dst, int ldk, int nrows, int K, int KP, SrcOf src_of, int w, int lane) {
+  // rows w, w+4, w+8, ... ; per row MAXK2 float2 slots per lane
+  float2 v[MAXROWS_PER_WAVE][MAXK2];
+#pragma unroll
+  for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
+    const int r = w + 4 * rr;
+    const float* src = src_of(min(r, nrows - 1));
+    const bool row_ok = (r < nrows) && (src != nullptr);
+    const float* sp = src ? src : dst;            // never dereferenced when !row_ok (clamped below)
+#pragma unroll
+    for (int c = 0; c < MAXK2; ++c) {
+      const int k = 2 * lane + 128 * c;
+      const bool ok = row_ok && (k < K);
+      float2 t = make_float2(0.f, 0.f);
+      if (src) t = *reinterpret_cast<const float2*>(sp + min(k, K - 2));
+      v[rr][c] = ok ? t : make_float2(0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
+    const int r = w + 4 * rr;
+#pragma unroll
+    for (int c = 0; c < MAXK2; ++c) {
+      const int k = 2 * lane + 128 * c;
+      if (r < nrows && k < KP) *reinterpret_cast<float2*>(dst + r * ldk + k) = v[rr][c];
+    }
+  }
+}
+
+// acc[mt][g] += As[16mt + i][k] * Ws[16g + i][k] over this wave's k chunks [16 c0, 16 (c0 + nc)).
 template <int NG>
-__device__ __forceinline__ void ksplit_mfma(f32x4 (&acc)[2][NG], const float* (&a_ptr)[2], const bool (&a_ok)[2],
-                                            const float* (&w_ptr)[NG], bool w_ok, int nk2, int nk2_valid) {
-  const int last = max(nk2_valid - 1, 0);
-#pragma unroll 4
-  for (int p = 0; p < nk2; ++p) {
-    const bool k_ok = p < nk2_valid;
-    const int pc = min(p, last);
-    float2 a[2], w[NG];
+__device__ __forceinline__ void panel_mfma(f32x4 (&acc)[2][NG], const float* As, const float* Ws, int ldk,
+                                           int c0, int nc, int q, int i) {
+  const float* ap = As + i * ldk + 4 * q;          // A[i = row][k = 16c + 4q + e]
+  const float* wp = Ws + i * ldk + 4 * q;          // B[k][j = unit]
+#pragma unroll 2
+  for (int c = c0; c < c0 + nc; ++c) {
+    float4 a[2], wv[NG];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      a[mt] = *reinterpret_cast<const float2*>(a_ptr[mt] + 2 * pc);
-      if (!(a_ok[mt] && k_ok)) a[mt] = make_float2(0.f, 0.f);
-    }
+    for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap + 16 * mt * ldk + 16 * c);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      w[g] = *reinterpret_cast<const float2*>(w_ptr[g] + 2 * pc);
-      if (!(w_ok && k_ok)) w[g] = make_float2(0.f, 0.f);
-    }
+    for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const float4*>(wp + 16 * g * ldk + 16 * c);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        acc[mt][g] = mfma16(a[mt].x, w[g].x, acc[mt][g]);
-        acc[mt][g] = mfma16(a[mt].y, w[g].y, acc[mt][g]);
+        acc[mt][g] = mfma16(a[mt].x, wv[g].x, acc[mt][g]);
+        acc[mt][g] = mfma16(a[mt].y, wv[g].y, acc[mt][g]);
+        acc[mt][g] = mfma16(a[mt].z, wv[g].z, acc[mt][g]);
+        acc[mt][g] = mfma16(a[mt].w, wv[g].w, acc[mt][g]);
       }
   }
 }
 
-// one time step `s` of both directions (dir 0 walks t = s, dir 1 walks t = T-1-s)
+// one time step `s` of both directions (dir 0 walks t = s, dir 1 walks t = T-1-s).
+// MAXK2 = ceil(KP / 128) float2 slots per lane per row (KP = H padded to a multiple of 64).
+template <int MAXK2>
 __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
                                                            const float* __restrict__ bhh, float* __restrict__ y,
-                                                           float* __restrict__ gates, int B, int T, int H, int KQ, int s) {
-  __shared__ float red[4 * GRU_BM * RED_LD];
+                                                           float* __restrict__ gates, int B, int T, int H, int KP, int s) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GruWork wk = gru_decode((H + GRU_NU - 1) / GRU_NU, (B + GRU_BM - 1) / GRU_BM);
+  if (!wk.valid) return;
+  const int ldk = KP + 4;
+  float* As = smem;                                // [32][ldk]  h_prev rows
+  float* Ws = As + GRU_BM * ldk;                   // [48][ldk]  W_hh rows of the 3 gates x 16 units
+  float* red = Ws + 3 * GRU_NU * ldk;              // [4][32][RED_LD]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
-  const int d = blockIdx.z, j0 = blockIdx.x * GRU_NU, b0 = blockIdx.y * GRU_BM;
+  const int d = wk.d, j0 = wk.jb * GRU_NU, b0 = wk.bb * GRU_BM;
   const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
   const size_t ystride = (size_t)2 * H;
 
-  if (s > 0) {
-    const int k0 = (4 * w + q) * KQ;                            // this lane's k range [k0, k0 + KQ)
-    const int nk2_valid = max(0, min(KQ, H - k0)) >> 1;         // H, KQ, k0 even
-    const int kc = min(k0, H - 2);                              // keep the (unused) address in bounds
-    f32x4 acc[2][3];
-    const float* a_ptr[2];
-    bool a_ok[2];
+  // epilogue operands, fetched up front (clamped, unconditional) so their latency hides under the staging
+  const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
+  float e_gi[2][3], e_bhh[3];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int b = b0 + 16 * mt + i;
-      a_ok[mt] = b < B;
-      a_ptr[mt] = y + ((size_t)min(b, B - 1) * T + tp) * ystride + d * H + kc;
+  for (int g = 0; g < 3; ++g) e_bhh[g] = bhh[(d * 3 + g) * H + jc];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bc = min(b0 + (tid >> 4) + 16 * pass, B - 1);
+    const float* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) e_gi[pass][g] = gip[g * H];
+  }
+
+  if (s > 0) {
+    stage_rows<GRU_BM / 4, MAXK2>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
+      const int b = b0 + r;
+      return b < B ? y + ((size_t)b * T + tp) * ystride + d * H : nullptr;
+    }, w, lane);
+    stage_rows<3 * GRU_NU / 4, MAXK2>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
+      const int g = r >> 4, ju = j0 + (r & 15);
+      return ju < H ? whh + ((size_t)(d * 3 + g) * H + ju) * H : nullptr;
+    }, w, lane);
+    __syncthreads();
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[mt][g] = {0.f, 0.f, 0.f, 0.f};
-    }
-    const int ju = j0 + i;
-    const bool w_ok = ju < H;
-    const float* w_ptr[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) w_ptr[g] = whh + ((size_t)(d * 3 + g) * H + min(ju, H - 1)) * H + kc;
-    ksplit_mfma<3>(acc, a_ptr, a_ok, w_ptr, w_ok, KQ >> 1, nk2_valid);
-    // partial tile of this wave -> LDS: red[w][row][16 g + col]
+    const int nc = KP >> 6;                                     // 16-wide k chunks per wave
+    panel_mfma<3>(acc, As, Ws, ldk, w * nc, nc, q, i);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -99,7 +160,6 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
   __syncthreads();
 
   // gate epilogue: thread -> (row, unit), two passes of 16 rows
-  const int jj = tid & 15, j = j0 + jj;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int row = (tid >> 4) + 16 * pass, b = b0 + row;
@@ -107,18 +167,17 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
       float gh[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        float v = bhh[(d * 3 + g) * H + j];
+        float v = e_bhh[g];
         if (s > 0) {
 #pragma unroll
           for (int ww = 0; ww < 4; ++ww) v += red[(ww * GRU_BM + row) * RED_LD + 16 * g + jj];
         }
         gh[g] = v;
       }
-      const float* gip = gi + (((size_t)b * T + t) * 2 + d) * 3 * H + j;
-      const float r = sigmoidf_(gip[0] + gh[0]);
-      const float z = sigmoidf_(gip[H] + gh[1]);
-      const float n = tanhf(gip[2 * H] + r * gh[2]);
-      const float hp = (s > 0) ? y[((size_t)b * T + tp) * ystride + d * H + j] : 0.f;
+      const float r = sigmoidf_(e_gi[pass][0] + gh[0]);
+      const float z = sigmoidf_(e_gi[pass][1] + gh[1]);
+      const float n = tanhf(e_gi[pass][2] + r * gh[2]);
+      const float hp = (s > 0) ? As[row * ldk + j] : 0.f;       // h_prev[b][j] is in the staged panel
       y[((size_t)b * T + t) * ystride + d * H + j] = (1.f - z) * n + z * hp;
       float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
       gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = gh[2];
@@ -132,14 +191,22 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
 //   dn    = D_p (1 - z) (1 - n^2);  dz = D_p (h_{p-1} - n) z (1 - z);  dr = dn * hn * r (1 - r)
 //   dgi_p = [dr, dz, dn];  dgh_p = [dr, dz, dn * r];  Dz_p = D_p * z
 // The workgroup owns units [16 jb, +16) of rows [32 bb, +32): the contraction over the 3H gates of step
-// p+1 reads dgh rows (contiguous) and rows of W_hh^T (whhT[dir][unit][3H], transposed by the caller).
+// p+1 is done gate block by gate block (K = H each): dgh rows and rows of W_hh^T (whhT[dir][unit][3H],
+// transposed by the caller) are both contiguous.
+template <int MAXK2>
 __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ gates, const float* __restrict__ whhT,
                                                            float* __restrict__ dgi, float* __restrict__ dgh,
-                                                           float* __restrict__ dhz, int B, int T, int H, int KQ, int s) {
-  __shared__ float red[4 * GRU_BM * RED_LD];
+                                                           float* __restrict__ dhz, int B, int T, int H, int KP, int s) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GruWork wk = gru_decode((H + GRU_NU - 1) / GRU_NU, (B + GRU_BM - 1) / GRU_BM);
+  if (!wk.valid) return;
+  const int ldk = KP + 4;
+  float* As = smem;                                // [32][ldk]  dgh rows of one gate block
+  float* Ws = As + GRU_BM * ldk;                   // [16][ldk]  W_hh^T rows of the 16 units, same gate block
+  float* red = Ws + GRU_NU * ldk;                  // [4][32][RED_LD]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
-  const int d = blockIdx.z, j0 = blockIdx.x * GRU_NU, b0 = blockIdx.y * GRU_BM;
+  const int d = wk.d, j0 = wk.jb * GRU_NU, b0 = wk.bb * GRU_BM;
   const int t = d ? s : T - 1 - s;                 // time index processed at BPTT step s
   const int tn = d ? t - 1 : t + 1;                // the step the forward processed right after t
   const int tp = d ? t + 1 : t - 1;                // ... and right before t (source of h_prev)
@@ -147,25 +214,39 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
   const float* dhz_in = dhz + ((size_t)((s + 1) & 1) * 2 + d) * B * H;
   float* dhz_out = dhz + ((size_t)(s & 1) * 2 + d) * B * H;
 
-  if (s > 0) {
-    const int k0 = (4 * w + q) * KQ;
-    const int nk2_valid = max(0, min(KQ, K - k0)) >> 1;
-    const int kc = min(k0, K - 2);
-    f32x4 acc[2][1];
-    const float* a_ptr[2];
-    bool a_ok[2];
+  // epilogue operands, fetched up front (clamped, unconditional)
+  const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
+  float e_dy[2], e_dhz[2], e_g[2][4], e_hp[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int b = b0 + 16 * mt + i;
-      a_ok[mt] = b < B;
-      a_ptr[mt] = dgh + (((size_t)min(b, B - 1) * T + tn) * 2 + d) * K + kc;
-      acc[mt][0] = {0.f, 0.f, 0.f, 0.f};
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bc = min(b0 + (tid >> 4) + 16 * pass, B - 1);
+    e_dy[pass] = dy[((size_t)bc * T + t) * 2 * H + d * H + jc];
+    e_dhz[pass] = dhz_in[(size_t)bc * H + jc];                     // garbage at s == 0: not used there
+    const float* gp = gates + (((size_t)bc * T + t) * 2 + d) * 4 * H + jc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_g[pass][g] = gp[g * H];
+    const int tpc = min(max(tp, 0), T - 1);
+    e_hp[pass] = y[((size_t)bc * T + tpc) * 2 * H + d * H + jc];
+  }
+
+  if (s > 0) {
+    f32x4 acc[2][1];
+    acc[0][0] = {0.f, 0.f, 0.f, 0.f};
+    acc[1][0] = {0.f, 0.f, 0.f, 0.f};
+    const int nc = KP >> 6;
+    for (int g = 0; g < 3; ++g) {
+      if (g) __syncthreads();                      // previous gate block consumed
+      stage_rows<GRU_BM / 4, MAXK2>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
+        const int b = b0 + r;
+        return b < B ? dgh + (((size_t)b * T + tn) * 2 + d) * K + g * H : nullptr;
+      }, w, lane);
+      stage_rows<GRU_NU / 4, MAXK2>(Ws, ldk, GRU_NU, H, KP, [&](int r) -> const float* {
+        const int ju = j0 + r;
+        return ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr;
+      }, w, lane);
+      __syncthreads();
+      panel_mfma<1>(acc, As, Ws, ldk, w * nc, nc, q, i);
     }
-    const int ju = j0 + i;
-    const bool w_ok = ju < H;
-    const float* w_ptr[1];
-    w_ptr[0] = whhT + ((size_t)d * H + min(ju, H - 1)) * K + kc;
-    ksplit_mfma<1>(acc, a_ptr, a_ok, w_ptr, w_ok, KQ >> 1, nk2_valid);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -173,20 +254,18 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
   }
   __syncthreads();
 
-  const int jj = tid & 15, j = j0 + jj;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int row = (tid >> 4) + 16 * pass, b = b0 + row;
     if (b < B && j < H) {
-      float D = dy[((size_t)b * T + t) * 2 * H + d * H + j];
+      float D = e_dy[pass];
       if (s > 0) {
-        D += dhz_in[(size_t)b * H + j];
+        D += e_dhz[pass];
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) D += red[(ww * GRU_BM + row) * RED_LD + jj];
       }
-      const float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
-      const float r = gp[0], z = gp[H], n = gp[2 * H], hn = gp[3 * H];
-      const float hp = (s < T - 1) ? y[((size_t)b * T + tp) * 2 * H + d * H + j] : 0.f;
+      const float r = e_g[pass][0], z = e_g[pass][1], n = e_g[pass][2], hn = e_g[pass][3];
+      const float hp = (s < T - 1) ? e_hp[pass] : 0.f;
       const float dn = D * (1.f - z) * (1.f - n * n);
       const float dz = D * (hp - n) * z * (1.f - z);
       const float dr = dn * hn * r * (1.f - r);
@@ -198,17 +277,26 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
   }
 }
 
-static int even_ceil_div16(int K) {
-  int kq = (K + 15) / 16;
-  return kq + (kq & 1);
-}
-
 static int gru_validate(const void* const* ptrs, int n, int B, int T, int H) {
   for (int i = 0; i < n; ++i)
     if (!ptrs[i]) { set_error("hopmi_gru: null pointer argument #%d", i); return HOPMI_EINVAL; }
   if (B <= 0 || T <= 0) { set_error("hopmi_gru: B=%d T=%d must be > 0", B, T); return HOPMI_EINVAL; }
-  if (H < 2 || (H & 1) || H > 4096) { set_error("hopmi_gru: hidden size H=%d must be even and in [2,4096]", H); return HOPMI_EINVAL; }
+  if (H < 2 || (H & 1) || H > 384) { set_error("hopmi_gru: hidden size H=%d must be even and in [2,384] (LDS panel budget)", H); return HOPMI_EINVAL; }
   return HOPMI_OK;
+}
+
+template <int MAXK2>
+static void launch_gru_fwd(dim3 grid, size_t lds, hipStream_t st, const float* gi, const float* whh, const float* bhh,
+                           float* y, float* gates, int B, int T, int H, int KP) {
+  for (int s = 0; s < T; ++s)
+    hipLaunchKernelGGL(gru_fwd_step_kernel<MAXK2>, grid, dim3(256), lds, st, gi, whh, bhh, y, gates, B, T, H, KP, s);
+}
+
+template <int MAXK2>
+static void launch_gru_bwd(dim3 grid, size_t lds, hipStream_t st, const float* dy, const float* y, const float* gates,
+                           const float* whhT, float* dgi, float* dgh, float* ws, int B, int T, int H, int KP) {
+  for (int s = 0; s < T; ++s)
+    hipLaunchKernelGGL(gru_bwd_step_kernel<MAXK2>, grid, dim3(256), lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP, s);
 }
 
 }  // namespace hopmi
@@ -219,11 +307,17 @@ extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh
                              int B, int T, int H, void* stream) {
   const void* ptrs[] = {gi, whh, bhh, y, gates};
   if (int e = gru_validate(ptrs, 5, B, T, H)) return e;
-  const dim3 grid((H + GRU_NU - 1) / GRU_NU, (B + GRU_BM - 1) / GRU_BM, 2);
-  const int KQ = even_ceil_div16(H);
+  const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
+  const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
+  const int KP = ceil_to(H, 64);
+  const size_t lds = ((size_t)(GRU_BM + 3 * GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int s = 0; s < T; ++s)
-    hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, st, gi, whh, bhh, y, gates, B, T, H, KQ, s);
+  switch ((KP + 127) / 128) {
+    case 1: launch_gru_fwd<1>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+    case 2: launch_gru_fwd<2>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+    case 3: launch_gru_fwd<3>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+    default: launch_gru_fwd<4>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+  }
   return check_launch("hopmi_gru_fwd");
 }
 
@@ -235,10 +329,16 @@ extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates
                              float* dgi, float* dgh, float* ws, int B, int T, int H, void* stream) {
   const void* ptrs[] = {dy, y, gates, whhT, dgi, dgh, ws};
   if (int e = gru_validate(ptrs, 7, B, T, H)) return e;
-  const dim3 grid((H + GRU_NU - 1) / GRU_NU, (B + GRU_BM - 1) / GRU_BM, 2);
-  const int KQ = even_ceil_div16(3 * H);
+  const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
+  const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
+  const int KP = ceil_to(H, 64);
+  const size_t lds = ((size_t)(GRU_BM + GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int s = 0; s < T; ++s)
-    hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KQ, s);
+  switch ((KP + 127) / 128) {
+    case 1: launch_gru_bwd<1>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+    case 2: launch_gru_bwd<2>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+    case 3: launch_gru_bwd<3>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+    default: launch_gru_bwd<4>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+  }
   return check_launch("hopmi_gru_bwd");
 }
