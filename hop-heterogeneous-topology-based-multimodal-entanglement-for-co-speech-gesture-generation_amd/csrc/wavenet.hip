@@ -1,0 +1,352 @@
+// One fused WaveNet layer of the HOP graph-wavenet block (reference: model/gwnet.py:181-237), forward:
+//
+//   r^      = BN_{i-1}(y_{i-1})                      applied ON LOAD as r^ = y*scale + shift (identity for layer 0)
+//   u       = tanh(Wf0 r^[t] + Wf1 r^[t+d] + bf) * sigmoid(Wg0 r^[t] + Wg1 r^[t+d] + bg)     gwnet.py:186-200
+//   utail   = u[last 4 frames]                       the only part of the skip path that reaches the output
+//   y_i     = Wm.[u; uA1; uA2] + bm + r^[t+d]        graph conv + residual, gwnet.py:224-233 (pre-BN)
+//   stats   = per-channel sum / sum of squares of y_i (BatchNorm2d batch statistics, gwnet.py:237)
+//
+// replacing ~15 aten launches and 10 activation round trips per layer by one kernel: the activation tile
+// is read once (two time taps), everything between lives in LDS/registers, y_i is written once.
+//
+// Work decomposition: the output rows (clip b, frame t', node v) are flat, row = slab*V + v with
+// slab = b*T_out + t'; a workgroup (4 waves) takes tiles of S consecutive output slabs (<= 80 rows) and
+// walks tiles persistently, keeping in registers its 16-output-channel slices of the TCN weights
+// (4 x 64 x 16) and of Wm (192 x 16).  Per tile: the two tap panels R0 = r^[t'], R1 = r^[t'+d] go
+// HBM -> registers -> (normalise) -> LDS; TCN on exact-fp32 MFMA with A operands read as ds_read_b128; the
+// gate; node mix on MFMA; channel contraction on MFMA; epilogue adds bias + residual (from the R1 panel),
+// stores y and accumulates the BatchNorm partial sums.  A tiny second kernel turns the per-workgroup
+// partials into mean / rstd / running stats / the next layer's scale+shift in a fixed order (reproducible).
+#include "gcn_dev.h"
+
+namespace hopmi {
+
+struct LayerGeom {
+  GcnGeom g;       // V, S = output slabs per tile, mtiles, rows_lds, mix-matrix geometry, ntiles
+  int B, T_in, T_out, d;
+  int n_slabs;     // B * T_out
+  float invV, invT;  // 1/V, 1/T_out for the (row + 0.5) * inv index splits (exact for the ranges validated)
+};
+
+constexpr int WN_MAX_MT = 5;                       // <= 80 rows per tile
+
+static LayerGeom make_layer_geom(int B, int T_in, int V, int d, int grid_target) {
+  LayerGeom L;
+  L.B = B; L.T_in = T_in; L.d = d; L.T_out = T_in - d;
+  L.n_slabs = B * L.T_out;
+  int S = (L.n_slabs + grid_target - 1) / grid_target;            // one tile per workgroup when it fits ...
+  const int smax = (16 * WN_MAX_MT) / V > 0 ? (16 * WN_MAX_MT) / V : 1;
+  if (S > smax) S = smax;                                         // ... else walk several
+  if (S < 1) S = 1;
+  L.g = make_geom(L.n_slabs, V, S);
+  L.invV = 1.0f / V;
+  L.invT = 1.0f / L.T_out;
+  return L;
+}
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// per-thread description of the NIT rows this thread streams in a tile (the idx -> row map is the same
+// for the load phase and the skip-tail store phase)
+template <int NIT>
+struct RowMap {
+  int in0[NIT];     // float4 index of the tap-0 source row start (+ c4), clamped into the tensor
+  int tail[NIT];    // float4 index into utail (+ c4) or -1
+  bool ok[NIT];     // row < R
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
+                                                           const float* __restrict__ wtcn, const float* __restrict__ btcn,
+                                                           const float* __restrict__ prep, const float* __restrict__ Wm,
+                                                           const float* __restrict__ bm, float* __restrict__ y,
+                                                           float* __restrict__ fs, float* __restrict__ utail,
+                                                           float* __restrict__ stats_part, LayerGeom L, int do_gcn, int utail_ld4) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GcnGeom& g = L.g;
+  constexpr int NIT = rows_nit(MT);
+  float* R0 = smem;                                // [rows_lds][LDD]  r^ at frame t'
+  float* R1 = R0 + g.rows_lds * LDD;               // [rows_lds][LDD]  r^ at frame t'+d
+  float* Hc = R1 + g.rows_lds * LDD;               // [rows_lds][LDH]  u | uA1 | uA2
+  float* AT = Hc + g.rows_lds * LDH;               // [KP][ldA]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int V = g.V, c4 = tid & 15;
+  const int shift4 = L.d * V * 16;                 // tap-1 row offset in float4 units
+
+  // ---- weights of this wave's 16 output channels, K permuted as k = 16i + 4q + e -------------------
+  float4 wt[2][2][4];                              // [gate f/g][tap][i]
+#pragma unroll
+  for (int gate = 0; gate < 2; ++gate)
+#pragma unroll
+    for (int tap = 0; tap < 2; ++tap) {
+      const float4* wp = reinterpret_cast<const float4*>(wtcn + (size_t)((2 * tap + gate) * 64 + 16 * w + j) * C + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wt[gate][tap][i] = wp[4 * i];
+    }
+  const float bf = btcn[16 * w + j], bg = btcn[C + 16 * w + j];
+  float4 wreg[12];
+  float bias = 0.f;
+  if (do_gcn) {
+    const float4* wp = reinterpret_cast<const float4*>(Wm + (size_t)(16 * w + j) * K3 + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) wreg[i] = wp[4 * i];
+    bias = bm[16 * w + j];
+    PrepRegs mr;
+    prep_issue(mr, prep, g.KP * g.ldA, tid);
+    prep_commit(AT, mr, g.KP * g.ldA, tid);
+  }
+  const float4 sc4 = reinterpret_cast<const float4*>(scsh)[c4];
+  const float4 sh4 = reinterpret_cast<const float4*>(scsh + C)[c4];
+  float st1 = 0.f, st2 = 0.f;                      // BatchNorm partial sums of channel 16w + j
+  // the 4 padding rows behind the tile are read by the node mix's K padding (times zero): keep them finite
+  for (int idx = tid; idx < 4 * C; idx += 256) Hc[(16 * MT + idx / C) * LDH + idx % C] = 0.f;
+
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    const int slab0 = tile * g.S;
+    const int nsl = min(g.S, L.n_slabs - slab0);
+    const int R = nsl * V;
+    const size_t orow0 = (size_t)slab0 * V;        // first flat output row of the tile
+
+    // ---- phase 0: stream both tap panels, normalise, commit to LDS --------------------------------
+    RowMap<NIT> rm;
+    RowRegs<NIT> x0r, x1r;
+    {
+      const float4* src4 = reinterpret_cast<const float4*>(xin);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = (tid >> 4) + 16 * it;
+        const int rc = min(row, R - 1);
+        const int s = (int)((rc + 0.5f) * L.invV);
+        const int v = rc - s * V;
+        const int slab = slab0 + s;
+        const int b = (int)((slab + 0.5f) * L.invT);
+        const int tp = slab - b * L.T_out;
+        rm.ok[it] = row < R;
+        rm.in0[it] = ((b * L.T_in + tp) * V + v) * 16 + c4;
+        rm.tail[it] = (rm.ok[it] && tp >= L.T_out - 4) ? ((b * 4 + tp - (L.T_out - 4)) * V + v) * utail_ld4 + c4 : -1;
+        x0r.v[it] = src4[rm.in0[it]];
+        x1r.v[it] = src4[rm.in0[it] + shift4];
+      }
+      __syncthreads();                             // previous tile's LDS fully consumed
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = (tid >> 4) + 16 * it;
+        if (row < g.rows_lds) {
+          float4 a = x0r.v[it], b2 = x1r.v[it];
+          a = make_float4(a.x * sc4.x + sh4.x, a.y * sc4.y + sh4.y, a.z * sc4.z + sh4.z, a.w * sc4.w + sh4.w);
+          b2 = make_float4(b2.x * sc4.x + sh4.x, b2.y * sc4.y + sh4.y, b2.z * sc4.z + sh4.z, b2.w * sc4.w + sh4.w);
+          if (!rm.ok[it]) { a = make_float4(0.f, 0.f, 0.f, 0.f); b2 = a; }
+          *reinterpret_cast<float4*>(R0 + row * LDD + 4 * c4) = a;
+          *reinterpret_cast<float4*>(R1 + row * LDD + 4 * c4) = b2;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 1: gated TCN (two taps, two gates) on MFMA, gate, u -> LDS --------------------------
+    {
+      f32x4 af[MT], ag[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { af[mt] = {0.f, 0.f, 0.f, 0.f}; ag[mt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int tap = 0; tap < 2; ++tap) {
+        const float* ra = (tap ? R1 : R0) + j * LDD + 4 * q;      // A[i = row][k = 16i + 4q + e]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float4 a[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(ra + 16 * mt * LDD + 16 * i);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            af[mt] = mfma16(a[mt].x, wt[0][tap][i].x, af[mt]);
+            ag[mt] = mfma16(a[mt].x, wt[1][tap][i].x, ag[mt]);
+            af[mt] = mfma16(a[mt].y, wt[0][tap][i].y, af[mt]);
+            ag[mt] = mfma16(a[mt].y, wt[1][tap][i].y, ag[mt]);
+            af[mt] = mfma16(a[mt].z, wt[0][tap][i].z, af[mt]);
+            ag[mt] = mfma16(a[mt].z, wt[1][tap][i].z, ag[mt]);
+            af[mt] = mfma16(a[mt].w, wt[0][tap][i].w, af[mt]);
+            ag[mt] = mfma16(a[mt].w, wt[1][tap][i].w, ag[mt]);
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + 4 * q + r;
+          const float f = tanhf(af[mt][r] + bf), sg = sigmoid_(ag[mt][r] + bg);
+          Hc[row * LDH + 16 * w + j] = f * sg;
+          if (fs != nullptr && row < R) {
+            float* fp = fs + (orow0 + row) * (2 * C) + 16 * w + j;
+            fp[0] = f;
+            fp[C] = sg;
+          }
+        }
+    }
+    __syncthreads();
+
+    // ---- skip tail: last 4 frames of u, LDS -> HBM as whole 256-B rows ------------------------------
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = (tid >> 4) + 16 * it;
+      if (rm.tail[it] >= 0)
+        reinterpret_cast<float4*>(utail)[rm.tail[it]] = *reinterpret_cast<const float4*>(Hc + row * LDH + 4 * c4);
+    }
+
+    if (do_gcn) {
+      // ---- phase 2: node mix ---------------------------------------------------------------------
+      node_mix_dispatch(Hc, AT, g, nsl, w, q, j);
+      __syncthreads();
+      // ---- phase 3: channel contraction + bias + residual, y store, BatchNorm partial sums ------
+      f32x4 acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
+      const float* ha = Hc + j * LDH + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        float4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(ha + 16 * mt * LDH + 16 * i);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt] = mfma16(a[mt].x, wreg[i].x, acc[mt]);
+          acc[mt] = mfma16(a[mt].y, wreg[i].y, acc[mt]);
+          acc[mt] = mfma16(a[mt].z, wreg[i].z, acc[mt]);
+          acc[mt] = mfma16(a[mt].w, wreg[i].w, acc[mt]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + 4 * q + r;
+          if (row < R) {
+            const float yv = acc[mt][r] + bias + R1[row * LDD + 16 * w + j];      // gwnet.py:233
+            if (y != nullptr) y[(orow0 + row) * C + 16 * w + j] = yv;
+            st1 += yv;
+            st2 += yv * yv;
+          }
+        }
+    }
+  }
+
+  if (stats_part != nullptr) {
+    st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
+    st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
+    if (q == 0) {
+      stats_part[blockIdx.x * 2 * C + 16 * w + j] = st1;
+      stats_part[blockIdx.x * 2 * C + C + 16 * w + j] = st2;
+    }
+  }
+}
+
+// BatchNorm2d training-mode finalisation (gwnet.py:237; torch semantics: biased variance normalises,
+// unbiased variance feeds running_var, momentum 0.1): fixed-order sum of the per-workgroup partials.
+__global__ __launch_bounds__(64) void wn_bn_finalize_kernel(const float* __restrict__ part, int nblk, double n,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            float momentum, float eps, float* __restrict__ scsh_out,
+                                                            float* __restrict__ mean_rstd_out) {
+  const int c = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += part[b * 2 * C + c];
+    s2 += part[b * 2 * C + C + c];
+  }
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scsh_out[c] = sc;
+  scsh_out[C + c] = beta[c] - (float)mean * sc;
+  mean_rstd_out[c] = (float)mean;
+  mean_rstd_out[C + c] = rstd;
+  if (running_mean != nullptr) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+static int wn_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+static int wn_grid(const LayerGeom& L) {
+  const int cap = wn_env_int("HOPMI_WN_GRID", 256);
+  return L.g.ntiles < cap ? L.g.ntiles : cap;
+}
+
+static int wn_validate(int B, int T_in, int V, int d) {
+  if (B <= 0 || V < 1 || V > HOPMI_MAX_NODES || d < 1 || T_in - d < 4) {
+    set_error("hopmi_wn_layer: bad geometry B=%d T_in=%d V=%d dilation=%d (need T_in - dilation >= 4, V in [1,%d])", B, T_in,
+              V, d, HOPMI_MAX_NODES);
+    return HOPMI_EINVAL;
+  }
+  if ((long long)B * T_in * V >= (1LL << 20) * 16) {
+    set_error("hopmi_wn_layer: B*T*V too large for the 32-bit row index math");
+    return HOPMI_EINVAL;
+  }
+  if ((long long)B * (T_in - d) >= (1 << 20)) {
+    set_error("hopmi_wn_layer: B*T_out >= 2^20 not supported (float index split)");
+    return HOPMI_EINVAL;
+  }
+  return HOPMI_OK;
+}
+
+template <int MT>
+static void launch_wn_fwd(const float* xin, const float* scsh, const float* wtcn, const float* btcn, const float* prep,
+                          const float* Wm, const float* bm, float* y, float* fs, float* utail, int utail_ld, float* part,
+                          const LayerGeom& L, int do_gcn, int grid, hipStream_t st) {
+  const GcnGeom& g = L.g;
+  const size_t lds = ((size_t)g.rows_lds * (2 * LDD + LDH) + (size_t)g.KP * g.ldA) * sizeof(float);
+  hipLaunchKernelGGL(wn_layer_fwd_kernel<MT>, dim3(grid), dim3(256), lds, st, xin, scsh, wtcn, btcn, prep, Wm, bm, y, fs,
+                     utail, part, L, do_gcn, utail_ld / 4);
+}
+
+}  // namespace hopmi
+
+using namespace hopmi;
+
+extern "C" size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation) {
+  if (wn_validate(B, T_in, V, dilation)) return 0;
+  const LayerGeom L = make_layer_geom(B, T_in, V, dilation, wn_env_int("HOPMI_WN_GRID", 256));
+  return (size_t)wn_grid(L) * 2 * C;
+}
+
+extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn, const float* btcn,
+                                  const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
+                                  int utail_ld, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, float* scsh_out, float* mean_rstd_out, float* ws,
+                                  int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
+  if (int e = wn_validate(B, T_in, V, dilation)) return e;
+  if (!xin || !scsh_in || !wtcn || !btcn || !utail) { set_error("hopmi_wn_layer_fwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (utail_ld < C || (utail_ld & 3)) { set_error("hopmi_wn_layer_fwd: utail_ld=%d must be a multiple of 4 and >= 64", utail_ld); return HOPMI_EINVAL; }
+  if (do_gcn && (!prep || !Wm || !bm)) { set_error("hopmi_wn_layer_fwd: do_gcn needs prep, Wm, bm"); return HOPMI_EINVAL; }
+  const bool stats = scsh_out != nullptr;
+  if (stats && (!do_gcn || !gamma || !beta || !mean_rstd_out || !ws)) {
+    set_error("hopmi_wn_layer_fwd: batch statistics need do_gcn, gamma, beta, mean_rstd_out and ws");
+    return HOPMI_EINVAL;
+  }
+  const LayerGeom L = make_layer_geom(B, T_in, V, dilation, wn_env_int("HOPMI_WN_GRID", 256));
+  const int grid = wn_grid(L);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = stats ? ws : nullptr;
+  switch (L.g.mtiles) {
+    case 1: launch_wn_fwd<1>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 2: launch_wn_fwd<2>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 3: launch_wn_fwd<3>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 4: launch_wn_fwd<4>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 5: launch_wn_fwd<5>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    default: set_error("hopmi_wn_layer_fwd: internal: %d m-tiles", L.g.mtiles); return HOPMI_EINVAL;
+  }
+  if (int e = check_launch("hopmi_wn_layer_fwd")) return e;
+  if (stats) {
+    hipLaunchKernelGGL(wn_bn_finalize_kernel, dim3(1), dim3(64), 0, st, part, grid, (double)L.n_slabs * V, gamma, beta,
+                       running_mean, running_var, momentum, eps, scsh_out, mean_rstd_out);
+    return check_launch("hopmi_wn_bn_finalize");
+  }
+  return HOPMI_OK;
+}

@@ -129,6 +129,53 @@ class gwnet(nn.Module):
         scale = bn.weight * torch.rsqrt(var + bn.eps)
         return y * scale + (bn.bias - mean * scale)
 
+    def _packed_tcn(self, i):
+        """filter/gate Conv2d (1,2) weights of layer i as the fused kernel wants them:
+        [Wf tap0, Wg tap0, Wf tap1, Wg tap1] each (out, in), and [bf, bg]."""
+        wf, wg = self.filter_convs[i].weight, self.gate_convs[i].weight
+        wtcn = torch.stack([wf[:, :, 0, 0], wg[:, :, 0, 0], wf[:, :, 0, 1], wg[:, :, 0, 1]]).contiguous()
+        return wtcn, torch.cat([self.filter_convs[i].bias, self.gate_convs[i].bias])
+
+    def _skip_tails_fused(self, x, prep):
+        """The 8 WaveNet layers as 8 fused kernels (no autograd graph): x (B,T,V,64) start-conv output ->
+        (B,4,V,8*64) gated activations of every layer's last 4 frames (all the skip path needs).
+        Training mode uses batch statistics and advances the running statistics like nn.BatchNorm2d."""
+        B, _, V, _ = x.shape
+        tails = torch.empty(B, 4, V, 64 * len(DILATIONS), dtype=torch.float32, device=x.device)
+        scsh = torch.cat([torch.ones(64, device=x.device), torch.zeros(64, device=x.device)])
+        xin = x.contiguous()
+        last = len(DILATIONS) - 1
+        for i, d in enumerate(DILATIONS):
+            bn = self.bn[i]
+            wtcn, btcn = self._packed_tcn(i)
+            mlp = self.gconv[i].mlp.mlp
+            # the last layer's gcn/BN output is dead (gwnet.py:240); in training the reference still
+            # advances bn[7]'s running statistics, which needs y_7's batch statistics.
+            do_gcn = (i != last) or self.training
+            bnargs = (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps) if self.training else None
+            y, _, scsh_out, _ = ops.wn_layer_fwd(xin, scsh, wtcn, btcn, prep, mlp.weight, mlp.bias,
+                                                 tails[..., 64 * i:64 * (i + 1)], d, want_y=(i != last),
+                                                 do_gcn=do_gcn, bn=bnargs)
+            if self.training:
+                bn.num_batches_tracked += 1
+            if i == last:
+                break
+            if self.training:
+                scsh = scsh_out
+            else:
+                sc = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                scsh = torch.cat([sc, bn.bias - bn.running_mean * sc])
+            xin = y
+        return tails
+
+    def _tail(self, tails):
+        """skip 1x1 convs summed over layers (one K=512 GEMM), relu, end convs: gwnet.py:209-220,240-246."""
+        ws = torch.cat([c.weight.flatten(1) for c in self.skip_convs], 1)               # (256, 8*64)
+        bs = torch.stack([c.bias for c in self.skip_convs]).sum(0)
+        s = F.relu(F.linear(tails, ws, bs))
+        s = F.relu(F.linear(s, self.end_conv_1.weight.flatten(1), self.end_conv_1.bias))
+        return F.linear(s, self.end_conv_2.weight.flatten(1), self.end_conv_2.bias)
+
     def forward_cl(self, x):
         """x (B,T>=13,V,in_dim) channels-last -> (B,4,V,out_dim) channels-last."""
         if x.shape[1] < self.receptive_field:
@@ -136,6 +183,8 @@ class gwnet(nn.Module):
         x = F.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias)        # gwnet.py:149
         A1, A2 = self.adjacency()
         prep = ops.gcn_prepare(A1, A2)          # on-chip images of the mix matrices, shared by all layers
+        if not torch.is_grad_enabled() and self.dropout == 0:
+            return self._tail(self._skip_tails_fused(x, prep))
         T_out = x.shape[1] - sum(DILATIONS)
         tails = []
         last = len(DILATIONS) - 1
@@ -157,11 +206,7 @@ class gwnet(nn.Module):
                         self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2, prep) + hi)
                 break
             x = self._batchnorm(i, self.gconv[i].forward_cl(u, A1, A2, prep) + hi)           # gwnet.py:226-237
-        ws = torch.cat([c.weight.flatten(1) for c in self.skip_convs], 1)               # (256, 8*64)
-        bs = torch.stack([c.bias for c in self.skip_convs]).sum(0)
-        s = F.relu(F.linear(torch.cat(tails, -1), ws, bs))                              # gwnet.py:209-220,240
-        s = F.relu(F.linear(s, self.end_conv_1.weight.flatten(1), self.end_conv_1.bias))
-        return F.linear(s, self.end_conv_2.weight.flatten(1), self.end_conv_2.bias)     # gwnet.py:243-246
+        return self._tail(torch.cat(tails, -1))
 
     def forward(self, input):
         """input (B,in_dim,V,T) NCHW (any strides) -> (B,out_dim,V,T-12) NCHW contiguous."""

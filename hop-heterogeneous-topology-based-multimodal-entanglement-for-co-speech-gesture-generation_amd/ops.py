@@ -139,6 +139,47 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
     return _GcnFn.apply(x, A1, A2, Wm, bm, prep)
 
 
+# ------------------------------------------------------------------------- fused WaveNet layer
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, want_y=True, want_fs=False,
+                 do_gcn=True, bn=None):
+    """One fused WaveNet layer (hopmi_wn_layer_fwd).  No autograd here: the differentiable wrapper is the
+    stack-level Function.  xin (B,T_in,V,64) contiguous; utail: a (B,4,V,64) view whose last-dim stride
+    is 1 (a channel slice of the (B,4,V,512) skip-tail buffer).  bn = (gamma, beta, running_mean,
+    running_var, momentum, eps) for training-mode batch statistics -> returns scale/shift for the next
+    layer and (mean, rstd).  Returns (y, fs, scsh_out, mean_rstd)."""
+    B, T_in, V, _ = xin.shape
+    T_out = T_in - dilation
+    dev = xin.device
+    y = torch.empty(B, T_out, V, 64, dtype=torch.float32, device=dev) if want_y else None
+    fs = torch.empty(B, T_out, V, 128, dtype=torch.float32, device=dev) if want_fs else None
+    L = _lib.lib()
+    scsh_out = mean_rstd = ws = None
+    gamma = beta = rm = rv = None
+    momentum, eps = 0.1, 1e-5
+    if bn is not None:
+        gamma, beta, rm, rv, momentum, eps = bn
+        scsh_out = torch.empty(128, dtype=torch.float32, device=dev)
+        mean_rstd = torch.empty(128, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.hopmi_wn_layer_ws_floats(B, T_in, V, dilation), dtype=torch.float32, device=dev)
+    if utail.stride(-1) != 1 or utail.stride(2) % 4 or utail.shape != (B, 4, V, 64):
+        raise _lib.HopmiError(f"hopmi wn_layer: bad utail view {tuple(utail.shape)} strides {utail.stride()}")
+    st = _stream()
+    n_out = B * T_out * V
+    nbytes = 4 * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + n_out * 128 * (1 if want_fs else 0) + B * 4 * V * 64)
+    flops = n_out * (2 * 2 * 2 * 64 * 64 + (2 * 192 * 64 + 4 * 64 * V if do_gcn else 0))
+    _lib.check(_timed("wn_layer_fwd", nbytes, flops,
+                      lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), wtcn.data_ptr(), btcn.data_ptr(),
+                                                   _ptr(prep), _ptr(Wm), _ptr(bm), _ptr(y), _ptr(fs), utail.data_ptr(),
+                                                   utail.stride(2), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
+                                                   float(momentum), float(eps), _ptr(scsh_out), _ptr(mean_rstd), _ptr(ws),
+                                                   B, T_in, V, dilation, 1 if do_gcn else 0, st)), "hopmi_wn_layer_fwd")
+    return y, fs, scsh_out, mean_rstd
+
+
 # ------------------------------------------------------------------------------------------- GRU
 class _GruLayerFn(torch.autograd.Function):
     """Recurrence of one bidirectional GRU layer (hopmi_gru_fwd / hopmi_gru_bwd).

@@ -66,6 +66,30 @@ int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const floa
                   float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
                   int n_slabs, int V, void* stream);
 
+/* ---- one fused WaveNet layer, forward: model/gwnet.py:181-237 (gated dilated TCN :186-200, the part of
+ *      the skip path that reaches the output :209-220, graph conv :224-231, residual :233, BatchNorm2d
+ *      batch statistics :237).  Activations channels-last [B][T][V][64].
+ *
+ *   xin      [B][T_in][V][64]  previous layer's PRE-BatchNorm output (or the start-conv output)
+ *   scsh_in  [128]             scale[64], shift[64] applied to xin on load (previous layer's BatchNorm as
+ *                              an affine map; ones / zeros for the first layer)
+ *   wtcn     [4][64][64]       Wf tap0, Wg tap0, Wf tap1, Wg tap1, each [out][in]  (filter_convs / gate_convs
+ *                              weight[:, :, 0, tap]);  btcn [128] = filter bias, gate bias
+ *   prep, Wm, bm               as hopmi_gcn_fwd (used when do_gcn)
+ *   y        [B][T_out][V][64] gcn(u) + bm + r^[t+d], pre-BatchNorm (nullable; T_out = T_in - dilation)
+ *   fs       [B][T_out][V][128] tanh and sigmoid gate values saved for the backward (nullable)
+ *   utail    u of the last 4 frames, row (b, f, v) at utail[((b*4 + f)*V + v)*utail_ld .. +64]
+ *   training-mode BatchNorm of y (all nullable together => no statistics): gamma, beta [64];
+ *   running_mean/var [64] updated in place (nullable); scsh_out [128] = this layer's scale/shift for the
+ *   next layer; mean_rstd_out [128]; ws = hopmi_wn_layer_ws_floats(...) floats of per-workgroup partials.
+ */
+size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation);
+int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn, const float* btcn,
+                       const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
+                       int utail_ld, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, float* scsh_out, float* mean_rstd_out, float* ws,
+                       int B, int T_in, int V, int dilation, int do_gcn, void* stream);
+
 /* ---- bidirectional GRU layer recurrence: model/HOP.py:166-167,248 (decoder nn.GRU, hidden 350) and
  *      model/multimodal_context_net.py:236-237,257 (discriminator nn.GRU, hidden 64); torch.nn.GRU
  *      semantics, gate order r,z,n, h0 = 0.

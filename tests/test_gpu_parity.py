@@ -161,6 +161,36 @@ def test_gwnet_vs_reference_golden(golden, V, training):
         assert_close(m.bn[i].running_var, g[f"bn{i}_rv"], what=f"bn{i} running_var")
 
 
+@pytest.mark.parametrize("V,B", [(9, 2), (42, 2), (9, 37), (42, 7)])
+@pytest.mark.parametrize("training", [True, False])
+def test_gwnet_fused_layers_nograd(golden, V, B, training):
+    """The fused WaveNet-layer kernels (no-grad path of gwnet.forward) against the oracle, and for B=2 against
+    the reference golden: output and, in training mode, the BatchNorm running statistics of all 8 layers."""
+    import hopmi
+    from oracle import fill, ref_cpu, spec
+    dev = _dev()
+    m = hopmi.gwnet(None, V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173,
+                    out_dim=173, residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512)
+    fill.fill_state_(m)
+    m.to(dev).train(training)
+    x0 = fill.uniform("gwnet.x0", (B, 173, V, 16))
+    with torch.no_grad():
+        out = m(x0.to(dev))
+    sd = spec.build_sd(spec.gwnet_spec(V, prefix=""))
+    with torch.no_grad():
+        want, upd = ref_cpu.gwnet_forward(sd, x0, prefix="", training=training)
+    assert_close(out, want, what="out vs oracle")
+    if B == 2:
+        g = golden(f"gwnet_V{V}_{'train' if training else 'eval'}")
+        assert_close(out, g["out"], what="out vs reference")
+    for i in range(8):
+        rm = upd[f"bn.{i}.running_mean"] if training else sd[f"bn.{i}.running_mean"]
+        rv = upd[f"bn.{i}.running_var"] if training else sd[f"bn.{i}.running_var"]
+        assert_close(m.bn[i].running_mean, rm, what=f"bn{i} running_mean")
+        assert_close(m.bn[i].running_var, rv, what=f"bn{i} running_var")
+        assert int(m.bn[i].num_batches_tracked) == (1 if training else 0)
+
+
 # ---------------------------------------------------------------------------------- full model
 def _make_model(V, dev):
     import hopmi
