@@ -314,8 +314,14 @@ __global__ __launch_bounds__(256) void gcn_bwd_reduce_kernel(const float* __rest
   const int psz = C * K3 + C + 2 * V * V;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= psz) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * psz + i];
+  float s = 0.f;                       // fixed order; 8 independent loads in flight per step
+  for (int b0 = 0; b0 < nblk; b0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (b0 + u < nblk) ? part[(size_t)(b0 + u) * psz + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   if (i < C * K3) dWm[i] = s;
   else if (i < C * K3 + C) dbm[i - C * K3] = s;
   else if (i < C * K3 + C + V * V) dA1[i - C * K3 - C] = s;

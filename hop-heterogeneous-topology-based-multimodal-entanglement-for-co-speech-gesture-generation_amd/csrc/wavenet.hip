@@ -242,30 +242,48 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
 
 // BatchNorm2d training-mode finalisation (gwnet.py:237; torch semantics: biased variance normalises,
 // unbiased variance feeds running_var, momentum 0.1): fixed-order sum of the per-workgroup partials.
-__global__ __launch_bounds__(64) void wn_bn_finalize_kernel(const float* __restrict__ part, int nblk, double n,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                            float momentum, float eps, float* __restrict__ scsh_out,
-                                                            float* __restrict__ mean_rstd_out) {
-  const int c = threadIdx.x;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += part[b * 2 * C + c];
-    s2 += part[b * 2 * C + C + c];
+__global__ __launch_bounds__(1024) void wn_bn_finalize_kernel(const float* __restrict__ part, int nblk, double n,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float momentum, float eps, float* __restrict__ scsh_out,
+                                                              float* __restrict__ mean_rstd_out) {
+  // 8 chunks x 128 columns (64 sums, 64 sums of squares): thread (chunk, col) adds the partials of the
+  // workgroups b = chunk (mod 8) in a fixed order with 8 independent loads in flight; then the 8 chunk
+  // sums are added in a fixed order (bitwise reproducible).
+  __shared__ double red[8][2 * C];
+  const int col = threadIdx.x & 127, chunk = threadIdx.x >> 7;
+  double acc = 0.0;
+  for (int b0 = chunk; b0 < nblk; b0 += 64) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 8 * u;
+      v[u] = (b < nblk) ? part[(size_t)b * 2 * C + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (double)v[u];
   }
-  const double mean = s1 / n;
-  double var = s2 / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * rstd;
-  scsh_out[c] = sc;
-  scsh_out[C + c] = beta[c] - (float)mean * sc;
-  mean_rstd_out[c] = (float)mean;
-  mean_rstd_out[C + c] = rstd;
-  if (running_mean != nullptr) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  red[chunk][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += red[k][c]; s2 += red[k][C + c]; }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scsh_out[c] = sc;
+    scsh_out[C + c] = beta[c] - (float)mean * sc;
+    mean_rstd_out[c] = (float)mean;
+    mean_rstd_out[C + c] = rstd;
+    if (running_mean != nullptr) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
   }
 }
 
@@ -344,7 +362,7 @@ extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const 
   }
   if (int e = check_launch("hopmi_wn_layer_fwd")) return e;
   if (stats) {
-    hipLaunchKernelGGL(wn_bn_finalize_kernel, dim3(1), dim3(64), 0, st, part, grid, (double)L.n_slabs * V, gamma, beta,
+    hipLaunchKernelGGL(wn_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, part, grid, (double)L.n_slabs * V, gamma, beta,
                        running_mean, running_var, momentum, eps, scsh_out, mean_rstd_out);
     return check_launch("hopmi_wn_bn_finalize");
   }

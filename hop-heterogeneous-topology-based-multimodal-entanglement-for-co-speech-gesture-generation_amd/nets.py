@@ -167,11 +167,42 @@ class ConvDiscriminator(nn.Module):
         self.out = nn.Linear(self.hidden_size, 1)
         self.out2 = nn.Linear(28, 1)
 
+    @staticmethod
+    def _conv3_cl(x, conv):
+        """Valid Conv1d(k=3) on channels-last x (B,T,C): the three taps side by side, one GEMM
+        (MIOpen's im2col path runs these tiny convs per sample: ~440 launches per training step)."""
+        T = x.shape[1] - 2
+        w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, -1)          # (O, 3*C), tap-major
+        return torch.nn.functional.linear(torch.cat([x[:, 0:T], x[:, 1:T + 1], x[:, 2:T + 2]], dim=2), w, conv.bias)
+
+    @staticmethod
+    def _bn_cl(x, bn, training):
+        """BatchNorm1d on channels-last x (B,T,C), torch semantics (batch stats over B and T)."""
+        if training:
+            var, mean = torch.var_mean(x, dim=(0, 1), unbiased=False)
+            with torch.no_grad():
+                n = x.shape[0] * x.shape[1]
+                bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+                bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+                bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        scale = bn.weight * torch.rsqrt(var + bn.eps)
+        return x * scale + (bn.bias - mean * scale)
+
+    def _pre_conv_cl(self, poses):
+        """pre_conv (multimodal_context_net.py:226-234) without leaving the (B,T,C) layout; LeakyReLU(True)
+        has slope 1.0, i.e. it is the identity."""
+        x = self._bn_cl(self._conv3_cl(poses, self.pre_conv[0]), self.pre_conv[1], self.training)
+        x = self._bn_cl(self._conv3_cl(x, self.pre_conv[3]), self.pre_conv[4], self.training)
+        return self._conv3_cl(x, self.pre_conv[6])
+
     def forward(self, poses, in_text=None):
-        feat = self.pre_conv(poses.transpose(1, 2)).transpose(1, 2)
-        if feat.is_cuda:        # same cell as the decoder: hand-written recurrence (multimodal_context_net.py:257)
+        if poses.is_cuda:       # GEMM-shaped convs + the hand-written GRU recurrence (same cell as the decoder)
+            feat = self._pre_conv_cl(poses)
             output = ops.gru_bidirectional(feat, self.gru, self.gru.dropout, self.training)
         else:                   # host-side use (CPU unit test of the stock-op part); never on the GPU path
+            feat = self.pre_conv(poses.transpose(1, 2)).transpose(1, 2)
             output, _ = self.gru(feat, None)
         output = output[:, :, :self.hidden_size] + output[:, :, self.hidden_size:]
         output = self.out(output.contiguous().view(-1, output.shape[2])).view(poses.shape[0], -1)

@@ -285,6 +285,29 @@ def test_train_llm_vs_reference_golden(golden, V, epoch, monkeypatch):
             assert checksum_close(checksum(sd[str(n)]), want, RTOL, atol), (n, checksum(sd[str(n)]), want)
 
 
+@pytest.mark.parametrize("P", [27, 126])
+def test_discriminator_vs_reference_golden(golden, P):
+    import hopmi
+    from oracle import fill
+    from oracle.golden_util import checksum, checksum_close
+    dev = _dev()
+    g = golden(f"disc_P{P}")
+    d = hopmi.ConvDiscriminator(P)
+    d.gru.dropout = 0.0
+    fill.fill_state_(d)
+    d.to(dev).train()
+    x = fill.normal("disc.poses", (3, 34, P), 0.3).to(dev).requires_grad_()
+    y = d(x)
+    assert_close(y, g["out"], what="D out")
+    torch.log(y + 1e-8).sum().backward()
+    assert_close(x.grad, g["dx"], what="D dx")
+    params = dict(d.named_parameters())
+    for n, want in zip(g["grad_names"], g["grad_cs"]):
+        assert checksum_close(checksum(params[str(n)].grad), want, RTOL), n
+    assert_close(d.pre_conv[1].running_mean, g["bn1_rm"], what="bn1 rm")
+    assert_close(d.pre_conv[1].running_var, g["bn1_rv"], what="bn1 rv")
+
+
 def test_native_library_is_loaded():
     """The driver records which in-tree .so the GPU tests loaded: make sure it is ours."""
     from hopmi import _lib
