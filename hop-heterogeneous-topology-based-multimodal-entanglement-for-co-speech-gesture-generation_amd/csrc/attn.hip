@@ -1,0 +1,470 @@
+// Audio->text "reprogramming" cross-attention of HOP (reference: model/HOP.py:289-299):
+//
+//   scores = einsum("blhe,she->bhls", Q, K);  A = dropout(softmax(scores / sqrt(E)));  O = einsum("bhls,she->blhe", A, V)
+//
+// with L = 34 audio frames, S = 1500 text prototypes shared by the whole batch, H = 8 heads, E = 128.
+// The reference materialises the (B,8,34,1500) score tensor (209 MB at B = 128) three times per forward;
+// here it never leaves the chip: flash-style online softmax, exact-fp32 MFMA (16x16x4) for both contractions.
+//
+// Rows (b, l) are flat: N = B*L query rows per head.  Workgroup = (64-row tile, head); wave w owns 16 rows
+// entirely (its softmax statistics never cross waves) and keeps their Q fragments in registers.  The 64-key
+// K and V chunks are streamed HBM/L2 -> registers -> LDS (register prefetch of the next chunk under the
+// current chunk's MFMAs).  Linear workgroup id = tile*H + head, so with H = 8 every head lives on one XCD
+// and its K/V (1.5 MB) stay in that XCD's L2 (speed only).  Dropout uses a stateless hash of
+// (seed, row, head, key) so the backward can regenerate the mask.
+#include "common.h"
+
+namespace hopmi {
+
+constexpr int AE = 128;            // head dim (d_keys = d_ff = 128, HOP.py:119)
+constexpr int AKC = 64;            // keys per chunk
+constexpr int ABM = 64;            // query rows per workgroup
+constexpr int ALD = AE + 4;        // LDS row stride of the K / V chunk images
+constexpr int APLD = AKC + 4;      // LDS row stride of a wave's P tile
+
+__device__ __forceinline__ unsigned attn_hash(unsigned seed, unsigned row, unsigned head, unsigned key) {
+  unsigned x = seed ^ (row * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (head * 0xC2B2AE3Du);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;      // murmur3 fmix32
+  return x;
+}
+
+__global__ __launch_bounds__(256) void reprog_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                              const float* __restrict__ Vv, float* __restrict__ O,
+                                                              float* __restrict__ lse, int N, int S, int H, float scale,
+                                                              unsigned drop_thresh, float drop_scale, unsigned seed) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;                                // [64][ALD]
+  float* Vs = Ks + AKC * ALD;                      // [64][ALD]
+  float* Ps = Vs + AKC * ALD;                      // [4 waves][16][APLD]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int h = blockIdx.x % H, tile = blockIdx.x / H;
+  const size_t rs = (size_t)H * AE;                                 // row stride of Q/K/V/O
+  const int row_a = tile * ABM + 16 * w + j;                        // A-layout row of this lane
+
+  // Q fragments: A[i = row][k = 16ii + 4q + e]
+  float4 qf[8];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(Q + (size_t)min(row_a, N - 1) * rs + (size_t)h * AE + 4 * q);
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) qf[ii] = qp[4 * ii];
+  }
+  f32x4 acc_o[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) acc_o[nt] = {0.f, 0.f, 0.f, 0.f};
+  float m_run[4], l_run[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_run[r] = -1e30f; l_run[r] = 0.f; }
+
+  // chunk staging: thread -> (key row = (tid >> 5) + 8 it, float4 column = tid & 31)
+  const int srow = tid >> 5, sc4 = tid & 31;
+  float4 kreg[8], vreg[8];
+  auto issue = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int key = min(c * AKC + srow + 8 * it, S - 1);
+      kreg[it] = reinterpret_cast<const float4*>(K + (size_t)key * rs + (size_t)h * AE)[sc4];
+      vreg[it] = reinterpret_cast<const float4*>(Vv + (size_t)key * rs + (size_t)h * AE)[sc4];
+    }
+  };
+  const int nchunk = (S + AKC - 1) / AKC;
+  issue(0);
+  float* Pw = Ps + w * 16 * APLD;
+
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                                               // previous chunk's LDS images consumed
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      *reinterpret_cast<float4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
+      *reinterpret_cast<float4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
+    }
+    __syncthreads();
+    if (c + 1 < nchunk) issue(c + 1);                              // lands under this chunk's MFMAs
+
+    // ---- scores: S[16 rows][64 keys] = Q K^T ------------------------------------------------------
+    f32x4 acc_s[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc_s[nt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      float4 b[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc_s[nt] = mfma16(qf[ii].x, b[nt].x, acc_s[nt]);
+        acc_s[nt] = mfma16(qf[ii].y, b[nt].y, acc_s[nt]);
+        acc_s[nt] = mfma16(qf[ii].z, b[nt].z, acc_s[nt]);
+        acc_s[nt] = mfma16(qf[ii].w, b[nt].w, acc_s[nt]);
+      }
+    }
+    // ---- online softmax over this chunk (lane holds rows 4q + r, key column 16 nt + j) -------------
+    const int key0 = c * AKC;
+    float p[4][4], alpha[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float sv = (key0 + 16 * nt + j < S) ? acc_s[nt][r] * scale : -1e30f;
+        p[nt][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+      mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+      const float m_new = fmaxf(m_run[r], mx);
+      alpha[r] = __expf(m_run[r] - m_new);
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float e = __expf(p[nt][r] - m_new);
+        p[nt][r] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+      l_run[r] = l_run[r] * alpha[r] + sum;
+      m_run[r] = m_new;
+    }
+    // dropout on the probabilities (HOP.py:296), P -> this wave's LDS tile in [row][key] order
+    const int row_c0 = tile * ABM + 16 * w + 4 * q;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = p[nt][r];
+        if (drop_thresh) pv = (attn_hash(seed, row_c0 + r, h, key0 + 16 * nt + j) >= drop_thresh) ? pv * drop_scale : 0.f;
+        Pw[(4 * q + r) * APLD + 16 * nt + j] = pv;
+      }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_o[nt][r] *= alpha[r];
+    __syncthreads();                                               // P tile visible (wave-private, but keeps waves in step)
+    // ---- O[16 rows][128] += P[16][64 keys] V[64 keys][128] ------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = *reinterpret_cast<const float4*>(Pw + j * APLD + 16 * i + 4 * q);     // A[row j][key 16i+4q+e]
+      const float* vb = Vs + (16 * i + 4 * q) * ALD + j;                                      // B[k = key][n = e]
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        acc_o[nt] = mfma16(a.x, vb[16 * nt], acc_o[nt]);
+        acc_o[nt] = mfma16(a.y, vb[ALD + 16 * nt], acc_o[nt]);
+        acc_o[nt] = mfma16(a.z, vb[2 * ALD + 16 * nt], acc_o[nt]);
+        acc_o[nt] = mfma16(a.w, vb[3 * ALD + 16 * nt], acc_o[nt]);
+      }
+    }
+  }
+
+  // ---- epilogue: normalise, store O and the log-sum-exp of every row ---------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = tile * ABM + 16 * w + 4 * q + r;
+    if (row < N) {
+      const float inv = 1.f / l_run[r];
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) O[(size_t)row * rs + (size_t)h * AE + 16 * nt + j] = acc_o[nt][r] * inv;
+      if (j == 0) lse[(size_t)row * H + h] = m_run[r] + __logf(l_run[r]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward.  With P = softmax(scale * Q K^T) (recomputed from the saved log-sum-exp), M the dropout keep
+// mask / (1 - p), delta[n][h] = sum_e dO O (computed by the caller):
+//   dV = (P o M)^T dO        dP = (dO V^T) o M        dS = P o (dP - delta) * scale
+//   dQ = dS K                dK = dS^T Q
+// Two kernels so that every output element has exactly one owner (no atomics, bitwise reproducible):
+//   reprog_attn_bwd_dq_kernel   grid (64-row query tile, head): like the forward, loops over key chunks
+//   reprog_attn_bwd_dkv_kernel  grid (64-key chunk, head): wave w owns 16 keys (K/V rows in registers, dK/dV
+//                               in accumulators) and loops over the query tiles staged through LDS
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reprog_attn_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                 const float* __restrict__ Vv, const float* __restrict__ dO,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 float* __restrict__ dQ, int N, int S, int H, float scale,
+                                                                 unsigned drop_thresh, float drop_scale, unsigned seed) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = Ks + AKC * ALD;
+  float* Ps = Vs + AKC * ALD;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int h = blockIdx.x % H, tile = blockIdx.x / H;
+  const size_t rs = (size_t)H * AE;
+  const int row_a = min(tile * ABM + 16 * w + j, N - 1);
+
+  float4 qf[8], dof[8];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(Q + (size_t)row_a * rs + (size_t)h * AE + 4 * q);
+    const float4* dp = reinterpret_cast<const float4*>(dO + (size_t)row_a * rs + (size_t)h * AE + 4 * q);
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) { qf[ii] = qp[4 * ii]; dof[ii] = dp[4 * ii]; }
+  }
+  float lse_r[4], del_r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(tile * ABM + 16 * w + 4 * q + r, N - 1);
+    lse_r[r] = lse[(size_t)row * H + h];
+    del_r[r] = delta[(size_t)row * H + h];
+  }
+  f32x4 acc_dq[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) acc_dq[nt] = {0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid >> 5, sc4 = tid & 31;
+  float4 kreg[8], vreg[8];
+  auto issue = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int key = min(c * AKC + srow + 8 * it, S - 1);
+      kreg[it] = reinterpret_cast<const float4*>(K + (size_t)key * rs + (size_t)h * AE)[sc4];
+      vreg[it] = reinterpret_cast<const float4*>(Vv + (size_t)key * rs + (size_t)h * AE)[sc4];
+    }
+  };
+  const int nchunk = (S + AKC - 1) / AKC;
+  issue(0);
+  float* Pw = Ps + w * 16 * APLD;
+  const int row_c0 = tile * ABM + 16 * w + 4 * q;
+
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      *reinterpret_cast<float4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
+      *reinterpret_cast<float4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
+    }
+    __syncthreads();
+    if (c + 1 < nchunk) issue(c + 1);
+
+    f32x4 acc_s[4], acc_dp[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      float4 bk[4], bv[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bk[nt] = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+        bv[nt] = *reinterpret_cast<const float4*>(Vs + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc_s[nt] = mfma16(qf[ii].x, bk[nt].x, acc_s[nt]);
+        acc_dp[nt] = mfma16(dof[ii].x, bv[nt].x, acc_dp[nt]);
+        acc_s[nt] = mfma16(qf[ii].y, bk[nt].y, acc_s[nt]);
+        acc_dp[nt] = mfma16(dof[ii].y, bv[nt].y, acc_dp[nt]);
+        acc_s[nt] = mfma16(qf[ii].z, bk[nt].z, acc_s[nt]);
+        acc_dp[nt] = mfma16(dof[ii].z, bv[nt].z, acc_dp[nt]);
+        acc_s[nt] = mfma16(qf[ii].w, bk[nt].w, acc_s[nt]);
+        acc_dp[nt] = mfma16(dof[ii].w, bv[nt].w, acc_dp[nt]);
+      }
+    }
+    const int key0 = c * AKC;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + 16 * nt + j;
+        const float pr = (key < S) ? __expf(acc_s[nt][r] * scale - lse_r[r]) : 0.f;
+        float dp = acc_dp[nt][r];
+        if (drop_thresh) dp = (attn_hash(seed, row_c0 + r, h, key) >= drop_thresh) ? dp * drop_scale : 0.f;
+        Pw[(4 * q + r) * APLD + 16 * nt + j] = pr * (dp - del_r[r]) * scale;              // dS
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = *reinterpret_cast<const float4*>(Pw + j * APLD + 16 * i + 4 * q);     // dS[row j][key]
+      const float* kb = Ks + (16 * i + 4 * q) * ALD + j;                                      // B[k = key][n = e]
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        acc_dq[nt] = mfma16(a.x, kb[16 * nt], acc_dq[nt]);
+        acc_dq[nt] = mfma16(a.y, kb[ALD + 16 * nt], acc_dq[nt]);
+        acc_dq[nt] = mfma16(a.z, kb[2 * ALD + 16 * nt], acc_dq[nt]);
+        acc_dq[nt] = mfma16(a.w, kb[3 * ALD + 16 * nt], acc_dq[nt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = tile * ABM + 16 * w + 4 * q + r;
+    if (row < N) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) dQ[(size_t)row * rs + (size_t)h * AE + 16 * nt + j] = acc_dq[nt][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                  const float* __restrict__ Vv, const float* __restrict__ dO,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  float* __restrict__ dK, float* __restrict__ dV, int N, int S,
+                                                                  int H, float scale, unsigned drop_thresh, float drop_scale,
+                                                                  unsigned seed) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;                                // [64 rows][ALD]
+  float* Ds = Qs + ABM * ALD;                      // [64 rows][ALD]  dO
+  float* Ps = Ds + ABM * ALD;                      // [4 waves][2][16][APLD]   (P o M)^T and dS^T tiles
+  float* Ls = Ps + 4 * 2 * 16 * APLD;              // [64] lse, [64] delta
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int h = blockIdx.x % H, chunk = blockIdx.x / H;
+  const size_t rs = (size_t)H * AE;
+  const int key_a = min(chunk * AKC + 16 * w + j, S - 1);        // A-layout key row of this lane
+
+  float4 kf[8], vf[8];
+  {
+    const float4* kp = reinterpret_cast<const float4*>(K + (size_t)key_a * rs + (size_t)h * AE + 4 * q);
+    const float4* vp = reinterpret_cast<const float4*>(Vv + (size_t)key_a * rs + (size_t)h * AE + 4 * q);
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) { kf[ii] = kp[4 * ii]; vf[ii] = vp[4 * ii]; }
+  }
+  f32x4 acc_dk[8], acc_dv[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) { acc_dk[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dv[nt] = {0.f, 0.f, 0.f, 0.f}; }
+
+  const int srow = tid >> 5, sc4 = tid & 31;
+  float4 qreg[8], dreg[8];
+  float lreg = 0.f, greg = 0.f;
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = min(t * ABM + srow + 8 * it, N - 1);
+      qreg[it] = reinterpret_cast<const float4*>(Q + (size_t)row * rs + (size_t)h * AE)[sc4];
+      dreg[it] = reinterpret_cast<const float4*>(dO + (size_t)row * rs + (size_t)h * AE)[sc4];
+    }
+    if (tid < ABM) {
+      const int row = min(t * ABM + tid, N - 1);
+      lreg = lse[(size_t)row * H + h];
+      greg = delta[(size_t)row * H + h];
+    }
+  };
+  const int ntile = (N + ABM - 1) / ABM;
+  issue(0);
+  float* Pw = Ps + w * 2 * 16 * APLD;              // (P o M)^T
+  float* Sw = Pw + 16 * APLD;                      // dS^T
+  const int key_c0 = chunk * AKC + 16 * w + 4 * q; // C-layout key rows 4q + r of this wave's tile
+
+  for (int t = 0; t < ntile; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      *reinterpret_cast<float4*>(Qs + (srow + 8 * it) * ALD + 4 * sc4) = qreg[it];
+      *reinterpret_cast<float4*>(Ds + (srow + 8 * it) * ALD + 4 * sc4) = dreg[it];
+    }
+    if (tid < ABM) { Ls[tid] = lreg; Ls[ABM + tid] = greg; }
+    __syncthreads();
+    if (t + 1 < ntile) issue(t + 1);
+
+    // S^T[16 keys][64 rows] = K_w Q^T ;  dP^T = V_w dO^T
+    f32x4 acc_s[4], acc_dp[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      float4 bq[4], bd[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bq[nt] = *reinterpret_cast<const float4*>(Qs + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+        bd[nt] = *reinterpret_cast<const float4*>(Ds + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc_s[nt] = mfma16(kf[ii].x, bq[nt].x, acc_s[nt]);
+        acc_dp[nt] = mfma16(vf[ii].x, bd[nt].x, acc_dp[nt]);
+        acc_s[nt] = mfma16(kf[ii].y, bq[nt].y, acc_s[nt]);
+        acc_dp[nt] = mfma16(vf[ii].y, bd[nt].y, acc_dp[nt]);
+        acc_s[nt] = mfma16(kf[ii].z, bq[nt].z, acc_s[nt]);
+        acc_dp[nt] = mfma16(vf[ii].z, bd[nt].z, acc_dp[nt]);
+        acc_s[nt] = mfma16(kf[ii].w, bq[nt].w, acc_s[nt]);
+        acc_dp[nt] = mfma16(vf[ii].w, bd[nt].w, acc_dp[nt]);
+      }
+    }
+    // lane holds key rows 4q + r, query-row column 16 nt + j
+    const int row0 = t * ABM;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int row = row0 + 16 * nt + j;
+      const float lrow = Ls[16 * nt + j], drow = Ls[ABM + 16 * nt + j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key_c0 + r;
+        const float pr = (key < S && row < N) ? __expf(acc_s[nt][r] * scale - lrow) : 0.f;
+        float keepf = 1.f;
+        if (drop_thresh) keepf = (attn_hash(seed, row, h, key) >= drop_thresh) ? drop_scale : 0.f;
+        Pw[(4 * q + r) * APLD + 16 * nt + j] = pr * keepf;                                   // (P o M)^T
+        Sw[(4 * q + r) * APLD + 16 * nt + j] = pr * (acc_dp[nt][r] * keepf - drow) * scale;  // dS^T
+      }
+    }
+    __syncthreads();
+    // dV_w[16 keys][128] += (P o M)^T[16][64 rows] dO[64 rows][128];  dK_w += dS^T Q
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 ap = *reinterpret_cast<const float4*>(Pw + j * APLD + 16 * i + 4 * q);   // A[key j][row 16i+4q+e]
+      const float4 as = *reinterpret_cast<const float4*>(Sw + j * APLD + 16 * i + 4 * q);
+      const float* db = Ds + (16 * i + 4 * q) * ALD + j;                                     // B[k = row][n = e]
+      const float* qb = Qs + (16 * i + 4 * q) * ALD + j;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        acc_dv[nt] = mfma16(ap.x, db[16 * nt], acc_dv[nt]);
+        acc_dk[nt] = mfma16(as.x, qb[16 * nt], acc_dk[nt]);
+        acc_dv[nt] = mfma16(ap.y, db[ALD + 16 * nt], acc_dv[nt]);
+        acc_dk[nt] = mfma16(as.y, qb[ALD + 16 * nt], acc_dk[nt]);
+        acc_dv[nt] = mfma16(ap.z, db[2 * ALD + 16 * nt], acc_dv[nt]);
+        acc_dk[nt] = mfma16(as.z, qb[2 * ALD + 16 * nt], acc_dk[nt]);
+        acc_dv[nt] = mfma16(ap.w, db[3 * ALD + 16 * nt], acc_dv[nt]);
+        acc_dk[nt] = mfma16(as.w, qb[3 * ALD + 16 * nt], acc_dk[nt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = key_c0 + r;
+    if (key < S) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        dK[(size_t)key * rs + (size_t)h * AE + 16 * nt + j] = acc_dk[nt][r];
+        dV[(size_t)key * rs + (size_t)h * AE + 16 * nt + j] = acc_dv[nt][r];
+      }
+    }
+  }
+}
+
+}  // namespace hopmi
+
+using namespace hopmi;
+
+extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
+                                     int N, int S, int H, int E, float scale, float p_drop, unsigned seed, void* stream) {
+  if (!q || !k || !v || !o || !lse) { set_error("hopmi_reprog_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (E != AE || N <= 0 || S <= 0 || H <= 0) {
+    set_error("hopmi_reprog_attn_fwd: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", N, S, H, E);
+    return HOPMI_EINVAL;
+  }
+  if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_reprog_attn_fwd: p_drop=%f outside [0,1)", p_drop); return HOPMI_EINVAL; }
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const int ntile = (N + ABM - 1) / ABM;
+  const size_t lds = (size_t)(2 * AKC * ALD + 4 * 16 * APLD) * sizeof(float);
+  hipLaunchKernelGGL(reprog_attn_fwd_kernel, dim3(ntile * H), dim3(256), lds, static_cast<hipStream_t>(stream), q, k, v, o,
+                     lse, N, S, H, scale, thresh, dscale, seed);
+  return check_launch("hopmi_reprog_attn_fwd");
+}
+
+extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
+                                     const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
+                                     float scale, float p_drop, unsigned seed, void* stream) {
+  if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv) { set_error("hopmi_reprog_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (E != AE || N <= 0 || S <= 0 || H <= 0) {
+    set_error("hopmi_reprog_attn_bwd: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", N, S, H, E);
+    return HOPMI_EINVAL;
+  }
+  if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_reprog_attn_bwd: p_drop=%f outside [0,1)", p_drop); return HOPMI_EINVAL; }
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t lds_q = (size_t)(2 * AKC * ALD + 4 * 16 * APLD) * sizeof(float);
+  hipLaunchKernelGGL(reprog_attn_bwd_dq_kernel, dim3(((N + ABM - 1) / ABM) * H), dim3(256), lds_q, st, q, k, v, d_o, lse, delta,
+                     dq, N, S, H, scale, thresh, dscale, seed);
+  if (int e = check_launch("hopmi_reprog_attn_bwd(dq)")) return e;
+  const size_t lds_kv = (size_t)(2 * ABM * ALD + 4 * 2 * 16 * APLD + 2 * ABM) * sizeof(float);
+  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel, dim3(((S + AKC - 1) / AKC) * H), dim3(256), lds_kv, st, q, k, v, d_o, lse,
+                     delta, dk, dv, N, S, H, scale, thresh, dscale, seed);
+  return check_launch("hopmi_reprog_attn_bwd(dkv)");
+}

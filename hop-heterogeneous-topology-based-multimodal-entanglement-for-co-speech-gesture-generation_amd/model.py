@@ -70,12 +70,18 @@ class ReprogrammingLayer(nn.Module):
         out = self.reprogramming(q, k, v).reshape(B, L, -1)
         return self.out_projection(self.activation(out))                       # HOP.py:284-285
 
+    _calls = 0          # dropout stream position (host side, no device sync)
+
     def reprogramming(self, q, k, v):
-        """HOP.py:289-299: softmax(q k^T / sqrt(E)) (dropout) v over the S prototypes."""
+        """HOP.py:289-299: softmax(q k^T / sqrt(E)) (dropout) v over the S prototypes -- flash-style HIP
+        kernel, the (B,H,L,S) score tensor is never materialised."""
         scale = 1.0 / sqrt(q.shape[-1])
-        scores = torch.einsum("blhe,she->bhls", q, k)
-        A = self.dropout(torch.softmax(scale * scores, dim=-1))
-        return torch.einsum("bhls,she->blhe", A, v)
+        p = self.dropout.p if self.training else 0.0
+        if q.shape[-1] != 128:
+            raise NotImplementedError("hopmi reprogramming kernel: head dim d_keys must be 128 (HOP.py:119)")
+        ReprogrammingLayer._calls += 1
+        seed = (torch.initial_seed() * 2654435761 + ReprogrammingLayer._calls * 40503) & 0xFFFFFFFF
+        return ops.reprog_attention(q, k, v, scale, p, seed)
 
 
 class Model(nn.Module):

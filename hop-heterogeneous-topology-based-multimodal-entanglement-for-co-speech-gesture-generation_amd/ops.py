@@ -139,6 +139,70 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
     return _GcnFn.apply(x, A1, A2, Wm, bm, prep)
 
 
+# ------------------------------------------------------------------- reprogramming cross-attention
+_M32 = 0xFFFFFFFF
+
+
+def attn_keep_mask(seed: int, N: int, H: int, S: int, p_drop: float, device) -> torch.Tensor:
+    """The dropout keep-mask of hopmi_reprog_attn_fwd as a (N,H,S) bool tensor: the same stateless hash
+    (murmur3 finaliser of seed ^ row*c1 ^ key*c2 ^ head*c3) evaluated with integer tensor ops."""
+    row = torch.arange(N, device=device, dtype=torch.int64).view(N, 1, 1)
+    head = torch.arange(H, device=device, dtype=torch.int64).view(1, H, 1)
+    key = torch.arange(S, device=device, dtype=torch.int64).view(1, 1, S)
+    x = (seed & _M32) ^ ((row * 0x9E3779B1) & _M32) ^ ((key * 0x85EBCA77) & _M32) ^ ((head * 0xC2B2AE3D) & _M32)
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & _M32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & _M32
+    x = x ^ (x >> 16)
+    return x >= int(p_drop * 4294967296.0)
+
+
+class _ReprogAttnFn(torch.autograd.Function):
+    """softmax(q k^T * scale) (dropout) v over the S prototypes without materialising the scores
+    (hopmi_reprog_attn_fwd).  q (B,L,H,E); k, v (S,H,E)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, p_drop, seed):
+        q, k, v = _dev_f32(q, "q"), _dev_f32(k, "k"), _dev_f32(v, "v")
+        B, Lq, H, E = q.shape
+        S = k.shape[0]
+        if k.shape != (S, H, E) or v.shape != (S, H, E):
+            raise _lib.HopmiError(f"hopmi reprog_attn: bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+        o = torch.empty_like(q)
+        lse = torch.empty(B, Lq, H, dtype=torch.float32, device=q.device)
+        Lb, st = _lib.lib(), _stream()
+        N = B * Lq
+        _lib.check(_timed("reprog_attn_fwd", 4 * (2 * N * H * E + 2 * S * H * E), 4 * N * H * S * E,
+                          lambda: Lb.hopmi_reprog_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
+                                                           lse.data_ptr(), N, S, H, E, float(scale), float(p_drop),
+                                                           int(seed) & _M32, st)), "hopmi_reprog_attn_fwd")
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale, ctx.p_drop, ctx.seed = float(scale), float(p_drop), int(seed) & _M32
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, Lq, H, E = q.shape
+        S = k.shape[0]
+        do = _dev_f32(do, "do")
+        delta = (do * o).sum(-1)                                    # (B,L,H): the only reduction left to torch
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        Lb, st = _lib.lib(), _stream()
+        N = B * Lq
+        _lib.check(_timed("reprog_attn_bwd", 4 * (4 * N * H * E + 4 * S * H * E), 14 * N * H * S * E,
+                          lambda: Lb.hopmi_reprog_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(),
+                                                           lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                                           dv.data_ptr(), N, S, H, E, ctx.scale, ctx.p_drop, ctx.seed, st)),
+                   "hopmi_reprog_attn_bwd")
+        return dq, dk, dv, None, None, None
+
+
+def reprog_attention(q, k, v, scale, p_drop=0.0, seed=0):
+    return _ReprogAttnFn.apply(q, k, v, scale, p_drop, seed)
+
+
 # ------------------------------------------------------------------------- fused WaveNet layer
 def _ptr(t):
     return None if t is None else t.data_ptr()

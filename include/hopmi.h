@@ -90,6 +90,22 @@ int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn
                        float momentum, float eps, float* scsh_out, float* mean_rstd_out, float* ws,
                        int B, int T_in, int V, int dilation, int do_gcn, void* stream);
 
+/* ---- reprogramming cross-attention: model/HOP.py:289-299 (ReprogrammingLayer.reprogramming)
+ *   o[n][h][:] = sum_s dropout(softmax_s(scale * q[n][h][:] . k[s][h][:])) v[s][h][:]
+ *   q, o [N][H][E] with N = B*L flat query rows; k, v [S][H][E] shared by the batch; E must be 128;
+ *   lse [N][H] = log-sum-exp of the scaled scores (saved for the backward).
+ *   Dropout keeps probability (n, h, s) iff hash(seed, n, h, s) >= p_drop * 2^32 (stateless, so the
+ *   backward regenerates the same mask); p_drop = 0 disables it.
+ */
+int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
+                          int N, int S, int H, int E, float scale, float p_drop, unsigned seed, void* stream);
+
+/* Backward of the above: d_o [N][H][E] -> dq [N][H][E], dk, dv [S][H][E].  delta [N][H] = sum_e d_o * o
+ * (one small reduction by the caller).  Two launches, every output element has one owner: no atomics. */
+int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
+                          const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
+                          float scale, float p_drop, unsigned seed, void* stream);
+
 /* ---- bidirectional GRU layer recurrence: model/HOP.py:166-167,248 (decoder nn.GRU, hidden 350) and
  *      model/multimodal_context_net.py:236-237,257 (discriminator nn.GRU, hidden 64); torch.nn.GRU
  *      semantics, gate order r,z,n, h0 = 0.

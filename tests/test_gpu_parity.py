@@ -102,6 +102,51 @@ def test_gcn_full_size_properties(V, B):
     assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b)
 
 
+# ------------------------------------------------------------------------- reprogramming attention
+@pytest.mark.parametrize("tag,B,S,d_llm,p_drop", [("tiny", 2, 50, 48, 0.0), ("real", 1, 1500, 768, 0.0),
+                                                     ("tiny", 5, 50, 48, 0.1), ("real", 3, 1500, 768, 0.1)])
+def test_reprogramming_layer_vs_oracle(golden, tag, B, S, d_llm, p_drop):
+    """ReprogrammingLayer with the flash-style HIP attention vs the oracle (and the reference golden at
+    p_drop = 0, B as in the fixture); with dropout the oracle is given the kernel's hash mask."""
+    import hopmi
+    from hopmi import ops
+    from oracle import fill, ref_cpu, spec
+    dev = _dev()
+    m = hopmi.ReprogrammingLayer(128, 8, 128, d_llm, attention_dropout=p_drop)
+    fill.fill_state_(m)
+    m.to(dev).train()
+    tgt = fill.normal("reprog.target", (B, 34, 128))
+    src = fill.uniform("reprog.source", (S, d_llm), 0.5)
+    gout = fill.uniform("reprog.gout", (B, 34, d_llm))
+    tg, sg = tgt.to(dev).requires_grad_(), src.to(dev).requires_grad_()
+    hopmi.ReprogrammingLayer._calls = 100
+    out = m(tg, sg, sg)
+    (out * gout.to(dev)).sum().backward()
+    seed = (torch.initial_seed() * 2654435761 + 101 * 40503) & 0xFFFFFFFF
+    mask = None
+    if p_drop > 0:
+        mask = ops.attn_keep_mask(seed, B * 34, 8, S, p_drop, "cpu").view(B, 34, 8, S).permute(0, 2, 1, 3).float()
+        assert 0.85 < mask.mean().item() < 0.95
+    sd = spec.build_sd(spec.reprog_spec(d_llm, prefix=""))
+    for v in sd.values():
+        v.requires_grad_(True)
+    to, so = tgt.clone().requires_grad_(), src.clone().requires_grad_()
+    want = ref_cpu.reprogramming_layer(sd, to, so, so, 8, prefix="", drop_mask=mask, p_drop=p_drop)
+    (want * gout).sum().backward()
+    assert_close(out, want, what="out")
+    assert_close(tg.grad, to.grad, what="dtarget")
+    assert_close(sg.grad, so.grad, what="dsource")
+    for n, p in m.named_parameters():
+        if n == "key_projection.bias":
+            # analytically zero (a per-key bias shifts every score of a query by the same amount and the
+            # softmax is shift invariant): both sides hold rounding noise only
+            assert p.grad.abs().max().item() <= 1e-4 * m.key_projection.weight.grad.abs().max().item() + 1e-6
+            continue
+        assert_close(p.grad, sd[n].grad, what=n)
+    if p_drop == 0 and B == (2 if tag == "tiny" else 1):
+        assert_close(out, golden(f"reprog_{tag}")["out"], what="out vs reference")
+
+
 # ------------------------------------------------------------------------------------ GRU kernels
 @pytest.mark.parametrize("B,T,I,H,L", [(3, 5, 7, 6, 2), (37, 34, 20, 350, 2), (5, 28, 8, 64, 4), (130, 9, 12, 18, 1)])
 def test_gru_fwd_bwd_vs_oracle(B, T, I, H, L):
@@ -250,7 +295,8 @@ def test_model_eval_vs_reference_golden(golden, V):
 
 # ---------------------------------------------------------------------------------- train step
 def _zero_grad_param(name):
-    return name.endswith("mlp.mlp.bias") or name in ("pre_conv.0.bias", "pre_conv.3.bias")
+    return (name.endswith("mlp.mlp.bias") or name in ("pre_conv.0.bias", "pre_conv.3.bias")
+            or name.endswith("key_projection.bias"))      # softmax is invariant to a per-key bias
 
 
 @pytest.mark.parametrize("V", [9, 42])

@@ -166,7 +166,8 @@ def zero_grad_param(name):
     gradient; what reaches Adam is rounding noise g ~ 1e-7 >> eps = 1e-8, which Adam turns
     into +-lr steps of arbitrary sign.  No two implementations (or BLAS builds) agree on
     those steps, so their post-step values are only checked to within lr per element."""
-    return name.endswith("mlp.mlp.bias") or name in ("pre_conv.0.bias", "pre_conv.3.bias")
+    return (name.endswith("mlp.mlp.bias") or name in ("pre_conv.0.bias", "pre_conv.3.bias")
+            or name.endswith("key_projection.bias"))      # softmax is invariant to a per-key bias
 
 
 def cpu_rng(kind, shape):
