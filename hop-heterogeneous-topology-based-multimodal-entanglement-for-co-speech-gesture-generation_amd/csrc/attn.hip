@@ -17,10 +17,37 @@
 namespace hopmi {
 
 constexpr int AE = 128;            // head dim (d_keys = d_ff = 128, HOP.py:119)
-constexpr int AKC = 64;            // keys per chunk
-constexpr int ABM = 64;            // query rows per workgroup
-constexpr int ALD = AE + 4;        // LDS row stride of the K / V chunk images
+constexpr int AKC = 32;            // keys per chunk in the forward / dQ kernels: 43 KB of LDS => 3 workgroups per CU
+constexpr int ABM = 64;            // query rows per workgroup (16 per wave)
+constexpr int ALD = AE + 4;        // LDS row stride of the K / V (Q / dO) images
 constexpr int APLD = AKC + 4;      // LDS row stride of a wave's P tile
+constexpr int KVK = 64;            // dK/dV kernel: keys per workgroup (16 per wave)
+constexpr int KVR = 32;            // dK/dV kernel: query rows per staged tile
+constexpr int KVPLD = KVR + 4;     // LDS row stride of its transposed P / dS tiles
+constexpr int AKT = AKC / 16;      // key tiles per chunk
+
+// Reductions over the 16 lanes of a DPP row (= the 16 key columns j a lane quad-group holds), on the VALU
+// with DPP modifiers instead of ds_bpermute round trips: xor 1, xor 2 (quad_perm), then row_half_mirror
+// (lane i <-> 7 - i of each half: the two quads of a half), then row_mirror (i <-> 15 - i: the two halves).
+// Every lane of the row ends up with the row's result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_<0x141>(v));     // row_half_mirror
+  v = fmaxf(v, dpp_<0x140>(v));     // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_<0xB1>(v);
+  v += dpp_<0x4E>(v);
+  v += dpp_<0x141>(v);
+  v += dpp_<0x140>(v);
+  return v;
+}
 
 __device__ __forceinline__ unsigned attn_hash(unsigned seed, unsigned row, unsigned head, unsigned key) {
   unsigned x = seed ^ (row * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (head * 0xC2B2AE3Du);
@@ -28,7 +55,9 @@ __device__ __forceinline__ unsigned attn_hash(unsigned seed, unsigned row, unsig
   return x;
 }
 
-__global__ __launch_bounds__(256) void reprog_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+// <= 168 registers => 3 waves per SIMD => 3 workgroups per CU: all 544 workgroups of the B = 128 shape are
+// resident at once (with 2 per CU a second, nearly empty round doubled the kernel time)
+__global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                               const float* __restrict__ Vv, float* __restrict__ O,
                                                               float* __restrict__ lse, int N, int S, int H, float scale,
                                                               unsigned drop_thresh, float drop_scale, unsigned seed) {
@@ -57,40 +86,39 @@ __global__ __launch_bounds__(256) void reprog_attn_fwd_kernel(const float* __res
 
   // chunk staging: thread -> (key row = (tid >> 5) + 8 it, float4 column = tid & 31)
   const int srow = tid >> 5, sc4 = tid & 31;
-  float4 kreg[8], vreg[8];
+  float4 kreg[AKC / 8], vreg[AKC / 8];
   auto issue = [&](int c) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < AKC / 8; ++it) {
       const int key = min(c * AKC + srow + 8 * it, S - 1);
       kreg[it] = reinterpret_cast<const float4*>(K + (size_t)key * rs + (size_t)h * AE)[sc4];
       vreg[it] = reinterpret_cast<const float4*>(Vv + (size_t)key * rs + (size_t)h * AE)[sc4];
     }
   };
   const int nchunk = (S + AKC - 1) / AKC;
-  issue(0);
   float* Pw = Ps + w * 16 * APLD;
 
   for (int c = 0; c < nchunk; ++c) {
+    issue(c);                                                      // other resident workgroups cover this latency
     __syncthreads();                                               // previous chunk's LDS images consumed
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < AKC / 8; ++it) {
       *reinterpret_cast<float4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
       *reinterpret_cast<float4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
     }
     __syncthreads();
-    if (c + 1 < nchunk) issue(c + 1);                              // lands under this chunk's MFMAs
 
     // ---- scores: S[16 rows][64 keys] = Q K^T ------------------------------------------------------
-    f32x4 acc_s[4];
+    f32x4 acc_s[AKT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc_s[nt] = {0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < AKT; ++nt) acc_s[nt] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii) {
-      float4 b[4];
+      float4 b[AKT];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+      for (int nt = 0; nt < AKT; ++nt) b[nt] = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * ALD + 16 * ii + 4 * q);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < AKT; ++nt) {
         acc_s[nt] = mfma16(qf[ii].x, b[nt].x, acc_s[nt]);
         acc_s[nt] = mfma16(qf[ii].y, b[nt].y, acc_s[nt]);
         acc_s[nt] = mfma16(qf[ii].z, b[nt].z, acc_s[nt]);
@@ -99,35 +127,34 @@ __global__ __launch_bounds__(256) void reprog_attn_fwd_kernel(const float* __res
     }
     // ---- online softmax over this chunk (lane holds rows 4q + r, key column 16 nt + j) -------------
     const int key0 = c * AKC;
-    float p[4][4], alpha[4];
+    float p[AKT][4], alpha[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float mx = -1e30f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < AKT; ++nt) {
         const float sv = (key0 + 16 * nt + j < S) ? acc_s[nt][r] * scale : -1e30f;
         p[nt][r] = sv;
         mx = fmaxf(mx, sv);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
-      mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+      mx = row16_max(mx);
       const float m_new = fmaxf(m_run[r], mx);
       alpha[r] = __expf(m_run[r] - m_new);
       float sum = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < AKT; ++nt) {
         const float e = __expf(p[nt][r] - m_new);
         p[nt][r] = e;
         sum += e;
       }
-      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+      sum = row16_sum(sum);
       l_run[r] = l_run[r] * alpha[r] + sum;
       m_run[r] = m_new;
     }
     // dropout on the probabilities (HOP.py:296), P -> this wave's LDS tile in [row][key] order
     const int row_c0 = tile * ABM + 16 * w + 4 * q;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < AKT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float pv = p[nt][r];
@@ -141,7 +168,7 @@ __global__ __launch_bounds__(256) void reprog_attn_fwd_kernel(const float* __res
     __syncthreads();                                               // P tile visible (wave-private, but keeps waves in step)
     // ---- O[16 rows][128] += P[16][64 keys] V[64 keys][128] ------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AKT; ++i) {
       const float4 a = *reinterpret_cast<const float4*>(Pw + j * APLD + 16 * i + 4 * q);     // A[row j][key 16i+4q+e]
       const float* vb = Vs + (16 * i + 4 * q) * ALD + j;                                      // B[k = key][n = e]
 #pragma unroll
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(256) void reprog_attn_fwd_kernel(const float* __res
 //   reprog_attn_bwd_dkv_kernel  grid (64-key chunk, head): wave w owns 16 keys (K/V rows in registers, dK/dV
 //                               in accumulators) and loops over the query tiles staged through LDS
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reprog_attn_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                                  const float* __restrict__ Vv, const float* __restrict__ dO,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
                                                                  float* __restrict__ dQ, int N, int S, int H, float scale,
@@ -210,43 +237,42 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dq_kernel(const float* __
   for (int nt = 0; nt < 8; ++nt) acc_dq[nt] = {0.f, 0.f, 0.f, 0.f};
 
   const int srow = tid >> 5, sc4 = tid & 31;
-  float4 kreg[8], vreg[8];
+  float4 kreg[AKC / 8], vreg[AKC / 8];
   auto issue = [&](int c) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < AKC / 8; ++it) {
       const int key = min(c * AKC + srow + 8 * it, S - 1);
       kreg[it] = reinterpret_cast<const float4*>(K + (size_t)key * rs + (size_t)h * AE)[sc4];
       vreg[it] = reinterpret_cast<const float4*>(Vv + (size_t)key * rs + (size_t)h * AE)[sc4];
     }
   };
   const int nchunk = (S + AKC - 1) / AKC;
-  issue(0);
   float* Pw = Ps + w * 16 * APLD;
   const int row_c0 = tile * ABM + 16 * w + 4 * q;
 
   for (int c = 0; c < nchunk; ++c) {
+    issue(c);
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < AKC / 8; ++it) {
       *reinterpret_cast<float4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
       *reinterpret_cast<float4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
     }
     __syncthreads();
-    if (c + 1 < nchunk) issue(c + 1);
 
-    f32x4 acc_s[4], acc_dp[4];
+    f32x4 acc_s[AKT], acc_dp[AKT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
+    for (int nt = 0; nt < AKT; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii) {
-      float4 bk[4], bv[4];
+      float4 bk[AKT], bv[AKT];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < AKT; ++nt) {
         bk[nt] = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * ALD + 16 * ii + 4 * q);
         bv[nt] = *reinterpret_cast<const float4*>(Vs + (16 * nt + j) * ALD + 16 * ii + 4 * q);
       }
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < AKT; ++nt) {
         acc_s[nt] = mfma16(qf[ii].x, bk[nt].x, acc_s[nt]);
         acc_dp[nt] = mfma16(dof[ii].x, bv[nt].x, acc_dp[nt]);
         acc_s[nt] = mfma16(qf[ii].y, bk[nt].y, acc_s[nt]);
@@ -259,7 +285,7 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dq_kernel(const float* __
     }
     const int key0 = c * AKC;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < AKT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + 16 * nt + j;
@@ -270,7 +296,7 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dq_kernel(const float* __
       }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AKT; ++i) {
       const float4 a = *reinterpret_cast<const float4*>(Pw + j * APLD + 16 * i + 4 * q);     // dS[row j][key]
       const float* kb = Ks + (16 * i + 4 * q) * ALD + j;                                      // B[k = key][n = e]
 #pragma unroll
@@ -295,18 +321,22 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dq_kernel(const float* __
 __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                                   const float* __restrict__ Vv, const float* __restrict__ dO,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                  float* __restrict__ dK, float* __restrict__ dV, int N, int S,
-                                                                  int H, float scale, unsigned drop_thresh, float drop_scale,
-                                                                  unsigned seed) {
+                                                                  float* __restrict__ dKp, float* __restrict__ dVp, int N, int S,
+                                                                  int H, int nsplit, float scale, unsigned drop_thresh,
+                                                                  float drop_scale, unsigned seed) {
+  // workgroup = (key chunk of 64, head, row split): the query-row tiles t = split, split + nsplit, ... are
+  // walked here and the partial dK / dV go to slab `split` of dKp / dVp ([nsplit][S][H][E]); the caller
+  // adds the slabs in a fixed order.
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                                // [64 rows][ALD]
-  float* Ds = Qs + ABM * ALD;                      // [64 rows][ALD]  dO
-  float* Ps = Ds + ABM * ALD;                      // [4 waves][2][16][APLD]   (P o M)^T and dS^T tiles
-  float* Ls = Ps + 4 * 2 * 16 * APLD;              // [64] lse, [64] delta
+  float* Qs = smem;                                // [32 rows][ALD]
+  float* Ds = Qs + KVR * ALD;                      // [32 rows][ALD]  dO
+  float* Ps = Ds + KVR * ALD;                      // [4 waves][2][16][KVPLD]   (P o M)^T and dS^T tiles
+  float* Ls = Ps + 4 * 2 * 16 * KVPLD;             // [32] lse, [32] delta
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
-  const int h = blockIdx.x % H, chunk = blockIdx.x / H;
+  const int nchunk = (S + KVK - 1) / KVK;
+  const int h = blockIdx.x % H, chunk = (blockIdx.x / H) % nchunk, split = blockIdx.x / (H * nchunk);
   const size_t rs = (size_t)H * AE;
-  const int key_a = min(chunk * AKC + 16 * w + j, S - 1);        // A-layout key row of this lane
+  const int key_a = min(chunk * KVK + 16 * w + j, S - 1);        // A-layout key row of this lane
 
   float4 kf[8], vf[8];
   {
@@ -320,52 +350,52 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* _
   for (int nt = 0; nt < 8; ++nt) { acc_dk[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dv[nt] = {0.f, 0.f, 0.f, 0.f}; }
 
   const int srow = tid >> 5, sc4 = tid & 31;
-  float4 qreg[8], dreg[8];
+  float4 qreg[KVR / 8], dreg[KVR / 8];
   float lreg = 0.f, greg = 0.f;
   auto issue = [&](int t) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = min(t * ABM + srow + 8 * it, N - 1);
+    for (int it = 0; it < KVR / 8; ++it) {
+      const int row = min(t * KVR + srow + 8 * it, N - 1);
       qreg[it] = reinterpret_cast<const float4*>(Q + (size_t)row * rs + (size_t)h * AE)[sc4];
       dreg[it] = reinterpret_cast<const float4*>(dO + (size_t)row * rs + (size_t)h * AE)[sc4];
     }
-    if (tid < ABM) {
-      const int row = min(t * ABM + tid, N - 1);
+    if (tid < KVR) {
+      const int row = min(t * KVR + tid, N - 1);
       lreg = lse[(size_t)row * H + h];
       greg = delta[(size_t)row * H + h];
     }
   };
-  const int ntile = (N + ABM - 1) / ABM;
-  issue(0);
-  float* Pw = Ps + w * 2 * 16 * APLD;              // (P o M)^T
-  float* Sw = Pw + 16 * APLD;                      // dS^T
-  const int key_c0 = chunk * AKC + 16 * w + 4 * q; // C-layout key rows 4q + r of this wave's tile
+  const int ntile = (N + KVR - 1) / KVR;
+  if (split < ntile) issue(split);
+  float* Pw = Ps + w * 2 * 16 * KVPLD;             // (P o M)^T
+  float* Sw = Pw + 16 * KVPLD;                     // dS^T
+  const int key_c0 = chunk * KVK + 16 * w + 4 * q; // C-layout key rows 4q + r of this wave's tile
 
-  for (int t = 0; t < ntile; ++t) {
+  for (int t = split; t < ntile; t += nsplit) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < KVR / 8; ++it) {
       *reinterpret_cast<float4*>(Qs + (srow + 8 * it) * ALD + 4 * sc4) = qreg[it];
       *reinterpret_cast<float4*>(Ds + (srow + 8 * it) * ALD + 4 * sc4) = dreg[it];
     }
-    if (tid < ABM) { Ls[tid] = lreg; Ls[ABM + tid] = greg; }
+    if (tid < KVR) { Ls[tid] = lreg; Ls[KVR + tid] = greg; }
     __syncthreads();
-    if (t + 1 < ntile) issue(t + 1);
+    if (t + nsplit < ntile) issue(t + nsplit);
 
-    // S^T[16 keys][64 rows] = K_w Q^T ;  dP^T = V_w dO^T
-    f32x4 acc_s[4], acc_dp[4];
+    // S^T[16 keys][32 rows] = K_w Q^T ;  dP^T = V_w dO^T
+    f32x4 acc_s[2], acc_dp[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
+    for (int nt = 0; nt < 2; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii) {
-      float4 bq[4], bd[4];
+      float4 bq[2], bd[2];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < 2; ++nt) {
         bq[nt] = *reinterpret_cast<const float4*>(Qs + (16 * nt + j) * ALD + 16 * ii + 4 * q);
         bd[nt] = *reinterpret_cast<const float4*>(Ds + (16 * nt + j) * ALD + 16 * ii + 4 * q);
       }
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < 2; ++nt) {
         acc_s[nt] = mfma16(kf[ii].x, bq[nt].x, acc_s[nt]);
         acc_dp[nt] = mfma16(vf[ii].x, bd[nt].x, acc_dp[nt]);
         acc_s[nt] = mfma16(kf[ii].y, bq[nt].y, acc_s[nt]);
@@ -377,27 +407,27 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* _
       }
     }
     // lane holds key rows 4q + r, query-row column 16 nt + j
-    const int row0 = t * ABM;
+    const int row0 = t * KVR;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < 2; ++nt) {
       const int row = row0 + 16 * nt + j;
-      const float lrow = Ls[16 * nt + j], drow = Ls[ABM + 16 * nt + j];
+      const float lrow = Ls[16 * nt + j], drow = Ls[KVR + 16 * nt + j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key_c0 + r;
         const float pr = (key < S && row < N) ? __expf(acc_s[nt][r] * scale - lrow) : 0.f;
         float keepf = 1.f;
         if (drop_thresh) keepf = (attn_hash(seed, row, h, key) >= drop_thresh) ? drop_scale : 0.f;
-        Pw[(4 * q + r) * APLD + 16 * nt + j] = pr * keepf;                                   // (P o M)^T
-        Sw[(4 * q + r) * APLD + 16 * nt + j] = pr * (acc_dp[nt][r] * keepf - drow) * scale;  // dS^T
+        Pw[(4 * q + r) * KVPLD + 16 * nt + j] = pr * keepf;                                   // (P o M)^T
+        Sw[(4 * q + r) * KVPLD + 16 * nt + j] = pr * (acc_dp[nt][r] * keepf - drow) * scale;  // dS^T
       }
     }
     __syncthreads();
-    // dV_w[16 keys][128] += (P o M)^T[16][64 rows] dO[64 rows][128];  dK_w += dS^T Q
+    // dV_w[16 keys][128] += (P o M)^T[16][32 rows] dO[32 rows][128];  dK_w += dS^T Q
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 ap = *reinterpret_cast<const float4*>(Pw + j * APLD + 16 * i + 4 * q);   // A[key j][row 16i+4q+e]
-      const float4 as = *reinterpret_cast<const float4*>(Sw + j * APLD + 16 * i + 4 * q);
+    for (int i = 0; i < 2; ++i) {
+      const float4 ap = *reinterpret_cast<const float4*>(Pw + j * KVPLD + 16 * i + 4 * q);  // A[key j][row 16i+4q+e]
+      const float4 as = *reinterpret_cast<const float4*>(Sw + j * KVPLD + 16 * i + 4 * q);
       const float* db = Ds + (16 * i + 4 * q) * ALD + j;                                     // B[k = row][n = e]
       const float* qb = Qs + (16 * i + 4 * q) * ALD + j;
 #pragma unroll
@@ -413,6 +443,8 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* _
       }
     }
   }
+  float* dK = dKp + (size_t)split * S * rs;
+  float* dV = dVp + (size_t)split * S * rs;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int key = key_c0 + r;
@@ -447,6 +479,10 @@ extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float
   return check_launch("hopmi_reprog_attn_fwd");
 }
 
+// dK/dV grid = 24 key chunks x 8 heads x splits workgroups at 2 resident per CU (512 slots): 8 splits make
+// it exactly 3 full rounds at the B = 128 shape
+extern "C" int hopmi_reprog_attn_bwd_splits(void) { return 8; }
+
 extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                                      const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
                                      float scale, float p_drop, unsigned seed, void* stream) {
@@ -463,8 +499,9 @@ extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float
   hipLaunchKernelGGL(reprog_attn_bwd_dq_kernel, dim3(((N + ABM - 1) / ABM) * H), dim3(256), lds_q, st, q, k, v, d_o, lse, delta,
                      dq, N, S, H, scale, thresh, dscale, seed);
   if (int e = check_launch("hopmi_reprog_attn_bwd(dq)")) return e;
-  const size_t lds_kv = (size_t)(2 * ABM * ALD + 4 * 2 * 16 * APLD + 2 * ABM) * sizeof(float);
-  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel, dim3(((S + AKC - 1) / AKC) * H), dim3(256), lds_kv, st, q, k, v, d_o, lse,
-                     delta, dk, dv, N, S, H, scale, thresh, dscale, seed);
+  const int nsplit = hopmi_reprog_attn_bwd_splits();
+  const size_t lds_kv = (size_t)(2 * KVR * ALD + 4 * 2 * 16 * KVPLD + 2 * KVR) * sizeof(float);
+  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel, dim3(((S + KVK - 1) / KVK) * H * nsplit), dim3(256), lds_kv, st, q, k, v, d_o,
+                     lse, delta, dk, dv, N, S, H, nsplit, scale, thresh, dscale, seed);
   return check_launch("hopmi_reprog_attn_bwd(dkv)");
 }

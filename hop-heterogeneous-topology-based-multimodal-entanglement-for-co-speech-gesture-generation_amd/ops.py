@@ -188,15 +188,18 @@ class _ReprogAttnFn(torch.autograd.Function):
         S = k.shape[0]
         do = _dev_f32(do, "do")
         delta = (do * o).sum(-1)                                    # (B,L,H): the only reduction left to torch
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         Lb, st = _lib.lib(), _stream()
+        R = Lb.hopmi_reprog_attn_bwd_splits()
+        dq = torch.empty_like(q)
+        dk = torch.empty((R,) + tuple(k.shape), dtype=torch.float32, device=q.device)
+        dv = torch.empty_like(dk)
         N = B * Lq
         _lib.check(_timed("reprog_attn_bwd", 4 * (4 * N * H * E + 4 * S * H * E), 14 * N * H * S * E,
                           lambda: Lb.hopmi_reprog_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(),
                                                            lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                                            dv.data_ptr(), N, S, H, E, ctx.scale, ctx.p_drop, ctx.seed, st)),
                    "hopmi_reprog_attn_bwd")
-        return dq, dk, dv, None, None, None
+        return dq, dk.sum(0), dv.sum(0), None, None, None
 
 
 def reprog_attention(q, k, v, scale, p_drop=0.0, seed=0):

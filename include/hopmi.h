@@ -100,8 +100,11 @@ int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn
 int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
                           int N, int S, int H, int E, float scale, float p_drop, unsigned seed, void* stream);
 
-/* Backward of the above: d_o [N][H][E] -> dq [N][H][E], dk, dv [S][H][E].  delta [N][H] = sum_e d_o * o
- * (one small reduction by the caller).  Two launches, every output element has one owner: no atomics. */
+/* Backward of the above: d_o [N][H][E] -> dq [N][H][E] and PARTIAL dk, dv [R][S][H][E] with
+ * R = hopmi_reprog_attn_bwd_splits() (the query rows are split R ways over workgroups; the caller adds the
+ * R slabs in order).  delta [N][H] = sum_e d_o * o (one small reduction by the caller).  Two launches,
+ * every output element has one owner: no atomics, bitwise reproducible. */
+int hopmi_reprog_attn_bwd_splits(void);
 int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                           const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
                           float scale, float p_drop, unsigned seed, void* stream);
