@@ -151,8 +151,17 @@ class Model(nn.Module):
         if self._cache is not None and "kv" in self._cache:
             return self._cache["kv"]
         with torch.enable_grad():
-            # HOP.py:200: mapping_layer(E^T)^T == W_map @ E + b[:, None]   (1500 x d_llm)
-            S = torch.addmm(self.mapping_layer.bias.unsqueeze(1), self.mapping_layer.weight, self.word_embeddings)
+            # HOP.py:200: mapping_layer(E^T)^T == W_map @ E + b[:, None]   (1500 x d_llm).  K = vocab (30522)
+            # is huge and M x N tiny (72 GEMM tiles on 256 CUs): split K into equal chunks as one strided
+            # batched GEMM (no copies) and add the partial products in a fixed order.
+            W, E = self.mapping_layer.weight, self.word_embeddings
+            ks = next((c for c in (6, 8, 4, 3, 2) if self.vocab_size % c == 0 and self.vocab_size // c >= 1024), 1)
+            if ks > 1 and W.is_cuda:
+                kc = self.vocab_size // ks
+                part = torch.bmm(W.view(W.shape[0], ks, kc).transpose(0, 1), E.view(ks, kc, E.shape[1]))
+                S = part.sum(0) + self.mapping_layer.bias.unsqueeze(1)
+            else:
+                S = torch.addmm(self.mapping_layer.bias.unsqueeze(1), W, E)
             kv = self.reprogramming_layer.project_source(S, S)
         if self._cache is not None:
             self._cache["kv"] = kv
