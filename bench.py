@@ -139,7 +139,7 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
-        gf = ks["gcn_fwd"]
+        gf = ks["wn_layer_fwd"]
         gbs = gf["bytes"] / (gf["total_ms"] * 1e-3) / 1e9
         tfl = gf["flops"] / (gf["total_ms"] * 1e-3) / 1e12
         out = {
@@ -152,17 +152,22 @@ def main():
                                    f"({'GAN phase' if args.epoch > 10 else 'epoch<=10: 2 generator forwards + backward + Adam'})",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "llm": "BERT-base geometry, 6 layers, random init, frozen", "losses": last},
-            "roofline": {"kernel": "gcn_fwd_kernel (gwnet graph conv, all 8 layers)", "bound": "hbm", "achieved": gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                         "launches": gf["launches"], "avg_us": 1e3 * gf["total_ms"] / gf["launches"],
+            # the gwnet graph conv runs inside the fused WaveNet-layer kernel (BN-on-load, gated TCN, skip tail,
+            # node mix, graph conv, residual, BN statistics): algorithmic bytes = xin read + y / saved gates /
+            # skip tail written, per launch
+            "roofline": {"kernel": "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv, 8 layers x 2 forwards)",
+                         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "launches": gf["launches"], "avg_us": 1e3 * gf["total_ms"] / gf["launches"],
                          "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
                          "f32_mfma_tflops": tfl, "f32_mfma_frac": tfl / F32_MFMA_PEAK_TFLOPS,
                          "timing": "HIP events around each launch on the launch stream, inside the timed region"},
         }
-        if "gcn_bwd" in ks:
-            gb = ks["gcn_bwd"]
-            out["roofline"]["gcn_bwd_GBps"] = gb["bytes"] / (gb["total_ms"] * 1e-3) / 1e9
-            out["roofline"]["gcn_bwd_avg_us"] = 1e3 * gb["total_ms"] / gb["launches"]
+        for name in ("wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "gru_fwd", "gru_bwd"):
+            if name in ks and ks[name]["launches"]:
+                k = ks[name]
+                out["roofline"][name + "_avg_us"] = 1e3 * k["total_ms"] / k["launches"]
+                if k["flops"]:
+                    out["roofline"][name + "_tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V)
         print(json.dumps(out), flush=True)

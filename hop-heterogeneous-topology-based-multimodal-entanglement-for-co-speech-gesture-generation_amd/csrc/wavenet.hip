@@ -17,32 +17,9 @@
 // gate; node mix on MFMA; channel contraction on MFMA; epilogue adds bias + residual (from the R1 panel),
 // stores y and accumulates the BatchNorm partial sums.  A tiny second kernel turns the per-workgroup
 // partials into mean / rstd / running stats / the next layer's scale+shift in a fixed order (reproducible).
-#include "gcn_dev.h"
+#include "wn_dev.h"
 
 namespace hopmi {
-
-struct LayerGeom {
-  GcnGeom g;       // V, S = output slabs per tile, mtiles, rows_lds, mix-matrix geometry, ntiles
-  int B, T_in, T_out, d;
-  int n_slabs;     // B * T_out
-  float invV, invT;  // 1/V, 1/T_out for the (row + 0.5) * inv index splits (exact for the ranges validated)
-};
-
-constexpr int WN_MAX_MT = 5;                       // <= 80 rows per tile
-
-static LayerGeom make_layer_geom(int B, int T_in, int V, int d, int grid_target) {
-  LayerGeom L;
-  L.B = B; L.T_in = T_in; L.d = d; L.T_out = T_in - d;
-  L.n_slabs = B * L.T_out;
-  int S = (L.n_slabs + grid_target - 1) / grid_target;            // one tile per workgroup when it fits ...
-  const int smax = (16 * WN_MAX_MT) / V > 0 ? (16 * WN_MAX_MT) / V : 1;
-  if (S > smax) S = smax;                                         // ... else walk several
-  if (S < 1) S = 1;
-  L.g = make_geom(L.n_slabs, V, S);
-  L.invV = 1.0f / V;
-  L.invT = 1.0f / L.T_out;
-  return L;
-}
 
 __device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -287,31 +264,9 @@ __global__ __launch_bounds__(1024) void wn_bn_finalize_kernel(const float* __res
   }
 }
 
-static int wn_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
-
 static int wn_grid(const LayerGeom& L) {
   const int cap = wn_env_int("HOPMI_WN_GRID", 256);
   return L.g.ntiles < cap ? L.g.ntiles : cap;
-}
-
-static int wn_validate(int B, int T_in, int V, int d) {
-  if (B <= 0 || V < 1 || V > HOPMI_MAX_NODES || d < 1 || T_in - d < 4) {
-    set_error("hopmi_wn_layer: bad geometry B=%d T_in=%d V=%d dilation=%d (need T_in - dilation >= 4, V in [1,%d])", B, T_in,
-              V, d, HOPMI_MAX_NODES);
-    return HOPMI_EINVAL;
-  }
-  if ((long long)B * T_in * V >= (1LL << 20) * 16) {
-    set_error("hopmi_wn_layer: B*T*V too large for the 32-bit row index math");
-    return HOPMI_EINVAL;
-  }
-  if ((long long)B * (T_in - d) >= (1 << 20)) {
-    set_error("hopmi_wn_layer: B*T_out >= 2^20 not supported (float index split)");
-    return HOPMI_EINVAL;
-  }
-  return HOPMI_OK;
 }
 
 template <int MT>

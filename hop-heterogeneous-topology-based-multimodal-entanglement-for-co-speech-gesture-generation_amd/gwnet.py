@@ -18,6 +18,82 @@ from . import ops
 DILATIONS = (1, 2, 1, 2, 1, 2, 1, 2)            # gwnet.py:98-121 with blocks=4, layers=2
 
 
+class _WaveNetStackFn(torch.autograd.Function):
+    """The 8 fused WaveNet layers, training mode, differentiable: x0 (B,T,V,64) start-conv output ->
+    (B,4,V,512) skip tails.  Forward = 8 hopmi_wn_layer_fwd calls (BatchNorm batch statistics, running
+    statistics advanced in place); backward = 8 hopmi_wn_layer_bwd calls in reverse, each handing the next
+    one its gradient as two tap tensors plus the BatchNorm-backward coefficients.
+
+    apply(x0, A1, A2, prep, bns, *params) with params = 8 x (wf, bf, wg, bg), 8 x (Wm, bm), 8 x (gamma, beta);
+    `bns` is the list of nn.BatchNorm2d modules (running-stat buffers, momentum, eps)."""
+
+    @staticmethod
+    def forward(ctx, x0, A1, A2, prep, bns, *params):
+        n = len(DILATIONS)
+        tcn = [params[4 * i:4 * i + 4] for i in range(n)]
+        mlp = [params[4 * n + 2 * i:4 * n + 2 * i + 2] for i in range(n)]
+        aff = [params[6 * n + 2 * i:6 * n + 2 * i + 2] for i in range(n)]
+        B, _, V, _ = x0.shape
+        dev = x0.device
+        tails = torch.empty(B, 4, V, 64 * n, dtype=torch.float32, device=dev)
+        scsh = torch.cat([torch.ones(64, device=dev), torch.zeros(64, device=dev)])
+        xin = x0.contiguous()
+        saved_x, saved_y, saved_fs, saved_scsh, saved_mr, saved_wtcn = [xin], [], [], [], [], []
+        for i, d in enumerate(DILATIONS):
+            wf, bf, wg, bg = tcn[i]
+            wtcn = torch.stack([wf[:, :, 0, 0], wg[:, :, 0, 0], wf[:, :, 0, 1], wg[:, :, 0, 1]]).contiguous()
+            btcn = torch.cat([bf, bg])
+            bn = bns[i]
+            last = i == n - 1
+            y, fs, scsh_out, mean_rstd = ops.wn_layer_fwd(
+                xin, scsh, wtcn, btcn, prep, mlp[i][0], mlp[i][1], tails[..., 64 * i:64 * (i + 1)], d,
+                want_y=not last, want_fs=True, do_gcn=True,
+                bn=(aff[i][0], aff[i][1], bn.running_mean, bn.running_var, bn.momentum, bn.eps))
+            bn.num_batches_tracked += 1
+            saved_fs.append(fs); saved_scsh.append(scsh); saved_wtcn.append(wtcn)
+            if not last:
+                saved_y.append(y); saved_mr.append(mean_rstd); saved_x.append(y)
+                scsh, xin = scsh_out, y
+        ctx.n_x, ctx.n_y = len(saved_x), len(saved_y)
+        ctx.save_for_backward(prep, *saved_x, *saved_y, *saved_fs, *saved_scsh, *saved_mr, *saved_wtcn,
+                              *[m[0] for m in mlp], *[a[0] for a in aff])
+        return tails
+
+    @staticmethod
+    def backward(ctx, dtails):
+        n = len(DILATIONS)
+        sv = list(ctx.saved_tensors)
+        prep = sv.pop(0)
+        take = lambda k: [sv.pop(0) for _ in range(k)]
+        xs, ys, fss, scshs, mrs, wtcns, Wms, gammas = take(n), take(n - 1), take(n), take(n), take(n - 1), take(n), take(n), take(n)
+        dtails = dtails.contiguous()
+        V = xs[0].shape[2]
+        dA1 = torch.zeros(V, V, dtype=torch.float32, device=dtails.device)
+        dA2 = torch.zeros_like(dA1)
+        g_tcn, g_mlp, g_aff = [None] * n, [(None, None)] * n, [(None, None)] * n
+        P0n = P1n = coef = None
+        for i in range(n - 1, -1, -1):
+            do_gcn = i < n - 1
+            r = ops.wn_layer_bwd(xs[i], scshs[i], fss[i], wtcns[i], prep if do_gcn else None, Wms[i] if do_gcn else None,
+                                 P0n, P1n, DILATIONS[i + 1] if do_gcn else 1, ys[i] if do_gcn else None, coef,
+                                 dtails[..., 64 * i:64 * (i + 1)], gammas[i - 1] if i > 0 else None,
+                                 mrs[i - 1] if i > 0 else None, DILATIONS[i], do_gcn=do_gcn)
+            dw = r["dwtcn"]
+            g_tcn[i] = (torch.stack([dw[0], dw[2]], -1).unsqueeze(2), r["dbtcn"][:64],
+                        torch.stack([dw[1], dw[3]], -1).unsqueeze(2), r["dbtcn"][64:])
+            if do_gcn:
+                g_mlp[i] = (r["dWm"].view(64, 192, 1, 1), r["dbm"])
+                dA1 += r["dA1"]; dA2 += r["dA2"]
+            if i > 0:
+                g_aff[i - 1] = (r["dgamma_prev"], r["dbeta_prev"])
+            P0n, P1n, coef = r["P0"], r["P1"], r["coef_prev"]
+        # gradient w.r.t. x0: tap 0 lands on frame t, tap 1 (+ residual) on frame t + d of layer 0
+        d0 = DILATIONS[0]
+        dx0 = F.pad(P0n, (0, 0, 0, 0, 0, d0)) + F.pad(P1n, (0, 0, 0, 0, d0, 0))
+        flat = [t for tup in g_tcn for t in tup] + [t for tup in g_mlp for t in tup] + [t for tup in g_aff for t in tup]
+        return (dx0, dA1, dA2, None, None, *flat)
+
+
 class nconv(nn.Module):
     """gwnet.py:8-14 -- einsum('ncvl,vw->ncwl'); kept for API parity (tiny, torch)."""
 
@@ -185,6 +261,18 @@ class gwnet(nn.Module):
         prep = ops.gcn_prepare(A1, A2)          # on-chip images of the mix matrices, shared by all layers
         if not torch.is_grad_enabled() and self.dropout == 0:
             return self._tail(self._skip_tails_fused(x, prep))
+        if self.training and self.dropout == 0:
+            # differentiable fused stack: one forward and one backward kernel per WaveNet layer
+            params = []
+            for i in range(len(DILATIONS)):
+                params += [self.filter_convs[i].weight, self.filter_convs[i].bias, self.gate_convs[i].weight, self.gate_convs[i].bias]
+            for i in range(len(DILATIONS)):
+                params += [self.gconv[i].mlp.mlp.weight, self.gconv[i].mlp.mlp.bias]
+            for i in range(len(DILATIONS)):
+                params += [self.bn[i].weight, self.bn[i].bias]
+            return self._tail(_WaveNetStackFn.apply(x, A1, A2, prep, list(self.bn), *params))
+        # eval-mode BatchNorm with autograd (fine-tuning with frozen statistics): composed from the gcn kernel
+        # and library GEMMs
         T_out = x.shape[1] - sum(DILATIONS)
         tails = []
         last = len(DILATIONS) - 1

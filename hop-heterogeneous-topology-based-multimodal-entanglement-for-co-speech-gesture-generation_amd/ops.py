@@ -247,6 +247,39 @@ def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, wan
     return y, fs, scsh_out, mean_rstd
 
 
+def wn_layer_bwd(xin, scsh_in, fs, wtcn, prep, Wm, P0n, P1n, d_next, y, bn_coef, dutail, gamma_prev, mean_rstd_prev,
+                 dilation, do_gcn=True):
+    """Backward of one fused WaveNet layer (hopmi_wn_layer_bwd).  Returns a dict of the outputs the header
+    documents; entries that do not exist for this call (do_gcn=False, first layer) are None."""
+    B, T_in, V, _ = xin.shape
+    T_out = T_in - dilation
+    dev = xin.device
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    out = dict(P0=new(B, T_out, V, 64), P1=new(B, T_out, V, 64), dwtcn=new(4, 64, 64), dbtcn=new(128),
+               dWm=new(64, 192) if do_gcn else None, dbm=new(64) if do_gcn else None,
+               dA1=new(V, V) if do_gcn else None, dA2=new(V, V) if do_gcn else None,
+               dgamma_prev=new(64) if gamma_prev is not None else None,
+               dbeta_prev=new(64) if gamma_prev is not None else None,
+               coef_prev=new(3, 64) if gamma_prev is not None else None)
+    L = _lib.lib()
+    ws = new(L.hopmi_wn_layer_bwd_ws_floats(B, T_in, V, dilation))
+    if dutail.stride(-1) != 1 or dutail.stride(2) % 4 or dutail.shape != (B, 4, V, 64):
+        raise _lib.HopmiError(f"hopmi wn_layer_bwd: bad dutail view {tuple(dutail.shape)} strides {dutail.stride()}")
+    st = _stream()
+    n_out = B * T_out * V
+    _lib.check(_timed("wn_layer_bwd", 4 * (2 * B * T_in * V * 64 + n_out * 64 * 5 + n_out * 128), 0,
+                      lambda: L.hopmi_wn_layer_bwd(xin.data_ptr(), scsh_in.data_ptr(), fs.data_ptr(), wtcn.data_ptr(),
+                                                   _ptr(prep), _ptr(Wm), _ptr(P0n), _ptr(P1n), int(d_next), _ptr(y),
+                                                   _ptr(bn_coef), dutail.data_ptr(), dutail.stride(2), _ptr(gamma_prev),
+                                                   _ptr(mean_rstd_prev), out["P0"].data_ptr(), out["P1"].data_ptr(),
+                                                   out["dwtcn"].data_ptr(), out["dbtcn"].data_ptr(), _ptr(out["dWm"]),
+                                                   _ptr(out["dbm"]), _ptr(out["dA1"]), _ptr(out["dA2"]),
+                                                   _ptr(out["dgamma_prev"]), _ptr(out["dbeta_prev"]), _ptr(out["coef_prev"]),
+                                                   ws.data_ptr(), B, T_in, V, dilation, 1 if do_gcn else 0, st)),
+               "hopmi_wn_layer_bwd")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- GRU
 class _GruLayerFn(torch.autograd.Function):
     """Recurrence of one bidirectional GRU layer (hopmi_gru_fwd / hopmi_gru_bwd).

@@ -90,6 +90,26 @@ int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn
                        float momentum, float eps, float* scsh_out, float* mean_rstd_out, float* ws,
                        int B, int T_in, int V, int dilation, int do_gcn, void* stream);
 
+/* Backward of one fused WaveNet layer (autograd of gwnet.py:181-237), see csrc/wavenet_bwd.hip.
+ *   xin, scsh_in, fs, wtcn, prep, Wm : as in / saved by the forward
+ *   P0n, P1n [B][T_out - d_next][V][64]: gradient w.r.t. this layer's BatchNorm output as written by the NEXT
+ *            layer's backward (its tap-0 / tap-1 contributions), d_next = that layer's dilation   (do_gcn only)
+ *   y, bn_coef [3][64]: this layer's pre-BN output and the dy = ca*dx^ + cb*y + ck coefficients that the next
+ *            layer's backward call produced (coef_prev there)                                     (do_gcn only)
+ *   dutail: gradient w.r.t. this layer's skip-tail block, rows of stride dutail_ld
+ *   gamma_prev, mean_rstd_prev: BatchNorm_{i-1} (nullable for the first layer)
+ * Outputs: P0, P1 [B][T_out][V][64] (for the previous layer / the start conv), dwtcn [4][64][64], dbtcn [128],
+ *   dWm [64][192], dbm [64], dA1, dA2 [V][V] (do_gcn only), dgamma_prev, dbeta_prev [64], coef_prev [3][64].
+ *   ws: hopmi_wn_layer_bwd_ws_floats(...) floats.  Two launches (layer kernel + fixed-order reduce). */
+size_t hopmi_wn_layer_bwd_ws_floats(int B, int T_in, int V, int dilation);
+int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wtcn,
+                       const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
+                       const float* y, const float* bn_coef, const float* dutail, int dutail_ld,
+                       const float* gamma_prev, const float* mean_rstd_prev,
+                       float* P0, float* P1, float* dwtcn, float* dbtcn, float* dWm, float* dbm, float* dA1,
+                       float* dA2, float* dgamma_prev, float* dbeta_prev, float* coef_prev, float* ws,
+                       int B, int T_in, int V, int dilation, int do_gcn, void* stream);
+
 /* ---- reprogramming cross-attention: model/HOP.py:289-299 (ReprogrammingLayer.reprogramming)
  *   o[n][h][:] = sum_s dropout(softmax_s(scale * q[n][h][:] . k[s][h][:])) v[s][h][:]
  *   q, o [N][H][E] with N = B*L flat query rows; k, v [S][H][E] shared by the batch; E must be 128;
