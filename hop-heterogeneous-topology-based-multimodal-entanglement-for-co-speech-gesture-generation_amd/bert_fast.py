@@ -1,0 +1,84 @@
+"""Fast path for the frozen BERT the reference passes into `HOP.Model` (HOP.py:90-91,204; built at
+run_ted.py:177-195 as HF `BertModel` truncated to 6 layers).
+
+`FrozenBertEncoder(llm)(inputs_embeds)` computes `llm(inputs_embeds=...).last_hidden_state` from the module's own
+parameters with the same arithmetic (HF modeling_bert: absolute position + token-type-0 embeddings, LayerNorm
+eps from the config, post-LN encoder layers, erf-GELU, no attention mask), but
+  * Q, K, V projections are one GEMM (N = 3*hidden) instead of three,
+  * bias + dropout + residual + LayerNorm and bias + GELU are single HIP kernels (ops.bias_*),
+  * the pooler (unused by HOP) and the output_attentions / output_hidden_states tuples are skipped,
+  * no parameter gradients are produced (the LLM is frozen); activation gradients flow as usual.
+Dropout follows the module's train/eval state with the config's probabilities (the reference leaves the LLM in
+train mode).  If the module is not BERT-shaped (the reference also supports LLaMA, run_ted.py:133-175) `supports()`
+is False and the caller invokes the module itself.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def supports(llm) -> bool:
+    try:
+        cfg = llm.config
+        lay = llm.encoder.layer[0]
+        _ = (llm.embeddings.position_embeddings.weight, llm.embeddings.token_type_embeddings.weight,
+             llm.embeddings.LayerNorm.weight, lay.attention.self.query.weight, lay.attention.output.dense.weight,
+             lay.attention.output.LayerNorm.weight, lay.intermediate.dense.weight, lay.output.dense.weight,
+             lay.output.LayerNorm.weight)
+        return (getattr(cfg, "hidden_act", None) == "gelu" and getattr(cfg, "position_embedding_type", "absolute") == "absolute"
+                and cfg.hidden_size % 4 == 0 and cfg.hidden_size <= 1024 and cfg.intermediate_size % 4 == 0
+                and not any(p.requires_grad for p in llm.parameters()))
+    except (AttributeError, IndexError, TypeError):
+        return False
+
+
+class FrozenBertEncoder:
+    _calls = 0
+
+    def __init__(self, llm):
+        self.llm = llm
+        self._qkv = {}
+
+    def _fused_qkv(self, i, att):
+        ver = (att.query.weight._version, att.key.weight._version, att.value.weight._version, att.query.weight.data_ptr())
+        hit = self._qkv.get(i)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                w = torch.cat([att.query.weight, att.key.weight, att.value.weight], 0).contiguous()
+                b = torch.cat([att.query.bias, att.key.bias, att.value.bias], 0).contiguous()
+            hit = (ver, w, b)
+            self._qkv[i] = hit
+        return hit[1], hit[2]
+
+    def _seed(self):
+        FrozenBertEncoder._calls += 1
+        return (torch.initial_seed() * 2246822519 + FrozenBertEncoder._calls * 3266489917) & 0xFFFFFFFF
+
+    def __call__(self, inputs_embeds):
+        llm, cfg = self.llm, self.llm.config
+        B, L, D = inputs_embeds.shape
+        H = cfg.num_attention_heads
+        train = llm.training
+        p_h = cfg.hidden_dropout_prob if train else 0.0
+        p_a = cfg.attention_probs_dropout_prob if train else 0.0
+        emb = llm.embeddings
+        # BertEmbeddings: LayerNorm(inputs_embeds + token_type[0] + position[:L]) then dropout
+        h = F.layer_norm(inputs_embeds + (emb.token_type_embeddings.weight[0] + emb.position_embeddings.weight[:L]),
+                         (D,), emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps)
+        if p_h > 0:
+            h = F.dropout(h, p_h, True)
+        for i, lay in enumerate(llm.encoder.layer):
+            att = lay.attention
+            wqkv, bqkv = self._fused_qkv(i, att.self)
+            qkv = F.linear(h, wqkv, bqkv).view(B, L, 3, H, D // H).permute(2, 0, 3, 1, 4)        # (3,B,H,L,dh)
+            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p_a)
+            a = a.transpose(1, 2).reshape(B, L, D)
+            o = F.linear(a, att.output.dense.weight)
+            h = ops.bias_dropout_residual_layernorm(o, att.output.dense.bias, h, att.output.LayerNorm.weight,
+                                                    att.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
+            f = ops.bias_gelu(F.linear(h, lay.intermediate.dense.weight), lay.intermediate.dense.bias)
+            o = F.linear(f, lay.output.dense.weight)
+            h = ops.bias_dropout_residual_layernorm(o, lay.output.dense.bias, h, lay.output.LayerNorm.weight,
+                                                    lay.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
+        return h

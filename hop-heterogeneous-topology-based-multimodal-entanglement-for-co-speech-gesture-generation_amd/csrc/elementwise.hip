@@ -1,0 +1,214 @@
+// Fused element-wise epilogues of the frozen BERT block on the HOP path (reference: HOP.py:204 calls HF
+// BertModel; the ops are transformers' BertSelfOutput / BertOutput / BertIntermediate):
+//
+//   bias_gelu        out = gelu_erf(x + b)                                  (BertIntermediate)
+//   bias_drop_res_ln out = LayerNorm(dropout(x + b) + residual) * g + beta  (BertSelfOutput, BertOutput; eps 1e-12)
+//
+// and their backward w.r.t. the ACTIVATIONS only (the LLM is frozen, HOP.py:90-91, but gradients flow through
+// it to the align / reprogramming / mapping layers).  Both are pure HBM streamers: 16-B loads, one pass.
+// LayerNorm rows (D <= 1024, D % 4 == 0; 768 for BERT-base) are one wave each: the row lives in registers,
+// mean/variance by DPP + cross-row shuffles, so x is read once and out written once.  Dropout uses the same
+// stateless hash as the attention kernel (seed, row, column) so the backward regenerates the mask.
+#include "common.h"
+
+namespace hopmi {
+
+__device__ __forceinline__ unsigned ew_hash(unsigned seed, unsigned row, unsigned col) {
+  unsigned x = seed ^ (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ float gelu_erf_(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+// x [M][N] (N % 4 == 0), bias [N]
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                            float* __restrict__ out, size_t n4, int N4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(bias)[i % N4];
+    reinterpret_cast<float4*>(out)[i] = make_float4(gelu_erf_(v.x + b.x), gelu_erf_(v.y + b.y), gelu_erf_(v.z + b.z), gelu_erf_(v.w + b.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                            const float* __restrict__ dy, float* __restrict__ dx, size_t n4,
+                                                            int N4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(bias)[i % N4];
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    reinterpret_cast<float4*>(dx)[i] = make_float4(g.x * gelu_erf_grad_(v.x + b.x), g.y * gelu_erf_grad_(v.y + b.y),
+                                                   g.z * gelu_erf_grad_(v.z + b.z), g.w * gelu_erf_grad_(v.w + b.w));
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+constexpr int LN_MAX4 = 4;            // float4 per lane: D <= 64 * 4 * 4 = 1024
+
+// one wave per row: z = dropout(x + bias) + res[row % res_rows] ; out = (z - mean) * rstd * gamma + beta
+// saves z's normalised form xhat and rstd for the backward.
+__global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                   const float* __restrict__ res, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ out,
+                                                                   float* __restrict__ xhat, float* __restrict__ rstd_out, int M,
+                                                                   int D, int res_rows, float eps, unsigned drop_thresh,
+                                                                   float drop_scale, unsigned seed) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int D4 = D >> 2;
+  float4 z[LN_MAX4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX4; ++k) {
+    const int c4 = lane + 64 * k;
+    z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < D4) {
+      float4 v = reinterpret_cast<const float4*>(x)[(size_t)row * D4 + c4];
+      const float4 b = reinterpret_cast<const float4*>(bias)[c4];
+      const float4 r = reinterpret_cast<const float4*>(res)[(size_t)(row % res_rows) * D4 + c4];
+      v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+      if (drop_thresh) {
+        const unsigned col = 4 * c4;
+        v.x = ew_hash(seed, row, col) >= drop_thresh ? v.x * drop_scale : 0.f;
+        v.y = ew_hash(seed, row, col + 1) >= drop_thresh ? v.y * drop_scale : 0.f;
+        v.z = ew_hash(seed, row, col + 2) >= drop_thresh ? v.z * drop_scale : 0.f;
+        v.w = ew_hash(seed, row, col + 3) >= drop_thresh ? v.w * drop_scale : 0.f;
+      }
+      z[k] = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+      s += z[k].x + z[k].y + z[k].z + z[k].w;
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX4; ++k) {
+    if (lane + 64 * k < D4) {
+      const float a = z[k].x - mean, b = z[k].y - mean, c = z[k].z - mean, d = z[k].w - mean;
+      s2 += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / D + eps);
+#pragma unroll
+  for (int k = 0; k < LN_MAX4; ++k) {
+    const int c4 = lane + 64 * k;
+    if (c4 < D4) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c4], be = reinterpret_cast<const float4*>(beta)[c4];
+      const float4 h = make_float4((z[k].x - mean) * rstd, (z[k].y - mean) * rstd, (z[k].z - mean) * rstd, (z[k].w - mean) * rstd);
+      reinterpret_cast<float4*>(out)[(size_t)row * D4 + c4] = make_float4(h.x * g.x + be.x, h.y * g.y + be.y, h.z * g.z + be.z, h.w * g.w + be.w);
+      if (xhat != nullptr) reinterpret_cast<float4*>(xhat)[(size_t)row * D4 + c4] = h;
+    }
+  }
+  if (rstd_out != nullptr && lane == 0) rstd_out[row] = rstd;
+}
+
+// dz = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)), dxh = dout * gamma ; dres = dz ; dx = dz o dropout mask
+__global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
+                                                                   const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                                   float* __restrict__ dx, float* __restrict__ dres, int M, int D,
+                                                                   unsigned drop_thresh, float drop_scale, unsigned seed) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int D4 = D >> 2;
+  float4 dh[LN_MAX4], xh[LN_MAX4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX4; ++k) {
+    const int c4 = lane + 64 * k;
+    dh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[k] = dh[k];
+    if (c4 < D4) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+      const float4 d = reinterpret_cast<const float4*>(dout)[(size_t)row * D4 + c4];
+      xh[k] = reinterpret_cast<const float4*>(xhat)[(size_t)row * D4 + c4];
+      dh[k] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      s1 += dh[k].x + dh[k].y + dh[k].z + dh[k].w;
+      s2 += dh[k].x * xh[k].x + dh[k].y * xh[k].y + dh[k].z * xh[k].z + dh[k].w * xh[k].w;
+    }
+  }
+  const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D, rstd = rstd_in[row];
+#pragma unroll
+  for (int k = 0; k < LN_MAX4; ++k) {
+    const int c4 = lane + 64 * k;
+    if (c4 < D4) {
+      float4 dz = make_float4(rstd * (dh[k].x - m1 - xh[k].x * m2), rstd * (dh[k].y - m1 - xh[k].y * m2),
+                              rstd * (dh[k].z - m1 - xh[k].z * m2), rstd * (dh[k].w - m1 - xh[k].w * m2));
+      reinterpret_cast<float4*>(dres)[(size_t)row * D4 + c4] = dz;
+      if (drop_thresh) {
+        const unsigned col = 4 * c4;
+        dz.x = ew_hash(seed, row, col) >= drop_thresh ? dz.x * drop_scale : 0.f;
+        dz.y = ew_hash(seed, row, col + 1) >= drop_thresh ? dz.y * drop_scale : 0.f;
+        dz.z = ew_hash(seed, row, col + 2) >= drop_thresh ? dz.z * drop_scale : 0.f;
+        dz.w = ew_hash(seed, row, col + 3) >= drop_thresh ? dz.w * drop_scale : 0.f;
+      }
+      reinterpret_cast<float4*>(dx)[(size_t)row * D4 + c4] = dz;
+    }
+  }
+}
+
+static int ew_check(int M, int N, const char* what) {
+  if (M <= 0 || N <= 0 || (N & 3)) { set_error("%s: need M > 0, N > 0, N %% 4 == 0 (M=%d N=%d)", what, M, N); return HOPMI_EINVAL; }
+  return HOPMI_OK;
+}
+
+}  // namespace hopmi
+
+using namespace hopmi;
+
+extern "C" int hopmi_bias_gelu_fwd(const float* x, const float* bias, float* out, int M, int N, void* stream) {
+  if (int e = ew_check(M, N, "hopmi_bias_gelu_fwd")) return e;
+  if (!x || !bias || !out) { set_error("hopmi_bias_gelu_fwd: null pointer argument"); return HOPMI_EINVAL; }
+  const size_t n4 = (size_t)M * N / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(bias_gelu_fwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, out, n4, N / 4);
+  return check_launch("hopmi_bias_gelu_fwd");
+}
+
+extern "C" int hopmi_bias_gelu_bwd(const float* x, const float* bias, const float* dy, float* dx, int M, int N, void* stream) {
+  if (int e = ew_check(M, N, "hopmi_bias_gelu_bwd")) return e;
+  if (!x || !bias || !dy || !dx) { set_error("hopmi_bias_gelu_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  const size_t n4 = (size_t)M * N / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, dy, dx, n4, N / 4);
+  return check_launch("hopmi_bias_gelu_bwd");
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const float* bias, const float* res, int res_rows,
+                                                         const float* gamma, const float* beta, float* out, float* xhat,
+                                                         float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
+                                                         void* stream) {
+  if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_fwd")) return e;
+  if (!x || !bias || !res || !gamma || !beta || !out) { set_error("hopmi_bias_dropout_residual_layernorm_fwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (D > 256 * LN_MAX4 || res_rows <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
+    set_error("hopmi_bias_dropout_residual_layernorm_fwd: D=%d (max %d), res_rows=%d, p_drop=%f", D, 256 * LN_MAX4, res_rows, p_drop);
+    return HOPMI_EINVAL;
+  }
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, res,
+                     gamma, beta, out, xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed);
+  return check_launch("hopmi_bias_dropout_residual_layernorm_fwd");
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xhat, const float* rstd,
+                                                         const float* gamma, float* dx, float* dres, int M, int D,
+                                                         float p_drop, unsigned seed, void* stream) {
+  if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
+  if (!dout || !xhat || !rstd || !gamma || !dx || !dres) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (D > 256 * LN_MAX4 || !(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: D=%d p_drop=%f", D, p_drop); return HOPMI_EINVAL; }
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dout, xhat, rstd,
+                     gamma, dx, dres, M, D, thresh, dscale, seed);
+  return check_launch("hopmi_bias_dropout_residual_layernorm_bwd");
+}

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import bert_fast
 from . import gwnet as _gwnet
 from . import ops
 
@@ -135,6 +136,7 @@ class Model(nn.Module):
                                  nn.Linear(self.hidden_size // 2, self.pred_g_len))
         self._randn_like = torch.randn_like      # tests inject CPU-drawn noise here
         self._cache = None
+        self._bert_fast = None
 
     # -- per-step cache of the batch-independent prototype branch -------------------------------
     @contextlib.contextmanager
@@ -172,6 +174,12 @@ class Model(nn.Module):
         return self.forecast(in_audio, x_enc, text, pre_seq, vid_indices)
 
     def _llm(self, inputs_embeds):
+        """HOP.py:204.  A frozen HF BERT on a ROCm device runs through the fused fast path (same arithmetic,
+        fused QKV GEMM + HIP epilogues); anything else (LLaMA/GPT-2 options of run_ted.py:133-175) is called as is."""
+        if inputs_embeds.is_cuda and self._bert_fast is None:
+            self._bert_fast = bert_fast.FrozenBertEncoder(self.llm_model) if bert_fast.supports(self.llm_model) else False
+        if inputs_embeds.is_cuda and self._bert_fast:
+            return self._bert_fast(inputs_embeds)
         return self.llm_model(inputs_embeds=inputs_embeds).last_hidden_state
 
     def forecast(self, in_audio, x_enc, text, pre_seq, vid_indices):

@@ -139,6 +139,86 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
     return _GcnFn.apply(x, A1, A2, Wm, bm, prep)
 
 
+# ------------------------------------------------------- fused BERT epilogues (frozen LLM: no parameter grads)
+class _BiasGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        x, bias = _dev_f32(x, "x"), _dev_f32(bias.detach(), "bias")
+        N = x.shape[-1]
+        M = x.numel() // N
+        out = torch.empty_like(x)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_gelu_fwd", 8 * x.numel(), 0,
+                          lambda: L.hopmi_bias_gelu_fwd(x.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, st)),
+                   "hopmi_bias_gelu_fwd")
+        ctx.save_for_backward(x, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bias = ctx.saved_tensors
+        dy = _dev_f32(dy, "dy")
+        N = x.shape[-1]
+        M = x.numel() // N
+        dx = torch.empty_like(x)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_gelu_bwd", 12 * x.numel(), 0,
+                          lambda: L.hopmi_bias_gelu_bwd(x.data_ptr(), bias.data_ptr(), dy.data_ptr(), dx.data_ptr(), M, N, st)),
+                   "hopmi_bias_gelu_bwd")
+        return dx, None
+
+
+def bias_gelu(x, bias):
+    """gelu_erf(x + bias); gradient w.r.t. x only (frozen-LLM epilogue)."""
+    return _BiasGeluFn.apply(x, bias)
+
+
+class _BiasDropResLnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, res, gamma, beta, eps, p_drop, seed):
+        x, res = _dev_f32(x, "x"), _dev_f32(res, "res")
+        bias, gamma, beta = (_dev_f32(t.detach(), n) for t, n in ((bias, "bias"), (gamma, "gamma"), (beta, "beta")))
+        D = x.shape[-1]
+        M = x.numel() // D
+        res_rows = res.numel() // D
+        need = x.requires_grad or res.requires_grad
+        out = torch.empty_like(x)
+        xhat = torch.empty_like(x) if need else None
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device) if need else None
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_drop_res_ln_fwd", 4 * x.numel() * (4 if need else 3), 0,
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_fwd(
+                              x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
+                              out.data_ptr(), _ptr(xhat), _ptr(rstd), M, D, float(eps), float(p_drop), int(seed) & _M32, st)),
+                   "hopmi_bias_dropout_residual_layernorm_fwd")
+        if need:
+            ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.p_drop, ctx.seed, ctx.res_shape, ctx.x_rows = float(p_drop), int(seed) & _M32, res.shape, M
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xhat, rstd, gamma = ctx.saved_tensors
+        dout = _dev_f32(dout, "dout")
+        D = xhat.shape[-1]
+        M = ctx.x_rows
+        dx, dres = torch.empty_like(xhat), torch.empty_like(xhat)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_drop_res_ln_bwd", 16 * xhat.numel(), 0,
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_bwd(
+                              dout.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                              dres.data_ptr(), M, D, ctx.p_drop, ctx.seed, st)),
+                   "hopmi_bias_dropout_residual_layernorm_bwd")
+        if tuple(ctx.res_shape) != tuple(dres.shape):            # broadcast residual (e.g. position embeddings)
+            dres = dres.view(-1, *ctx.res_shape).sum(0)
+        return dx, None, dres, None, None, None, None, None
+
+
+def bias_dropout_residual_layernorm(x, bias, res, gamma, beta, eps, p_drop=0.0, seed=0):
+    """LayerNorm(dropout(x + bias) + res) * gamma + beta; gradients w.r.t. x and res only."""
+    return _BiasDropResLnFn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
+
+
 # ------------------------------------------------------------------- reprogramming cross-attention
 _M32 = 0xFFFFFFFF
 

@@ -129,6 +129,23 @@ int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const 
                           const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
                           float scale, float p_drop, unsigned seed, void* stream);
 
+/* ---- fused element-wise epilogues of the frozen BERT block (HOP.py:204 -> transformers BertIntermediate /
+ *      BertSelfOutput / BertOutput), forward and backward w.r.t. activations (the LLM is frozen, HOP.py:90-91).
+ *   bias_gelu:  out[M][N] = gelu_erf(x + bias)                     dx = dy * gelu'(x + bias)
+ *   bias_dropout_residual_layernorm:
+ *       z = dropout(x + bias) + res[row % res_rows];  out = LayerNorm_eps(z) * gamma + beta
+ *       saves xhat [M][D] and rstd [M] (nullable in inference);  backward returns dx (through the dropout
+ *       mask, regenerated from the same (seed,row,col) hash) and dres.  N, D multiples of 4, D <= 1024. */
+int hopmi_bias_gelu_fwd(const float* x, const float* bias, float* out, int M, int N, void* stream);
+int hopmi_bias_gelu_bwd(const float* x, const float* bias, const float* dy, float* dx, int M, int N, void* stream);
+int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const float* bias, const float* res, int res_rows,
+                                              const float* gamma, const float* beta, float* out, float* xhat,
+                                              float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
+                                              void* stream);
+int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xhat, const float* rstd,
+                                              const float* gamma, float* dx, float* dres, int M, int D,
+                                              float p_drop, unsigned seed, void* stream);
+
 /* ---- bidirectional GRU layer recurrence: model/HOP.py:166-167,248 (decoder nn.GRU, hidden 350) and
  *      model/multimodal_context_net.py:236-237,257 (discriminator nn.GRU, hidden 64); torch.nn.GRU
  *      semantics, gate order r,z,n, h0 = 0.

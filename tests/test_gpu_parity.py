@@ -102,6 +102,61 @@ def test_gcn_full_size_properties(V, B):
     assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b)
 
 
+# ------------------------------------------------------------------------- frozen BERT fast path
+@pytest.mark.parametrize("tag", ["tiny", "base2"])
+def test_bert_fast_path_vs_reference_golden(golden, tag):
+    """FrozenBertEncoder (fused QKV GEMM + HIP bias/GELU/dropout/residual/LayerNorm kernels) vs the HF BertModel
+    golden: output and the activation gradient."""
+    from transformers import BertConfig, BertModel
+    from hopmi import bert_fast
+    from oracle import fill
+    from oracle.golden_util import tiny_bert_config
+    dev = _dev()
+    g = golden(f"bert_{tag}")
+    cfg = tiny_bert_config() if tag == "tiny" else BertConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = BertModel(cfg)
+    fill.fill_state_(m)
+    for p in m.parameters():
+        p.requires_grad = False
+    m.to(dev).train()
+    assert bert_fast.supports(m)
+    B = 2 if tag == "tiny" else 1
+    x = fill.uniform("bert.inputs_embeds", (B, 34, cfg.hidden_size)).to(dev).requires_grad_()
+    out = bert_fast.FrozenBertEncoder(m)(x)
+    assert_close(out, g["out"], what="last_hidden_state")
+    (out * fill.uniform("bert.gout", out.shape).to(dev)).sum().backward()
+    assert_close(x.grad, g["dx"], what="dx")
+
+
+@pytest.mark.parametrize("M,D,p", [(7, 48, 0.0), (300, 768, 0.1), (5, 1024, 0.3)])
+def test_fused_epilogues_vs_torch(M, D, p):
+    """bias+GELU and bias+dropout+residual+LayerNorm kernels vs plain torch fp32 on the same mask."""
+    from hopmi import ops
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(M, D, generator=gen).to(dev).requires_grad_()
+    res = torch.randn(M, D, generator=gen).to(dev).requires_grad_()
+    b, gam, bet = (torch.randn(D, generator=gen).to(dev) for _ in range(3))
+    go = torch.randn(M, D, generator=gen).to(dev)
+    out = ops.bias_dropout_residual_layernorm(x, b, res, gam, bet, 1e-12, p, 99)
+    gx, gr = torch.autograd.grad(out, [x, res], go)
+    # the kernel's keep mask: ew_hash(seed, row, col) = murmur fmix of seed ^ row*c1 ^ col*c2
+    M32 = 0xFFFFFFFF
+    row = torch.arange(M, dtype=torch.int64).view(M, 1); col = torch.arange(D, dtype=torch.int64).view(1, D)
+    h = 99 ^ ((row * 0x9E3779B1) & M32) ^ ((col * 0x85EBCA77) & M32)
+    h = h ^ (h >> 16); h = (h * 0x85EBCA6B) & M32; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & M32; h = h ^ (h >> 16)
+    keep = (h >= int(p * 4294967296.0)).float().to(dev) / (1 - p) if p > 0 else torch.ones(M, D, device=dev)
+    xr, rr = x.detach().clone().requires_grad_(), res.detach().clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm((xr + b) * keep + rr, (D,), gam, bet, 1e-12)
+    rx, rres = torch.autograd.grad(ref, [xr, rr], go)
+    assert_close(out, ref, 1e-4, "ln out"); assert_close(gx, rx, 1e-4, "ln dx"); assert_close(gr, rres, 1e-4, "ln dres")
+    y = ops.bias_gelu(x, b)
+    gy, = torch.autograd.grad(y, [x], go)
+    yr = torch.nn.functional.gelu(xr + b)
+    gyr, = torch.autograd.grad(yr, [xr], go)
+    assert_close(y, yr, 1e-5, "gelu"); assert_close(gy, gyr, 1e-4, "gelu dx")
+
+
 # ------------------------------------------------------------------------- reprogramming attention
 @pytest.mark.parametrize("tag,B,S,d_llm,p_drop", [("tiny", 2, 50, 48, 0.0), ("real", 1, 1500, 768, 0.0),
                                                      ("tiny", 5, 50, 48, 0.1), ("real", 3, 1500, 768, 0.1)])
