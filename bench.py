@@ -147,7 +147,7 @@ def main():
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1] per GPU: {args.dataset} {V + 1}-joint ({V} graph nodes), "
+            "config": {"workload": f"BASELINE.json configs[{1 if V == 9 else 3}] per GPU: {args.dataset} {V + 1}-joint ({V} graph nodes), "
                                    f"34-frame clips, batch {B}/GPU, fp32, full train_llm step "
                                    f"({'GAN phase' if args.epoch > 10 else 'epoch<=10: 2 generator forwards + backward + Adam'})",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",

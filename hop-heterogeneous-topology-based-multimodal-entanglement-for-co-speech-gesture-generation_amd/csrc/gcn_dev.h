@@ -122,7 +122,39 @@ constexpr int rows_nit(int mt) { return ((16 * mt + 4) * 16 + 255) / 256; }
 // KS = K steps ceil(V/4), MTN = row tiles ceil(2V/16) of the stacked mix matrix: the matrix stays
 // in registers for all slabs and the result rows are stored unconditionally (rows m >= 2V of the
 // padded M go to a dump row in the tile's padding: columns >= 64 of row `dump_row` are never read).
-template <int KS, int MTN>
+template <int KS, int MTN, int SG>
+__device__ __forceinline__ void node_mix_group(float* hs, float* Hc, const float (&am)[MTN][KS], const int (&woff)[MTN][4],
+                                               int V, int w, int q, int j) {
+  // SG slabs at once: SG*MTN independent accumulator chains keep the matrix pipe fed while the LDS reads of
+  // the group and the previous group's result writes are in flight
+  float xb[SG][KS];
+#pragma unroll
+  for (int sg = 0; sg < SG; ++sg)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[sg][ks] = hs[(sg * V + 4 * ks + q) * LDH + 16 * w + j];   // B[k][n = c]
+  f32x4 acc[SG][MTN];
+#pragma unroll
+  for (int sg = 0; sg < SG; ++sg)
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) acc[sg][mt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int sg = 0; sg < SG; ++sg)
+#pragma unroll
+      for (int mt = 0; mt < MTN; ++mt) acc[sg][mt] = mfma16(am[mt][ks], xb[sg][ks], acc[sg][mt]);
+#pragma unroll
+  for (int sg = 0; sg < SG; ++sg)
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // rows m >= 2V of the padded M go to the dump row (absolute offset), the rest into slab sg
+        ((16 * mt + 4 * q + r) < 2 * V ? hs + sg * V * LDH : Hc)[woff[mt][r]] = acc[sg][mt][r];
+      }
+}
+
+template <int KS, int MTN, int SG>
 __device__ __forceinline__ void node_mix(float* Hc, const float* AT, const GcnGeom& g, int nsl, int dump_row,
                                          int w, int q, int j) {
   const int V = g.V;
@@ -140,27 +172,9 @@ __device__ __forceinline__ void node_mix(float* Hc, const float* AT, const GcnGe
                                 : (dump_row * LDH + C + 16 * w + j);
     }
   }
-  for (int s = 0; s < nsl; ++s) {
-    float* hs = Hc + s * V * LDH;
-    float xb[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xb[ks] = hs[(4 * ks + q) * LDH + 16 * w + j];           // B[k][n = c]
-    f32x4 acc[MTN];
-#pragma unroll
-    for (int mt = 0; mt < MTN; ++mt) acc[mt] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < MTN; ++mt) acc[mt] = mfma16(am[mt][ks], xb[ks], acc[mt]);
-#pragma unroll
-    for (int mt = 0; mt < MTN; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int off = woff[mt][r];
-        // a dump-row write of slab s must not land inside slab s+1.. : the dump row is beyond the tile
-        ((16 * mt + 4 * q + r) < 2 * V ? hs : Hc)[off] = acc[mt][r];
-      }
-  }
+  int s = 0;
+  for (; s + SG <= nsl; s += SG) node_mix_group<KS, MTN, SG>(Hc + s * V * LDH, Hc, am, woff, V, w, q, j);
+  for (; s < nsl; ++s) node_mix_group<KS, MTN, 1>(Hc + s * V * LDH, Hc, am, woff, V, w, q, j);
 }
 
 // generic V (runtime loops)
@@ -187,8 +201,8 @@ __device__ __forceinline__ void node_mix_generic(float* Hc, const float* AT, con
 
 __device__ __forceinline__ void node_mix_dispatch(float* Hc, const float* AT, const GcnGeom& g, int nsl, int w, int q, int j) {
   const int dump_row = g.rows_lds - 1;
-  if (g.V == 9) node_mix<3, 2>(Hc, AT, g, nsl, dump_row, w, q, j);            // TED
-  else if (g.V == 42) node_mix<11, 6>(Hc, AT, g, nsl, dump_row, w, q, j);     // TED-Expressive
+  if (g.V == 9) node_mix<3, 2, 4>(Hc, AT, g, nsl, dump_row, w, q, j);         // TED
+  else if (g.V == 42) node_mix<11, 6, 1>(Hc, AT, g, nsl, dump_row, w, q, j);  // TED-Expressive
   else node_mix_generic(Hc, AT, g, nsl, w, q, j);
 }
 

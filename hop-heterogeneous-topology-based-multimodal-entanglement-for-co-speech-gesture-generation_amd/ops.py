@@ -321,9 +321,12 @@ def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, wan
     _lib.check(_timed("wn_layer_fwd", nbytes, flops,
                       lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), wtcn.data_ptr(), btcn.data_ptr(),
                                                    _ptr(prep), _ptr(Wm), _ptr(bm), _ptr(y), _ptr(fs), utail.data_ptr(),
-                                                   utail.stride(2), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
-                                                   float(momentum), float(eps), _ptr(scsh_out), _ptr(mean_rstd), _ptr(ws),
-                                                   B, T_in, V, dilation, 1 if do_gcn else 0, st)), "hopmi_wn_layer_fwd")
+                                                   utail.stride(2), _ptr(ws), B, T_in, V, dilation,
+                                                   1 if do_gcn else 0, st)), "hopmi_wn_layer_fwd")
+    if bn is not None:
+        _lib.check(L.hopmi_wn_bn_finalize(ws.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
+                                          float(momentum), float(eps), scsh_out.data_ptr(), mean_rstd.data_ptr(),
+                                          B, T_in, V, dilation, st), "hopmi_wn_bn_finalize")
     return y, fs, scsh_out, mean_rstd
 
 

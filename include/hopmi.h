@@ -79,16 +79,21 @@ int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const floa
  *   y        [B][T_out][V][64] gcn(u) + bm + r^[t+d], pre-BatchNorm (nullable; T_out = T_in - dilation)
  *   fs       [B][T_out][V][128] tanh and sigmoid gate values saved for the backward (nullable)
  *   utail    u of the last 4 frames, row (b, f, v) at utail[((b*4 + f)*V + v)*utail_ld .. +64]
- *   training-mode BatchNorm of y (all nullable together => no statistics): gamma, beta [64];
- *   running_mean/var [64] updated in place (nullable); scsh_out [128] = this layer's scale/shift for the
- *   next layer; mean_rstd_out [128]; ws = hopmi_wn_layer_ws_floats(...) floats of per-workgroup partials.
+ *   ws       nullable; hopmi_wn_layer_ws_floats(...) floats receiving per-workgroup sum / sum-of-squares of y
+ *            (training-mode BatchNorm statistics, do_gcn only), to be finalised by hopmi_wn_bn_finalize.
  */
 size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation);
 int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn, const float* btcn,
                        const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
-                       int utail_ld, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                       float momentum, float eps, float* scsh_out, float* mean_rstd_out, float* ws,
-                       int B, int T_in, int V, int dilation, int do_gcn, void* stream);
+                       int utail_ld, float* ws, int B, int T_in, int V, int dilation, int do_gcn, void* stream);
+
+/* BatchNorm2d training-mode finalisation (gwnet.py:237) from the partials of the layer call with the same
+ * (B, T_in, V, dilation): fixed-order sums -> mean_rstd_out [128] (mean, rstd), scsh_out [128] = the scale / shift
+ * the next layer applies on load, running_mean / running_var [64] updated in place (nullable) with torch
+ * semantics (biased variance normalises, unbiased feeds running_var). */
+int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* scsh_out, float* mean_rstd_out,
+                         int B, int T_in, int V, int dilation, void* stream);
 
 /* Backward of one fused WaveNet layer (autograd of gwnet.py:181-237), see csrc/wavenet_bwd.hip.
  *   xin, scsh_in, fs, wtcn, prep, Wm : as in / saved by the forward
