@@ -86,25 +86,23 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
 
   // chunk staging: thread -> (key row = (tid >> 5) + 8 it, float4 column = tid & 31)
   const int srow = tid >> 5, sc4 = tid & 31;
-  float4 kreg[AKC / 8], vreg[AKC / 8];
-  auto issue = [&](int c) {
-#pragma unroll
-    for (int it = 0; it < AKC / 8; ++it) {
-      const int key = min(c * AKC + srow + 8 * it, S - 1);
-      kreg[it] = reinterpret_cast<const float4*>(K + (size_t)key * rs + (size_t)h * AE)[sc4];
-      vreg[it] = reinterpret_cast<const float4*>(Vv + (size_t)key * rs + (size_t)h * AE)[sc4];
-    }
-  };
+  f32x4 kreg[AKC / 8], vreg[AKC / 8];          // native vectors: HIP's float4 struct arrays stayed in scratch here
+#define HOPMI_ATTN_ISSUE_KV(c_)                                                                          \
+  _Pragma("unroll") for (int it = 0; it < AKC / 8; ++it) {                                               \
+    const int key_ = min((c_) * AKC + srow + 8 * it, S - 1);                                             \
+    kreg[it] = reinterpret_cast<const f32x4*>(K + (size_t)key_ * rs + (size_t)h * AE)[sc4];              \
+    vreg[it] = reinterpret_cast<const f32x4*>(Vv + (size_t)key_ * rs + (size_t)h * AE)[sc4];             \
+  }
   const int nchunk = (S + AKC - 1) / AKC;
   float* Pw = Ps + w * 16 * APLD;
 
   for (int c = 0; c < nchunk; ++c) {
-    issue(c);                                                      // other resident workgroups cover this latency
+    HOPMI_ATTN_ISSUE_KV(c)                                         // other resident workgroups cover this latency
     __syncthreads();                                               // previous chunk's LDS images consumed
 #pragma unroll
     for (int it = 0; it < AKC / 8; ++it) {
-      *reinterpret_cast<float4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
-      *reinterpret_cast<float4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
+      *reinterpret_cast<f32x4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
+      *reinterpret_cast<f32x4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
     }
     __syncthreads();
 
@@ -237,26 +235,24 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
   for (int nt = 0; nt < 8; ++nt) acc_dq[nt] = {0.f, 0.f, 0.f, 0.f};
 
   const int srow = tid >> 5, sc4 = tid & 31;
-  float4 kreg[AKC / 8], vreg[AKC / 8];
-  auto issue = [&](int c) {
-#pragma unroll
-    for (int it = 0; it < AKC / 8; ++it) {
-      const int key = min(c * AKC + srow + 8 * it, S - 1);
-      kreg[it] = reinterpret_cast<const float4*>(K + (size_t)key * rs + (size_t)h * AE)[sc4];
-      vreg[it] = reinterpret_cast<const float4*>(Vv + (size_t)key * rs + (size_t)h * AE)[sc4];
-    }
-  };
+  f32x4 kreg[AKC / 8], vreg[AKC / 8];          // native vectors: HIP's float4 struct arrays stayed in scratch here
+#define HOPMI_ATTN_ISSUE_KV(c_)                                                                          \
+  _Pragma("unroll") for (int it = 0; it < AKC / 8; ++it) {                                               \
+    const int key_ = min((c_) * AKC + srow + 8 * it, S - 1);                                             \
+    kreg[it] = reinterpret_cast<const f32x4*>(K + (size_t)key_ * rs + (size_t)h * AE)[sc4];              \
+    vreg[it] = reinterpret_cast<const f32x4*>(Vv + (size_t)key_ * rs + (size_t)h * AE)[sc4];             \
+  }
   const int nchunk = (S + AKC - 1) / AKC;
   float* Pw = Ps + w * 16 * APLD;
   const int row_c0 = tile * ABM + 16 * w + 4 * q;
 
   for (int c = 0; c < nchunk; ++c) {
-    issue(c);
+    HOPMI_ATTN_ISSUE_KV(c)
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < AKC / 8; ++it) {
-      *reinterpret_cast<float4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
-      *reinterpret_cast<float4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
+      *reinterpret_cast<f32x4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
+      *reinterpret_cast<f32x4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
     }
     __syncthreads();
 
@@ -350,23 +346,21 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* _
   for (int nt = 0; nt < 8; ++nt) { acc_dk[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dv[nt] = {0.f, 0.f, 0.f, 0.f}; }
 
   const int srow = tid >> 5, sc4 = tid & 31;
-  float4 qreg[KVR / 8], dreg[KVR / 8];
+  f32x4 qreg[KVR / 8], dreg[KVR / 8];
   float lreg = 0.f, greg = 0.f;
-  auto issue = [&](int t) {
-#pragma unroll
-    for (int it = 0; it < KVR / 8; ++it) {
-      const int row = min(t * KVR + srow + 8 * it, N - 1);
-      qreg[it] = reinterpret_cast<const float4*>(Q + (size_t)row * rs + (size_t)h * AE)[sc4];
-      dreg[it] = reinterpret_cast<const float4*>(dO + (size_t)row * rs + (size_t)h * AE)[sc4];
-    }
-    if (tid < KVR) {
-      const int row = min(t * KVR + tid, N - 1);
-      lreg = lse[(size_t)row * H + h];
-      greg = delta[(size_t)row * H + h];
-    }
-  };
+#define HOPMI_ATTN_ISSUE_QD(t_)                                                                          \
+  {                                                                                                      \
+    _Pragma("unroll") for (int it = 0; it < KVR / 8; ++it) {                                             \
+      const int row_ = min((t_) * KVR + srow + 8 * it, N - 1);                                           \
+      qreg[it] = reinterpret_cast<const f32x4*>(Q + (size_t)row_ * rs + (size_t)h * AE)[sc4];           \
+      dreg[it] = reinterpret_cast<const f32x4*>(dO + (size_t)row_ * rs + (size_t)h * AE)[sc4];          \
+    }                                                                                                    \
+    const int lrow_ = min((t_) * KVR + (tid & (KVR - 1)), N - 1);                                        \
+    lreg = lse[(size_t)lrow_ * H + h];                                                                   \
+    greg = delta[(size_t)lrow_ * H + h];                                                                 \
+  }
   const int ntile = (N + KVR - 1) / KVR;
-  if (split < ntile) issue(split);
+  if (split < ntile) HOPMI_ATTN_ISSUE_QD(split)
   float* Pw = Ps + w * 2 * 16 * KVPLD;             // (P o M)^T
   float* Sw = Pw + 16 * KVPLD;                     // dS^T
   const int key_c0 = chunk * KVK + 16 * w + 4 * q; // C-layout key rows 4q + r of this wave's tile
@@ -375,12 +369,12 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* _
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < KVR / 8; ++it) {
-      *reinterpret_cast<float4*>(Qs + (srow + 8 * it) * ALD + 4 * sc4) = qreg[it];
-      *reinterpret_cast<float4*>(Ds + (srow + 8 * it) * ALD + 4 * sc4) = dreg[it];
+      *reinterpret_cast<f32x4*>(Qs + (srow + 8 * it) * ALD + 4 * sc4) = qreg[it];
+      *reinterpret_cast<f32x4*>(Ds + (srow + 8 * it) * ALD + 4 * sc4) = dreg[it];
     }
     if (tid < KVR) { Ls[tid] = lreg; Ls[KVR + tid] = greg; }
     __syncthreads();
-    if (t + nsplit < ntile) issue(t + nsplit);
+    if (t + nsplit < ntile) HOPMI_ATTN_ISSUE_QD(t + nsplit)
 
     // S^T[16 keys][32 rows] = K_w Q^T ;  dP^T = V_w dO^T
     f32x4 acc_s[2], acc_dp[2];

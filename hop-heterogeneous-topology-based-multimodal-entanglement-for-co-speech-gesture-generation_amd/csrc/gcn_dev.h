@@ -76,7 +76,9 @@ __device__ __forceinline__ void prep_issue(PrepRegs& r, const float* __restrict_
 #pragma unroll
   for (int it = 0; it < PREP_IT; ++it) {
     const int idx = tid + 256 * it;
-    if (idx < n4) r.v[it] = src[idx];
+    // unconditional (clamped) load + select: a conditionally written register array ends up in scratch
+    const float4 v = src[min(idx, n4 - 1)];
+    r.v[it] = (idx < n4) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
