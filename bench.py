@@ -140,6 +140,14 @@ def main():
     if rank == 0:
         ks = timer.summary()
         gf = ks["wn_layer_fwd"]
+        # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
+        # inside this process): (2*FETCH_SIZE + WRITE_SIZE) KB per launch, gfx950 correction applied there
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f)["kernels"]["wn_layer_fwd"]["hbm_bytes_per_launch"] if (V == 9 and B == 128) else None
+        except (OSError, KeyError, ValueError):
+            traffic = None
         gbs = gf["bytes"] / (gf["total_ms"] * 1e-3) / 1e9
         tfl = gf["flops"] / (gf["total_ms"] * 1e-3) / 1e12
         out = {
@@ -157,7 +165,7 @@ def main():
             # skip tail written, per launch
             "roofline": {"kernel": "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv, 8 layers x 2 forwards)",
                          "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None, "launches": gf["launches"], "avg_us": 1e3 * gf["total_ms"] / gf["launches"],
+                         "traffic": traffic, "launches": gf["launches"], "avg_us": 1e3 * gf["total_ms"] / gf["launches"],
                          "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
                          "f32_mfma_tflops": tfl, "f32_mfma_frac": tfl / F32_MFMA_PEAK_TFLOPS,
                          "timing": "HIP events around each launch on the launch stream, inside the timed region"},
