@@ -277,6 +277,257 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Persistent forward: ONE launch per layer.  Workgroup (slice group g = (dir, batch group), unit block jb) keeps its
+// 48 x H slice of W_hh in LDS for all T steps and walks the time steps itself; the nJ workgroups of a group
+// exchange h_t through HBM/L2 with the placement-independent hand-off of the CDNA4 guide (Guideline 16, "sc1" form):
+//   producer: h_t stored with sc1 (write-through) stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup
+//             barrier -> one lane adds 1 to the group's arrival counter of step t (agent-scope relaxed atomic)
+//   consumer: one lane polls that counter with sc1 loads until all nJ workgroups arrived -> workgroup barrier ->
+//             EVERY load of the h_{t} panel is an sc1 load (L1 is never trusted for handed-off bytes)
+// Requirements: the whole grid is resident at once (host checks grid <= #CUs, one workgroup per CU by LDS size);
+// linear ids are group-major (a group's workgroups are dispatched together) with the unit-block count padded to a
+// multiple of 8 so a given unit block always lands on the same XCD.  Every spin is bounded: on timeout the
+// workgroup raises the status word and leaves, so the launch always drains.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 ld_sc1_f2(const float* p) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)(v & 0xFFFFFFFFull)), __uint_as_float((unsigned)(v >> 32)));
+}
+__device__ __forceinline__ void st_sc1_f(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// stage `nrows` rows (row r from src_of(r), nullptr -> zeros) with sc1 8-B loads; same shape as stage_rows
+template <int MAXROWS_PER_WAVE, int MAXK2, typename SrcOf>
+__device__ __forceinline__ void stage_rows_sc1(float* dst, int ldk, int nrows, int K, int KP, SrcOf src_of, int w, int lane) {
+  float2 v[MAXROWS_PER_WAVE][MAXK2];
+#pragma unroll
+  for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
+    const int r = w + 4 * rr;
+    const float* src = src_of(min(r, nrows - 1));
+    const bool row_ok = (r < nrows) && (src != nullptr);
+#pragma unroll
+    for (int c = 0; c < MAXK2; ++c) {
+      const int k = 2 * lane + 128 * c;
+      float2 t = make_float2(0.f, 0.f);
+      if (row_ok && k < K) t = ld_sc1_f2(src + k);
+      v[rr][c] = t;
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
+    const int r = w + 4 * rr;
+#pragma unroll
+    for (int c = 0; c < MAXK2; ++c) {
+      const int k = 2 * lane + 128 * c;
+      if (r < nrows && k < KP) *reinterpret_cast<float2*>(dst + r * ldk + k) = v[rr][c];
+    }
+  }
+}
+
+constexpr int GRU_SPIN_LIMIT = 1 << 20;            // ~1 s of polling before giving up
+
+// returns false on timeout (uniform over the workgroup)
+__device__ __forceinline__ bool gru_wait(const int* cnt, int want, int* status, int* flag_lds) {
+  if (threadIdx.x == 0) {
+    int ok = 1, spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > GRU_SPIN_LIMIT) { ok = 0; __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    *flag_lds = ok;
+  }
+  __syncthreads();
+  return *flag_lds != 0;
+}
+
+template <int MAXK2>
+__global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                                 const float* __restrict__ bhh, float* y,
+                                                                 float* __restrict__ gates, int* cnt, int* status, int B, int T,
+                                                                 int H, int KP, int nJ, int nJp, int nbb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int group = blockIdx.x / nJp, jb = blockIdx.x % nJp;
+  if (jb >= nJ) return;
+  const int d = group / nbb, bb = group % nbb;
+  const int ldk = KP + 4;
+  float* As = smem;                                // [32][ldk]  h_prev rows
+  float* Ws = As + GRU_BM * ldk;                   // [48][ldk]  resident W_hh slice
+  float* red = Ws + 3 * GRU_NU * ldk;              // [4][32][RED_LD]
+  int* flag = reinterpret_cast<int*>(red + 4 * GRU_BM * RED_LD);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
+  const int j0 = jb * GRU_NU, b0 = bb * GRU_BM;
+  const size_t ystride = (size_t)2 * H;
+  const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
+  int* gcnt = cnt + (size_t)group * T;
+
+  stage_rows<3 * GRU_NU / 4, MAXK2>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
+    const int g = r >> 4, ju = j0 + (r & 15);
+    return ju < H ? whh + ((size_t)(d * 3 + g) * H + ju) * H : nullptr;
+  }, w, lane);
+  float e_bhh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) e_bhh[g] = bhh[(d * 3 + g) * H + jc];
+  const int nc = KP >> 6;
+
+  for (int s = 0; s < T; ++s) {
+    const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
+    float e_gi[2][3];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int bc = min(b0 + (tid >> 4) + 16 * pass, B - 1);
+      const float* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) e_gi[pass][g] = gip[g * H];
+    }
+    if (s > 0) {
+      if (!gru_wait(gcnt + (s - 1), nJ, status, flag)) return;     // h_{s-1} of this group complete
+      stage_rows_sc1<GRU_BM / 4, MAXK2>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
+        const int b = b0 + r;
+        return b < B ? y + ((size_t)b * T + tp) * ystride + d * H : nullptr;
+      }, w, lane);
+      __syncthreads();
+      f32x4 acc[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[mt][g] = {0.f, 0.f, 0.f, 0.f};
+      panel_mfma<3>(acc, As, Ws, ldk, w * nc, nc, q, i);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(w * GRU_BM + 16 * mt + 4 * q + r) * RED_LD + 16 * g + i] = acc[mt][g][r];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = (tid >> 4) + 16 * pass, b = b0 + row;
+      if (b < B && j < H) {
+        float gh[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          float v = e_bhh[g];
+          if (s > 0) {
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) v += red[(ww * GRU_BM + row) * RED_LD + 16 * g + jj];
+          }
+          gh[g] = v;
+        }
+        const float r = sigmoidf_(e_gi[pass][0] + gh[0]);
+        const float z = sigmoidf_(e_gi[pass][1] + gh[1]);
+        const float n = tanhf(e_gi[pass][2] + r * gh[2]);
+        const float hp = (s > 0) ? As[row * ldk + j] : 0.f;
+        st_sc1_f(y + ((size_t)b * T + t) * ystride + d * H + j, (1.f - z) * n + z * hp);      // handed off: write-through
+        float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
+        gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = gh[2];
+      }
+    }
+    if (s + 1 < T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
+      __syncthreads();                                             // (also: As / red free for the next step)
+      if (tid == 0) __hip_atomic_fetch_add(gcnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Persistent BPTT: same structure; the workgroup keeps its 16 x 3H slice of W_hh^T in LDS (three gate blocks) and
+// hands dgh_t over (sc1 stores / sc1 loads + arrival counters); dgi, dhz stay private to the workgroup.
+template <int MAXK2>
+__global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ gates, const float* __restrict__ whhT,
+                                                                 float* __restrict__ dgi, float* dgh, float* dhz, int* cnt,
+                                                                 int* status, int B, int T, int H, int KP, int nJ, int nJp, int nbb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int group = blockIdx.x / nJp, jb = blockIdx.x % nJp;
+  if (jb >= nJ) return;
+  const int d = group / nbb, bb = group % nbb;
+  const int ldk = KP + 4;
+  float* As = smem;                                // [32][ldk]      dgh rows of one gate block
+  float* Ws = As + GRU_BM * ldk;                   // [3][16][ldk]   resident W_hh^T slice, one image per gate block
+  float* red = Ws + 3 * GRU_NU * ldk;              // [4][32][RED_LD]
+  int* flag = reinterpret_cast<int*>(red + 4 * GRU_BM * RED_LD);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
+  const int j0 = jb * GRU_NU, b0 = bb * GRU_BM;
+  const int K = 3 * H;
+  const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
+  int* gcnt = cnt + (size_t)group * T;
+
+  stage_rows<3 * GRU_NU / 4, MAXK2>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
+    const int g = r >> 4, ju = j0 + (r & 15);
+    return ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr;
+  }, w, lane);
+  const int nc = KP >> 6;
+
+  for (int s = 0; s < T; ++s) {
+    const int t = d ? s : T - 1 - s;
+    const int tn = d ? t - 1 : t + 1, tp = d ? t + 1 : t - 1;
+    const float* dhz_in = dhz + ((size_t)((s + 1) & 1) * 2 + d) * B * H;
+    float* dhz_out = dhz + ((size_t)(s & 1) * 2 + d) * B * H;
+    float e_dy[2], e_dhz[2], e_g[2][4], e_hp[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int bc = min(b0 + (tid >> 4) + 16 * pass, B - 1);
+      e_dy[pass] = dy[((size_t)bc * T + t) * 2 * H + d * H + jc];
+      e_dhz[pass] = dhz_in[(size_t)bc * H + jc];                   // this workgroup's own write of the previous step
+      const float* gp = gates + (((size_t)bc * T + t) * 2 + d) * 4 * H + jc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_g[pass][g] = gp[g * H];
+      const int tpc = min(max(tp, 0), T - 1);
+      e_hp[pass] = y[((size_t)bc * T + tpc) * 2 * H + d * H + jc];
+    }
+    if (s > 0) {
+      if (!gru_wait(gcnt + (s - 1), nJ, status, flag)) return;     // dgh of the previous BPTT step complete
+      f32x4 acc[2][1];
+      acc[0][0] = {0.f, 0.f, 0.f, 0.f};
+      acc[1][0] = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 3; ++g) {
+        if (g) __syncthreads();
+        stage_rows_sc1<GRU_BM / 4, MAXK2>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
+          const int b = b0 + r;
+          return b < B ? dgh + (((size_t)b * T + tn) * 2 + d) * K + g * H : nullptr;
+        }, w, lane);
+        __syncthreads();
+        panel_mfma<1>(acc, As, Ws + g * GRU_NU * ldk, ldk, w * nc, nc, q, i);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(w * GRU_BM + 16 * mt + 4 * q + r) * RED_LD + i] = acc[mt][0][r];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = (tid >> 4) + 16 * pass, b = b0 + row;
+      if (b < B && j < H) {
+        float D = e_dy[pass];
+        if (s > 0) {
+          D += e_dhz[pass];
+#pragma unroll
+          for (int ww = 0; ww < 4; ++ww) D += red[(ww * GRU_BM + row) * RED_LD + jj];
+        }
+        const float r = e_g[pass][0], z = e_g[pass][1], n = e_g[pass][2], hn = e_g[pass][3];
+        const float hp = (s < T - 1) ? e_hp[pass] : 0.f;
+        const float dn = D * (1.f - z) * (1.f - n * n);
+        const float dz = D * (hp - n) * z * (1.f - z);
+        const float dr = dn * hn * r * (1.f - r);
+        const size_t o = (((size_t)b * T + t) * 2 + d) * K + j;
+        dgi[o] = dr; dgi[o + H] = dz; dgi[o + 2 * H] = dn;
+        st_sc1_f(dgh + o, dr); st_sc1_f(dgh + o + H, dz); st_sc1_f(dgh + o + 2 * H, dn * r);   // handed off
+        dhz_out[(size_t)b * H + j] = D * z;
+      }
+    }
+    if (s + 1 < T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(gcnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 static int gru_validate(const void* const* ptrs, int n, int B, int T, int H) {
   for (int i = 0; i < n; ++i)
     if (!ptrs[i]) { set_error("hopmi_gru: null pointer argument #%d", i); return HOPMI_EINVAL; }
@@ -303,10 +554,65 @@ static void launch_gru_bwd(dim3 grid, size_t lds, hipStream_t st, const float* d
 
 using namespace hopmi;
 
-extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates,
+static int gru_num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 1;
+  }
+  return cus;
+}
+
+static int gru_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+// persistent path iff the caller gave a workspace, every workgroup can be resident at once (one per CU) and it is
+// not disabled (HOPMI_GRU_PERSISTENT=0)
+static bool gru_persistent_ok(int B, int H, const void* ws) {
+  const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
+  const int nJp = (nJ + 7) / 8 * 8;
+  return ws != nullptr && gru_env_int("HOPMI_GRU_PERSISTENT", 1) != 0 && 2 * nbb * nJp <= gru_num_cus();
+}
+
+extern "C" size_t hopmi_gru_ws_bytes(int B, int T, int H) {
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  const int nbb = (B + GRU_BM - 1) / GRU_BM;
+  return ((size_t)2 * nbb * T + 16) * sizeof(int);               // arrival counters [2*nbb][T] + status word
+}
+
+template <int MAXK2>
+static void launch_gru_fwd_persistent(int grid, size_t lds, hipStream_t st, const float* gi, const float* whh,
+                                      const float* bhh, float* y, float* gates, int* cnt, int* status, int B, int T, int H,
+                                      int KP, int nJ, int nJp, int nbb) {
+  hipLaunchKernelGGL(gru_fwd_persistent_kernel<MAXK2>, dim3(grid), dim3(256), lds, st, gi, whh, bhh, y, gates, cnt, status, B,
+                     T, H, KP, nJ, nJp, nbb);
+}
+
+extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws,
                              int B, int T, int H, void* stream) {
   const void* ptrs[] = {gi, whh, bhh, y, gates};
   if (int e = gru_validate(ptrs, 5, B, T, H)) return e;
+  if (gru_persistent_ok(B, H, ws)) {
+    const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM, nJp = (nJ + 7) / 8 * 8;
+    const int KP = ceil_to(H, 64);
+    const size_t lds = ((size_t)(GRU_BM + 3 * GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD + 4) * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int* cnt = static_cast<int*>(ws);
+    int* status = cnt + (size_t)2 * nbb * T;
+    if (hipMemsetAsync(ws, 0, hopmi_gru_ws_bytes(B, T, H), st) != hipSuccess) return check_launch("hopmi_gru_fwd(memset)");
+    const int grid = 2 * nbb * nJp;
+    switch ((KP + 127) / 128) {
+      case 1: launch_gru_fwd_persistent<1>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+      case 2: launch_gru_fwd_persistent<2>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+      case 3: launch_gru_fwd_persistent<3>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+      default: launch_gru_fwd_persistent<4>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+    }
+    return check_launch("hopmi_gru_fwd(persistent)");
+  }
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);
@@ -325,10 +631,35 @@ extern "C" size_t hopmi_gru_bwd_ws_floats(int B, int H) {
   return (B > 0 && H > 0) ? (size_t)4 * B * H : 0;
 }
 
+template <int MAXK2>
+static void launch_gru_bwd_persistent(int grid, size_t lds, hipStream_t st, const float* dy, const float* y,
+                                      const float* gates, const float* whhT, float* dgi, float* dgh, float* dhz, int* cnt,
+                                      int* status, int B, int T, int H, int KP, int nJ, int nJp, int nbb) {
+  hipLaunchKernelGGL(gru_bwd_persistent_kernel<MAXK2>, dim3(grid), dim3(256), lds, st, dy, y, gates, whhT, dgi, dgh, dhz, cnt,
+                     status, B, T, H, KP, nJ, nJp, nbb);
+}
+
 extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
-                             float* dgi, float* dgh, float* ws, int B, int T, int H, void* stream) {
+                             float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream) {
   const void* ptrs[] = {dy, y, gates, whhT, dgi, dgh, ws};
   if (int e = gru_validate(ptrs, 7, B, T, H)) return e;
+  if (gru_persistent_ok(B, H, ws2)) {
+    const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM, nJp = (nJ + 7) / 8 * 8;
+    const int KP = ceil_to(H, 64);
+    const size_t lds = ((size_t)(GRU_BM + 3 * GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD + 4) * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int* cnt = static_cast<int*>(ws2);
+    int* status = cnt + (size_t)2 * nbb * T;
+    if (hipMemsetAsync(ws2, 0, hopmi_gru_ws_bytes(B, T, H), st) != hipSuccess) return check_launch("hopmi_gru_bwd(memset)");
+    const int grid = 2 * nbb * nJp;
+    switch ((KP + 127) / 128) {
+      case 1: launch_gru_bwd_persistent<1>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+      case 2: launch_gru_bwd_persistent<2>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+      case 3: launch_gru_bwd_persistent<3>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+      default: launch_gru_bwd_persistent<4>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+    }
+    return check_launch("hopmi_gru_bwd(persistent)");
+  }
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);

@@ -364,6 +364,27 @@ def wn_layer_bwd(xin, scsh_in, fs, wtcn, prep, Wm, P0n, P1n, d_next, y, bn_coef,
 
 
 # ------------------------------------------------------------------------------------------- GRU
+GRU_CHECK_STATUS = False      # tests set this: reads the persistent kernel's status word back (a host sync)
+_PENDING_STATUS = []          # status words of persistent launches not yet checked (see deferred_status)
+
+
+def deferred_status():
+    """Sum of the status words of all persistent GRU launches since the last call, as a 0-dim float tensor (or
+    None).  The training step folds it into its one device->host transfer and raises if it is non-zero, so a
+    hand-off time-out can never pass silently and costs no extra sync."""
+    global _PENDING_STATUS
+    if not _PENDING_STATUS:
+        return None
+    st = torch.stack(_PENDING_STATUS).sum().float()
+    _PENDING_STATUS = []
+    return st
+
+
+def _track_status(ws):
+    if len(_PENDING_STATUS) < 4096:
+        _PENDING_STATUS.append(ws[-16])
+
+
 class _GruLayerFn(torch.autograd.Function):
     """Recurrence of one bidirectional GRU layer (hopmi_gru_fwd / hopmi_gru_bwd).
 
@@ -379,9 +400,13 @@ class _GruLayerFn(torch.autograd.Function):
         y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=gi.device)
         gates = torch.empty(B, T, 2, 4 * H, dtype=torch.float32, device=gi.device)
         L, st = _lib.lib(), _stream()
+        ws = torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=gi.device)
         _lib.check(_timed("gru_fwd", 0, 2 * T * B * 2 * 3 * H * H,
                           lambda: L.hopmi_gru_fwd(gi.data_ptr(), whh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
-                                                  gates.data_ptr(), B, T, H, st)), "hopmi_gru_fwd")
+                                                  gates.data_ptr(), ws.data_ptr(), B, T, H, st)), "hopmi_gru_fwd")
+        _track_status(ws)
+        if GRU_CHECK_STATUS and int(ws[-16].item()) != 0:
+            raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out (status word set)")
         ctx.save_for_backward(y, gates, whh)
         return y
 
@@ -396,10 +421,14 @@ class _GruLayerFn(torch.autograd.Function):
         dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
         dgh = torch.empty_like(dgi)
         ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
+        ws2 = torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=y.device)
         _lib.check(_timed("gru_bwd", 0, 2 * T * B * 2 * 3 * H * H,
                           lambda: L.hopmi_gru_bwd(dy.data_ptr(), y.data_ptr(), gates.data_ptr(), whhT.data_ptr(),
-                                                  dgi.data_ptr(), dgh.data_ptr(), ws.data_ptr(), B, T, H, st)),
+                                                  dgi.data_ptr(), dgh.data_ptr(), ws.data_ptr(), ws2.data_ptr(), B, T, H, st)),
                    "hopmi_gru_bwd")
+        _track_status(ws2)
+        if GRU_CHECK_STATUS and int(ws2[-16].item()) != 0:
+            raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
         # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
         # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
         yv = y.view(B, T, 2, H)

@@ -18,6 +18,8 @@ import contextlib
 import torch
 import torch.nn.functional as F
 
+from . import ops as _ops
+
 
 # random draws go through these three so tests can replay the reference's CPU stream on the GPU
 def _randn_like(t):
@@ -67,7 +69,14 @@ def _ret_dict(args, gan, huber, kld, div_reg, gen_error, dis_error):
         terms.append(("DIV_REG", args.loss_reg_weight, div_reg))
     if gan:
         terms += [("gen", args.loss_gan_weight, gen_error), ("dis", 1.0, dis_error)]
-    vals = torch.stack([t.detach().float() for _, _, t in terms]).cpu().tolist()
+    stacked = [t.detach().float() for _, _, t in terms]
+    status = _ops.deferred_status() if stacked[0].is_cuda else None     # persistent-kernel hand-off status words
+    if status is not None:
+        stacked.append(status.to(stacked[0].device))
+    vals = torch.stack(stacked).cpu().tolist()
+    if status is not None and vals.pop() != 0.0:
+        raise RuntimeError("hopmi: a persistent GRU kernel timed out waiting for a hand-off during this step; "
+                           "set HOPMI_GRU_PERSISTENT=0 to use per-time-step launches")
     ret = {}
     for (k, wgt, _), v in zip(terms, vals):
         if k in ("KLD", "DIV_REG") and v == 0.0:

@@ -159,18 +159,24 @@ int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xh
  *   whh   [2][3H][H], bhh [2][3H]
  *   y     [B][T][2H]     layer output, forward direction in [:H], reverse in [H:]  (torch layout)
  *   gates [B][T][2][4H]  saved for the backward: r, z, n and (W_hn h + b_hn)
- * One launch per time step is enqueued on `stream` (both directions per launch).
+ * ws: nullable workspace of hopmi_gru_ws_bytes(B, T, H) bytes.  With it, and when every workgroup of the layer can
+ * be resident at once (2 * ceil(B/32) * ceil8(ceil(H/16)) <= #CUs), the layer is ONE persistent launch (W_hh
+ * slices stay in LDS, time steps hand h_t over through arrival counters); its last int is a status word that
+ * is non-zero if a hand-off ever timed out.  Otherwise one launch per time step is enqueued (both directions
+ * per launch).
  */
-int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates,
+size_t hopmi_gru_ws_bytes(int B, int T, int H);
+int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws,
                   int B, int T, int H, void* stream);
 
 /* Back-propagation through time of the above.  dy [B][T][2H] -> dgi [B][T][2][3H] (gradient w.r.t. the
  * input projections) and dgh [B][T][2][3H] (w.r.t. the recurrent pre-activations); the caller turns them
  * into dx, dW_ih, db_ih, dW_hh, db_hh with four GEMMs / reductions.  whhT [2][H][3H] is W_hh transposed
- * per direction; ws holds hopmi_gru_bwd_ws_floats(B, H) floats. */
+ * per direction; ws holds hopmi_gru_bwd_ws_floats(B, H) floats; ws2 (nullable) = hopmi_gru_ws_bytes(B, T, H) bytes
+ * enables the persistent one-launch form exactly as in hopmi_gru_fwd. */
 size_t hopmi_gru_bwd_ws_floats(int B, int H);
 int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
-                  float* dgi, float* dgh, float* ws, int B, int T, int H, void* stream);
+                  float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);
 
 #ifdef __cplusplus
 }
