@@ -613,6 +613,7 @@ extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh
     }
     return check_launch("hopmi_gru_fwd(persistent)");
   }
+  if (ws != nullptr) (void)hipMemsetAsync(ws, 0, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));   // status = 0
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);
@@ -660,6 +661,7 @@ extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates
     }
     return check_launch("hopmi_gru_bwd(persistent)");
   }
+  if (ws2 != nullptr) (void)hipMemsetAsync(ws2, 0, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));  // status = 0
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);

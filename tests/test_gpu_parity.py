@@ -203,9 +203,12 @@ def test_reprogramming_layer_vs_oracle(golden, tag, B, S, d_llm, p_drop):
 
 
 # ------------------------------------------------------------------------------------ GRU kernels
+@pytest.mark.parametrize("persistent", ["1", "0"])
 @pytest.mark.parametrize("B,T,I,H,L", [(3, 5, 7, 6, 2), (37, 34, 20, 350, 2), (5, 28, 8, 64, 4), (130, 9, 12, 18, 1)])
-def test_gru_fwd_bwd_vs_oracle(B, T, I, H, L):
-    """hopmi_gru_fwd / hopmi_gru_bwd (through ops.gru_bidirectional) vs the oracle's explicit GRU cell."""
+def test_gru_fwd_bwd_vs_oracle(B, T, I, H, L, persistent, monkeypatch):
+    """hopmi_gru_fwd / hopmi_gru_bwd (through ops.gru_bidirectional) vs the oracle's explicit GRU cell, both as the
+    persistent one-launch-per-layer kernels and as the per-time-step launches (HOPMI_GRU_PERSISTENT=0)."""
+    monkeypatch.setenv("HOPMI_GRU_PERSISTENT", persistent)
     from hopmi import ops
     from oracle import fill, ref_cpu, spec
     dev = _dev()
