@@ -37,6 +37,7 @@ class _Group:
     def __init__(self, params):
         self.params = params
         self.buckets: Optional[List[_Bucket]] = None
+        self.order: List[torch.nn.Parameter] = []     # gradient production order seen in the planning backward
 
 
 class GradSync:
@@ -62,8 +63,14 @@ class GradSync:
             if ps:
                 self.groups.append(_Group(ps))
         self._bucket_of = {}
+        self._group_of = {}
         self._in_backward = False
         self.bytes_reduced = 0                       # for tests / reporting
+        if self.world > 1:
+            for g in self.groups:
+                for p in g.params:
+                    self._group_of[id(p)] = g
+                    p.register_post_accumulate_grad_hook(self._on_grad)
 
     # -- bucket plan of a group: built from the first backward that reaches it -----------------------
     def _plan(self, g: _Group):
@@ -75,9 +82,14 @@ class GradSync:
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
             if not torch.equal(lo, hi):
                 raise RuntimeError("GradSync: ranks disagree on which parameters receive gradients")
+        # bucket in the order the planning backward PRODUCED the gradients (identical on every rank: same
+        # graph), so each bucket's all-reduce starts as early as its last gradient exists -- for HOP that puts
+        # the 183 MB mapping-layer gradient mid-backward, hidden under the gwnet / audio-MLP backward
+        seen = {id(p) for p in g.order}
+        ordered = [p for p in g.order if p.grad is not None] + [p for p in reversed(live) if id(p) not in seen]
         g.buckets = []
         cur, cur_bytes = [], 0
-        for p in reversed(live):                 # reverse registration order ~ autograd's production order
+        for p in ordered:
             nbytes = p.numel() * p.element_size()
             if cur and cur_bytes + nbytes > self.bucket_bytes:
                 g.buckets.append(_Bucket(cur, self.grad_dtype))
@@ -89,7 +101,6 @@ class GradSync:
         for b in g.buckets:
             for p in b.params:
                 self._bucket_of[id(p)] = b
-                p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _launch(self, b: _Bucket):
         off = 0
@@ -104,7 +115,12 @@ class GradSync:
     def _on_grad(self, p):
         if not self._in_backward:
             return
-        b = self._bucket_of[id(p)]
+        b = self._bucket_of.get(id(p))
+        if b is None:                            # group not planned yet: just record the production order
+            g = self._group_of[id(p)]
+            if g.buckets is None:
+                g.order.append(p)
+            return
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -126,6 +142,8 @@ class GradSync:
         for g in self.groups:
             for b in g.buckets or ():
                 b.pending = len(b.params)
+            if g.buckets is None:
+                g.order = []
         self._in_backward = True
         try:
             loss.backward()

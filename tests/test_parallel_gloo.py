@@ -53,6 +53,10 @@ def _worker(rank, world, port, q):
             res["g_grad"] = G.a.weight.grad.clone()
         g_opt.step()
     res["unused_grad_none"] = G.unused.weight.grad is None
+    # buckets follow the gradient PRODUCTION order of the planning backward: b (last layer) before a
+    g_group = sync.groups[0]
+    flat = [id(p) for b in g_group.buckets for p in b.params]
+    res["order_ok"] = flat.index(id(G.b.weight)) < flat.index(id(G.a.weight))
     res["params"] = torch.cat([p.detach().flatten() for p in list(G.parameters()) + list(D.parameters())])
     # reference: mean of per-rank local gradients for the first D step, recomputed without sync
     torch.manual_seed(0)
@@ -87,5 +91,6 @@ def test_gradsync_world2_gloo():
     assert torch.equal(r0["g_grad"], r1["g_grad"])
     assert torch.equal(r0["params"], r1["params"])                              # replicas stay in lock-step
     assert r0["unused_grad_none"] and r1["unused_grad_none"]
+    assert r0["order_ok"] and r1["order_ok"]
     d_bytes = sum(p.numel() for n, p in Toy().named_parameters() if not n.startswith("unused")) * 4
     assert r0["d_bytes1"] == d_bytes and r0["d_bytes2"] == d_bytes              # D step never moves G buckets
