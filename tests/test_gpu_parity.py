@@ -295,6 +295,39 @@ def test_gwnet_fused_layers_nograd(golden, V, B, training):
         assert int(m.bn[i].num_batches_tracked) == (1 if training else 0)
 
 
+@pytest.mark.parametrize("V,B", [(9, 128), (42, 64)])
+def test_gwnet_full_size_properties(V, B):
+    """BASELINE.json sizes: (1) the fused WaveNet-layer kernels agree with the path composed of the standalone
+    graph-conv kernel + library GEMMs (eval-mode BatchNorm, which both can run); (2) training-mode forward and
+    backward are bitwise reproducible run to run (fixed-order reductions, no atomics)."""
+    import copy
+    import hopmi
+    dev = _dev()
+    torch.manual_seed(11)
+    m = hopmi.gwnet(None, V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173,
+                    out_dim=173, residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512).to(dev)
+    with torch.no_grad():
+        for bn in m.bn:
+            bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(B, 173, V, 16, device=dev)
+    m.eval()
+    with torch.no_grad():
+        fused = m(x)                                   # fused layer kernels (no autograd)
+    composed = m(x.clone().requires_grad_())           # eval BN + autograd: gcn kernel + torch ops
+    assert_close(fused, composed, 1e-4, "fused vs composed")
+    m.train()
+    outs = []
+    for _ in range(2):
+        mm = copy.deepcopy(m)
+        xi = x.clone().requires_grad_()
+        o = mm(xi)
+        o.square().mean().backward()
+        outs.append((o.detach(), xi.grad, mm.gconv[0].mlp.mlp.weight.grad, mm.filter_convs[3].weight.grad, mm.nodevec1.grad,
+                     mm.bn[2].weight.grad, mm.bn[5].running_var.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), "fused training path is not bitwise reproducible"
+
+
 # ---------------------------------------------------------------------------------- full model
 def _make_model(V, dev):
     import hopmi
