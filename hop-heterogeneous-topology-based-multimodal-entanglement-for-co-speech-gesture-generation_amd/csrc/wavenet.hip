@@ -35,7 +35,7 @@ struct RowMap {
 };
 
 template <int MT>
-__global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
+__global__ __launch_bounds__(256, MT <= 3 ? 2 : 1) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
                                                            const float* __restrict__ wtcn, const float* __restrict__ btcn,
                                                            const float* __restrict__ prep, const float* __restrict__ Wm,
                                                            const float* __restrict__ bm, float* __restrict__ y,
@@ -52,23 +52,12 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
   const int V = g.V, c4 = tid & 15;
   const int shift4 = L.d * V * 16;                 // tap-1 row offset in float4 units
 
-  // ---- weights of this wave's 16 output channels, K permuted as k = 16i + 4q + e -------------------
-  float4 wt[2][2][4];                              // [gate f/g][tap][i]
-#pragma unroll
-  for (int gate = 0; gate < 2; ++gate)
-#pragma unroll
-    for (int tap = 0; tap < 2; ++tap) {
-      const float4* wp = reinterpret_cast<const float4*>(wtcn + (size_t)((2 * tap + gate) * 64 + 16 * w + j) * C + 4 * q);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wt[gate][tap][i] = wp[4 * i];
-    }
+  // The wave's 16-output-channel weight slices (K permuted as k = 16i + 4q + e) are (re)loaded per tile,
+  // the TCN slices before phase 1 and the Wm slice after it, so the two never hold registers together and
+  // two workgroups fit a CU (<= 256 VGPRs): one's MFMA phases overlap the other's load / store phases.
   const float bf = btcn[16 * w + j], bg = btcn[C + 16 * w + j];
-  float4 wreg[12];
   float bias = 0.f;
   if (do_gcn) {
-    const float4* wp = reinterpret_cast<const float4*>(Wm + (size_t)(16 * w + j) * K3 + 4 * q);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) wreg[i] = wp[4 * i];
     bias = bm[16 * w + j];
     PrepRegs mr;
     prep_issue(mr, prep, g.KP * g.ldA, tid);
@@ -81,6 +70,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
   for (int idx = tid; idx < 4 * C; idx += 256) Hc[(16 * MT + idx / C) * LDH + idx % C] = 0.f;
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    HOPMI_STAMP(0);
     const int slab0 = tile * g.S;
     const int nsl = min(g.S, L.n_slabs - slab0);
     const int R = nsl * V;
@@ -106,6 +96,20 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
         x0r.v[it] = src4[rm.in0[it]];
         x1r.v[it] = src4[rm.in0[it] + shift4];
       }
+    }
+    int woff = 0;
+    asm volatile("" : "+v"(woff));                 // keeps the weight loads inside the tile loop (register budget)
+    float4 wt[2][2][4];                            // [gate f/g][tap][i]
+#pragma unroll
+    for (int gate = 0; gate < 2; ++gate)
+#pragma unroll
+      for (int tap = 0; tap < 2; ++tap) {
+        const float4* wp = reinterpret_cast<const float4*>(wtcn + (size_t)((2 * tap + gate) * 64 + 16 * w + j) * C + 4 * q + woff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wt[gate][tap][i] = wp[4 * i];
+      }
+    HOPMI_STAMP(1);
+    {
       __syncthreads();                             // previous tile's LDS fully consumed
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
       }
     }
     __syncthreads();
+    HOPMI_STAMP(2);
 
     // ---- phase 1: gated TCN (two taps, two gates) on MFMA, gate, u -> LDS --------------------------
     {
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
           }
         }
       }
+      HOPMI_STAMP(3);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -162,7 +168,14 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
           }
         }
     }
+    float4 wreg[12];
+    if (do_gcn) {
+      const float4* wp = reinterpret_cast<const float4*>(Wm + (size_t)(16 * w + j) * K3 + 4 * q + woff);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) wreg[i] = wp[4 * i];
+    }
     __syncthreads();
+    HOPMI_STAMP(4);
 
     // ---- skip tail: last 4 frames of u, LDS -> HBM as whole 256-B rows ------------------------------
 #pragma unroll
@@ -176,6 +189,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
       // ---- phase 2: node mix ---------------------------------------------------------------------
       node_mix_dispatch(Hc, AT, g, nsl, w, q, j);
       __syncthreads();
+      HOPMI_STAMP(5);
       // ---- phase 3: channel contraction + bias + residual, y store, BatchNorm partial sums ------
       f32x4 acc[MT];
 #pragma unroll
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
           acc[mt] = mfma16(a[mt].w, wreg[i].w, acc[mt]);
         }
       }
+      HOPMI_STAMP(6);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -209,6 +224,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
     }
   }
 
+  HOPMI_STAMP(7);
   if (stats_part != nullptr) {
     st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
     st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
@@ -266,8 +282,14 @@ __global__ __launch_bounds__(1024) void wn_bn_finalize_kernel(const float* __res
   }
 }
 
+// forward tiling: <= 48-row tiles, two resident workgroups per CU
+constexpr int WN_GRID_DEFAULT = 512, WN_FWD_MAX_MT = 3;
+static LayerGeom make_fwd_geom(int B, int T_in, int V, int d) {
+  return make_layer_geom(B, T_in, V, d, wn_env_int("HOPMI_WN_GRID", WN_GRID_DEFAULT), wn_env_int("HOPMI_WN_MAXMT", WN_FWD_MAX_MT));
+}
+
 static int wn_grid(const LayerGeom& L) {
-  const int cap = wn_env_int("HOPMI_WN_GRID", 256);
+  const int cap = wn_env_int("HOPMI_WN_GRID", WN_GRID_DEFAULT);
   return L.g.ntiles < cap ? L.g.ntiles : cap;
 }
 
@@ -285,9 +307,15 @@ static void launch_wn_fwd(const float* xin, const float* scsh, const float* wtcn
 
 using namespace hopmi;
 
+#ifdef HOPMI_STAMPS
+extern "C" int hopmi_debug_set_stamps_wn(long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation) {
   if (wn_validate(B, T_in, V, dilation)) return 0;
-  const LayerGeom L = make_layer_geom(B, T_in, V, dilation, wn_env_int("HOPMI_WN_GRID", 256));
+  const LayerGeom L = make_fwd_geom(B, T_in, V, dilation);
   return (size_t)wn_grid(L) * 2 * C;
 }
 
@@ -300,7 +328,7 @@ extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const 
   if (do_gcn && (!prep || !Wm || !bm)) { set_error("hopmi_wn_layer_fwd: do_gcn needs prep, Wm, bm"); return HOPMI_EINVAL; }
   const bool stats = ws != nullptr;
   if (stats && !do_gcn) { set_error("hopmi_wn_layer_fwd: batch statistics (ws) need do_gcn"); return HOPMI_EINVAL; }
-  const LayerGeom L = make_layer_geom(B, T_in, V, dilation, wn_env_int("HOPMI_WN_GRID", 256));
+  const LayerGeom L = make_fwd_geom(B, T_in, V, dilation);
   const int grid = wn_grid(L);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = stats ? ws : nullptr;
@@ -320,7 +348,7 @@ extern "C" int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const f
                                     int B, int T_in, int V, int dilation, void* stream) {
   if (int e = wn_validate(B, T_in, V, dilation)) return e;
   if (!ws || !gamma || !beta || !scsh_out || !mean_rstd_out) { set_error("hopmi_wn_bn_finalize: null pointer argument"); return HOPMI_EINVAL; }
-  const LayerGeom L = make_layer_geom(B, T_in, V, dilation, wn_env_int("HOPMI_WN_GRID", 256));
+  const LayerGeom L = make_fwd_geom(B, T_in, V, dilation);
   hipLaunchKernelGGL(wn_bn_finalize_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), ws, wn_grid(L),
                      (double)L.n_slabs * V, gamma, beta, running_mean, running_var, momentum, eps, scsh_out, mean_rstd_out);
   return check_launch("hopmi_wn_bn_finalize");

@@ -40,8 +40,33 @@ class WavEncoder(nn.Module):
             nn.Conv1d(32, 64, 15, stride=6), nn.BatchNorm1d(64), nn.LeakyReLU(0.3, inplace=True),
             nn.Conv1d(64, 32, 15, stride=6))
 
+    @staticmethod
+    def _bn(x, bn, training):
+        """BatchNorm1d on (B,C,L) composed from reductions + element-wise ops so that autograd differentiates the
+        plain formula: the library's fused training-mode backward loses 1-9 % on these 8k-sample rows in fp32
+        (tools/probes/wavenc_probe.py), which would break the 1e-3 parity bar on this branch."""
+        if training:
+            var, mean = torch.var_mean(x, dim=(0, 2), unbiased=False)
+            with torch.no_grad():
+                n = x.shape[0] * x.shape[2]
+                bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+                bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+                bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        scale = bn.weight * torch.rsqrt(var + bn.eps)
+        return x * scale[None, :, None] + (bn.bias - mean * scale)[None, :, None]
+
     def forward(self, wav_data):
-        return self.feat_extractor(wav_data.unsqueeze(1)).transpose(1, 2)
+        x = wav_data.unsqueeze(1)
+        for layer in self.feat_extractor:
+            if isinstance(layer, nn.BatchNorm1d):
+                x = self._bn(x, layer, self.training)
+            elif isinstance(layer, nn.LeakyReLU):
+                x = F.leaky_relu(x, layer.negative_slope)
+            else:
+                x = layer(x)
+        return x.transpose(1, 2)
 
 
 class ReprogrammingLayer(nn.Module):

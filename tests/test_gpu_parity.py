@@ -385,6 +385,46 @@ def test_model_eval_vs_reference_golden(golden, V):
     assert_close(out, g["out"], what="eval out")
 
 
+@pytest.mark.parametrize("V,use_gwnet,use_reprograme", [(9, False, True), (9, True, False), (42, False, False)])
+def test_model_ablation_branches_vs_reference_golden(golden, V, use_gwnet, use_reprograme):
+    """HOP.py:205-206,232-239 -- `use_gwnet=False` (Conv1d audio encoder) and `use_reprograme=False` (LLM on the
+    raw text embeddings): outputs, gradient checksums, the set of grad-less parameters and the state_dict keys."""
+    import hopmi
+    from transformers import BertModel
+    from oracle import fill
+    from oracle.golden_util import SynthTok, SynthVocab, checksum, checksum_close, hop_cfg, tiny_bert_config
+    dev = _dev()
+    tag = ("" if use_gwnet else "_nogwnet") + ("" if use_reprograme else "_noreprog")
+    g = golden(f"model_V{V}{tag}")
+    bcfg = tiny_bert_config()
+    cfg = hop_cfg(V, bcfg.hidden_size)
+    cfg.use_gwnet, cfg.use_reprograme = use_gwnet, use_reprograme
+    m = hopmi.Model(cfg, BertModel(bcfg), SynthTok(), SynthVocab(11)).float()
+    if use_reprograme:
+        m.reprogramming_layer.dropout.p = 0.0
+    fill.fill_state_(m)
+    m._randn_like = lambda t: torch.randn(t.shape).to(t.device)
+    m = m.to(dev)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    m.train()
+    inp = _inputs(V, bcfg, dev)
+    torch.manual_seed(4321)
+    out, z, mu, lv = m(inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"][:, :16], inp["vid_indices"])
+    assert_close(out, g["out"], what="out"); assert_close(z, g["z"], what="z")
+    ((out * fill.uniform("model.gout", out.shape).to(dev)).sum() + 0.3 * z.sum() + 0.1 * (mu * mu).sum() + 0.2 * lv.exp().sum()).backward()
+    params = dict(m.named_parameters())
+    for n, want in zip(g["grad_names"], g["grad_cs"]):
+        n = str(n)
+        if n in ("audio_encoder.feat_extractor.0.bias", "audio_encoder.feat_extractor.3.bias", "audio_encoder.feat_extractor.6.bias"):
+            # a conv bias in front of BatchNorm has an analytically zero gradient: both sides hold rounding noise
+            wgrad = params[n.replace(".bias", ".weight")].grad
+            assert params[n].grad.abs().sum() <= 1e-3 * wgrad.abs().sum(), n
+            continue
+        assert checksum_close(checksum(params[n].grad), want, RTOL), n
+    for n in g["nograd_names"]:
+        assert params[str(n)].grad is None, n
+
+
 # ---------------------------------------------------------------------------------- train step
 def _zero_grad_param(name):
     return (name.endswith("mlp.mlp.bias") or name in ("pre_conv.0.bias", "pre_conv.3.bias")
