@@ -34,8 +34,29 @@ struct RowMap {
   bool ok[NIT];     // row < R
 };
 
-template <int MT>
-__global__ __launch_bounds__(256, MT <= 3 ? 2 : 1) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
+// weight slices of wave w (16 output channels), K permuted as k = 16i + 4q + e
+__device__ __forceinline__ void load_tcn_slices(float4 (&wt)[2][2][4], const float* __restrict__ wtcn, int w, int q, int j, int off) {
+#pragma unroll
+  for (int gate = 0; gate < 2; ++gate)
+#pragma unroll
+    for (int tap = 0; tap < 2; ++tap) {
+      const float4* wp = reinterpret_cast<const float4*>(wtcn + (size_t)((2 * tap + gate) * 64 + 16 * w + j) * C + 4 * q + off);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wt[gate][tap][i] = wp[4 * i];
+    }
+}
+
+__device__ __forceinline__ void load_wm_slice(float4 (&wreg)[12], const float* __restrict__ Wm, int w, int q, int j, int off) {
+  const float4* wp = reinterpret_cast<const float4*>(Wm + (size_t)(16 * w + j) * K3 + 4 * q + off);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) wreg[i] = wp[4 * i];
+}
+
+// HOIST = the workgroup walks several tiles: weight slices are loaded once and stay in registers.
+// !HOIST = one tile per workgroup: the TCN slices are loaded behind the tile's activation loads and the Wm
+// slice after the TCN phase, which starts the activation stream earlier (8 % faster at V=9, B=128).
+template <int MT, bool HOIST>
+__global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
                                                            const float* __restrict__ wtcn, const float* __restrict__ btcn,
                                                            const float* __restrict__ prep, const float* __restrict__ Wm,
                                                            const float* __restrict__ bm, float* __restrict__ y,
@@ -52,9 +73,6 @@ __global__ __launch_bounds__(256, MT <= 3 ? 2 : 1) void wn_layer_fwd_kernel(cons
   const int V = g.V, c4 = tid & 15;
   const int shift4 = L.d * V * 16;                 // tap-1 row offset in float4 units
 
-  // The wave's 16-output-channel weight slices (K permuted as k = 16i + 4q + e) are (re)loaded per tile,
-  // the TCN slices before phase 1 and the Wm slice after it, so the two never hold registers together and
-  // two workgroups fit a CU (<= 256 VGPRs): one's MFMA phases overlap the other's load / store phases.
   const float bf = btcn[16 * w + j], bg = btcn[C + 16 * w + j];
   float bias = 0.f;
   if (do_gcn) {
@@ -62,6 +80,12 @@ __global__ __launch_bounds__(256, MT <= 3 ? 2 : 1) void wn_layer_fwd_kernel(cons
     PrepRegs mr;
     prep_issue(mr, prep, g.KP * g.ldA, tid);
     prep_commit(AT, mr, g.KP * g.ldA, tid);
+  }
+  float4 wt[2][2][4];                              // [gate f/g][tap][i]
+  float4 wreg[12];
+  if (HOIST) {
+    load_tcn_slices(wt, wtcn, w, q, j, 0);
+    if (do_gcn) load_wm_slice(wreg, Wm, w, q, j, 0);
   }
   const float4 sc4 = reinterpret_cast<const float4*>(scsh)[c4];
   const float4 sh4 = reinterpret_cast<const float4*>(scsh + C)[c4];
@@ -98,16 +122,10 @@ __global__ __launch_bounds__(256, MT <= 3 ? 2 : 1) void wn_layer_fwd_kernel(cons
       }
     }
     int woff = 0;
-    asm volatile("" : "+v"(woff));                 // keeps the weight loads inside the tile loop (register budget)
-    float4 wt[2][2][4];                            // [gate f/g][tap][i]
-#pragma unroll
-    for (int gate = 0; gate < 2; ++gate)
-#pragma unroll
-      for (int tap = 0; tap < 2; ++tap) {
-        const float4* wp = reinterpret_cast<const float4*>(wtcn + (size_t)((2 * tap + gate) * 64 + 16 * w + j) * C + 4 * q + woff);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wt[gate][tap][i] = wp[4 * i];
-      }
+    if (!HOIST) {
+      asm volatile("" : "+v"(woff));               // keeps the weight loads inside the tile loop
+      load_tcn_slices(wt, wtcn, w, q, j, woff);
+    }
     HOPMI_STAMP(1);
     {
       __syncthreads();                             // previous tile's LDS fully consumed
@@ -168,12 +186,7 @@ __global__ __launch_bounds__(256, MT <= 3 ? 2 : 1) void wn_layer_fwd_kernel(cons
           }
         }
     }
-    float4 wreg[12];
-    if (do_gcn) {
-      const float4* wp = reinterpret_cast<const float4*>(Wm + (size_t)(16 * w + j) * K3 + 4 * q + woff);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) wreg[i] = wp[4 * i];
-    }
+    if (!HOIST && do_gcn) load_wm_slice(wreg, Wm, w, q, j, woff);
     __syncthreads();
     HOPMI_STAMP(4);
 
@@ -282,8 +295,8 @@ __global__ __launch_bounds__(1024) void wn_bn_finalize_kernel(const float* __res
   }
 }
 
-// forward tiling: <= 48-row tiles, two resident workgroups per CU
-constexpr int WN_GRID_DEFAULT = 512, WN_FWD_MAX_MT = 3;
+// forward tiling: one workgroup per CU, tiles of up to 80 rows (two 48-row workgroups per CU measured slower)
+constexpr int WN_GRID_DEFAULT = 256, WN_FWD_MAX_MT = WN_MAX_MT;
 static LayerGeom make_fwd_geom(int B, int T_in, int V, int d) {
   return make_layer_geom(B, T_in, V, d, wn_env_int("HOPMI_WN_GRID", WN_GRID_DEFAULT), wn_env_int("HOPMI_WN_MAXMT", WN_FWD_MAX_MT));
 }
@@ -299,8 +312,12 @@ static void launch_wn_fwd(const float* xin, const float* scsh, const float* wtcn
                           const LayerGeom& L, int do_gcn, int grid, hipStream_t st) {
   const GcnGeom& g = L.g;
   const size_t lds = ((size_t)g.rows_lds * (2 * LDD + LDH) + (size_t)g.KP * g.ldA) * sizeof(float);
-  hipLaunchKernelGGL(wn_layer_fwd_kernel<MT>, dim3(grid), dim3(256), lds, st, xin, scsh, wtcn, btcn, prep, Wm, bm, y, fs,
-                     utail, part, L, do_gcn, utail_ld / 4);
+  if (g.ntiles > grid)
+    hipLaunchKernelGGL((wn_layer_fwd_kernel<MT, true>), dim3(grid), dim3(256), lds, st, xin, scsh, wtcn, btcn, prep, Wm, bm, y,
+                       fs, utail, part, L, do_gcn, utail_ld / 4);
+  else
+    hipLaunchKernelGGL((wn_layer_fwd_kernel<MT, false>), dim3(grid), dim3(256), lds, st, xin, scsh, wtcn, btcn, prep, Wm, bm, y,
+                       fs, utail, part, L, do_gcn, utail_ld / 4);
 }
 
 }  // namespace hopmi

@@ -24,11 +24,12 @@ class _WaveNetStackFn(torch.autograd.Function):
     statistics advanced in place); backward = 8 hopmi_wn_layer_bwd calls in reverse, each handing the next
     one its gradient as two tap tensors plus the BatchNorm-backward coefficients.
 
-    apply(x0, A1, A2, prep, bns, *params) with params = 8 x (wf, bf, wg, bg), 8 x (Wm, bm), 8 x (gamma, beta);
-    `bns` is the list of nn.BatchNorm2d modules (running-stat buffers, momentum, eps)."""
+    apply(x0, A1, A2, prep, bns, keep, *params) with params = 8 x (wf, bf, wg, bg), 8 x (Wm, bm), 8 x (gamma, beta);
+    `bns` is the list of nn.BatchNorm2d modules (running-stat buffers, momentum, eps); `keep` a list that receives
+    the per-layer statistics workspaces (gwnet.replay_bn_update)."""
 
     @staticmethod
-    def forward(ctx, x0, A1, A2, prep, bns, *params):
+    def forward(ctx, x0, A1, A2, prep, bns, keep, *params):
         n = len(DILATIONS)
         tcn = [params[4 * i:4 * i + 4] for i in range(n)]
         mlp = [params[4 * n + 2 * i:4 * n + 2 * i + 2] for i in range(n)]
@@ -36,7 +37,7 @@ class _WaveNetStackFn(torch.autograd.Function):
         B, _, V, _ = x0.shape
         dev = x0.device
         tails = torch.empty(B, 4, V, 64 * n, dtype=torch.float32, device=dev)
-        scsh = torch.cat([torch.ones(64, device=dev), torch.zeros(64, device=dev)])
+        scsh = _identity_scsh(dev)
         xin = x0.contiguous()
         saved_x, saved_y, saved_fs, saved_scsh, saved_mr, saved_wtcn = [xin], [], [], [], [], []
         for i, d in enumerate(DILATIONS):
@@ -48,8 +49,7 @@ class _WaveNetStackFn(torch.autograd.Function):
             y, fs, scsh_out, mean_rstd = ops.wn_layer_fwd(
                 xin, scsh, wtcn, btcn, prep, mlp[i][0], mlp[i][1], tails[..., 64 * i:64 * (i + 1)], d,
                 want_y=not last, want_fs=True, do_gcn=True,
-                bn=(aff[i][0], aff[i][1], bn.running_mean, bn.running_var, bn.momentum, bn.eps))
-            bn.num_batches_tracked += 1
+                bn=(aff[i][0], aff[i][1], bn.running_mean, bn.running_var, bn.momentum, bn.eps), stats_keep=keep)
             saved_fs.append(fs); saved_scsh.append(scsh); saved_wtcn.append(wtcn)
             if not last:
                 saved_y.append(y); saved_mr.append(mean_rstd); saved_x.append(y)
@@ -91,7 +91,18 @@ class _WaveNetStackFn(torch.autograd.Function):
         d0 = DILATIONS[0]
         dx0 = F.pad(P0n, (0, 0, 0, 0, 0, d0)) + F.pad(P1n, (0, 0, 0, 0, d0, 0))
         flat = [t for tup in g_tcn for t in tup] + [t for tup in g_mlp for t in tup] + [t for tup in g_aff for t in tup]
-        return (dx0, dA1, dA2, None, None, *flat)
+        return (dx0, dA1, dA2, None, None, None, *flat)
+
+
+_SCSH0 = {}
+
+
+def _identity_scsh(dev):
+    """scale = 1, shift = 0 for the first layer's normalise-on-load (a per-device constant)."""
+    t = _SCSH0.get(dev)
+    if t is None:
+        t = _SCSH0[dev] = torch.cat([torch.ones(64, device=dev), torch.zeros(64, device=dev)])
+    return t
 
 
 class nconv(nn.Module):
@@ -180,6 +191,7 @@ class gwnet(nn.Module):
         self.end_conv_1 = nn.Conv2d(skip_channels, end_channels, (1, 1), bias=True)
         self.end_conv_2 = nn.Conv2d(end_channels, out_dim, (1, 1), bias=True)
         self.receptive_field = receptive_field
+        self._bn_keep = []
         self.num_nodes, self.in_dim, self.out_dim = num_nodes, in_dim, out_dim
         self.skip_channels, self.end_channels = skip_channels, end_channels
 
@@ -218,9 +230,10 @@ class gwnet(nn.Module):
         Training mode uses batch statistics and advances the running statistics like nn.BatchNorm2d."""
         B, _, V, _ = x.shape
         tails = torch.empty(B, 4, V, 64 * len(DILATIONS), dtype=torch.float32, device=x.device)
-        scsh = torch.cat([torch.ones(64, device=x.device), torch.zeros(64, device=x.device)])
+        scsh = _identity_scsh(x.device)
         xin = x.contiguous()
         last = len(DILATIONS) - 1
+        keep = self._bn_keep = []
         for i, d in enumerate(DILATIONS):
             bn = self.bn[i]
             wtcn, btcn = self._packed_tcn(i)
@@ -231,9 +244,7 @@ class gwnet(nn.Module):
             bnargs = (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps) if self.training else None
             y, _, scsh_out, _ = ops.wn_layer_fwd(xin, scsh, wtcn, btcn, prep, mlp.weight, mlp.bias,
                                                  tails[..., 64 * i:64 * (i + 1)], d, want_y=(i != last),
-                                                 do_gcn=do_gcn, bn=bnargs)
-            if self.training:
-                bn.num_batches_tracked += 1
+                                                 do_gcn=do_gcn, bn=bnargs, stats_keep=keep)
             if i == last:
                 break
             if self.training:
@@ -242,7 +253,22 @@ class gwnet(nn.Module):
                 sc = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
                 scsh = torch.cat([sc, bn.bias - bn.running_mean * sc])
             xin = y
+        if self.training:
+            self._count_batches()
         return tails
+
+    def _count_batches(self):
+        torch._foreach_add_([bn.num_batches_tracked for bn in self.bn], 1)
+
+    def replay_bn_update(self):
+        """Apply the running-statistics update of the most recent training-mode fused forward once more: what a
+        second forward over the same input with unchanged weights does to the BatchNorm buffers (the kernels
+        are bitwise reproducible, so its batch statistics would be the same numbers)."""
+        if len(self._bn_keep) != len(self.bn):
+            raise RuntimeError("hopmi gwnet: no training-mode fused forward to replay")
+        for kept, bn in zip(self._bn_keep, self.bn):
+            ops.wn_bn_replay(kept, bn)
+        self._count_batches()
 
     def _tail(self, tails):
         """skip 1x1 convs summed over layers (one K=512 GEMM), relu, end convs: gwnet.py:209-220,240-246."""
@@ -270,7 +296,10 @@ class gwnet(nn.Module):
                 params += [self.gconv[i].mlp.mlp.weight, self.gconv[i].mlp.mlp.bias]
             for i in range(len(DILATIONS)):
                 params += [self.bn[i].weight, self.bn[i].bias]
-            return self._tail(_WaveNetStackFn.apply(x, A1, A2, prep, list(self.bn), *params))
+            keep = self._bn_keep = []
+            tails = _WaveNetStackFn.apply(x, A1, A2, prep, list(self.bn), keep, *params)
+            self._count_batches()
+            return self._tail(tails)
         # eval-mode BatchNorm with autograd (fine-tuning with frozen statistics): composed from the gcn kernel
         # and library GEMMs
         T_out = x.shape[1] - sum(DILATIONS)

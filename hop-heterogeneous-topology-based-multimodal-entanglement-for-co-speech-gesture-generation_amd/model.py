@@ -194,6 +194,34 @@ class Model(nn.Module):
             self._cache["kv"] = kv
         return kv
 
+    def _audio_branch(self, in_audio, pre_seq, B, V):
+        """HOP.py:209-231: beat MLP on the 16 audio windows, the `.view` scramble, gwnet, and the `pre` / `beat`
+        decoder inputs.  The branch has no dropout and no dependence on the speaker, so inside `step_cache()` a
+        no-grad forward over the same (in_audio, pre_seq) reuses the tensors of the previous forward of the step
+        and only repeats that forward's BatchNorm running-statistics update (train_llm.py:58 runs such a forward
+        for the diversity regulariser)."""
+        c = self._cache
+        key = (id(in_audio), in_audio._version, id(pre_seq), pre_seq._version, self.training)
+        if c is not None and not torch.is_grad_enabled() and c.get("audio_key") == key:
+            if self.training:
+                self.gwnet.replay_bn_update()
+            return c["audio"]
+        feat = self.beat(in_audio.unfold(1, 3400, 2191))                        # (B,16,170), once per window
+        t = torch.arange(16, device=feat.device).view(16, 1)
+        j = torch.arange(V, device=feat.device).view(1, V)
+        audio_feat = feat[:, (t * V + j) % 16]                                  # (B,16,V,170): the .view scramble
+        seq_audio = torch.cat([pre_seq.reshape(B, 16, V, 3), audio_feat], dim=3)
+        feature = self.gwnet.forward_cl(seq_audio).permute(0, 3, 2, 1)          # (B,173,V,4) NCHW semantics
+        g_seq = feature[:, :3].reshape(B, 3 * V, 4).permute(0, 2, 1)            # channel-major xyz, HOP.py:225-226
+        beat = feature[:, 3:].reshape(B, 34, -1)                                # raw reinterpretation, HOP.py:223
+        pre = g_seq.new_zeros((B, 34, 3 * V + 1))
+        pre[:, 0:4, :-1] = g_seq
+        pre[:, 0:4, -1] = 1
+        if c is not None and self.gwnet.dropout == 0:
+            c["audio_key"], c["audio"] = key, (pre.detach(), beat.detach())
+            c["audio_refs"] = (in_audio, pre_seq)                               # keeps the ids in the key alive
+        return pre, beat
+
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, in_audio, x_enc, text, pre_seq, vid_indices=None):
         return self.forecast(in_audio, x_enc, text, pre_seq, vid_indices)
@@ -224,17 +252,7 @@ class Model(nn.Module):
         audio_feature = None
         if self.use_gwnet:                                                      # HOP.py:209-231
             # issued first so that in backward the 183 MB mapping_layer gradient is produced early
-            feat = self.beat(in_audio.unfold(1, 3400, 2191))                    # (B,16,170), once per window
-            t = torch.arange(16, device=feat.device).view(16, 1)
-            j = torch.arange(V, device=feat.device).view(1, V)
-            audio_feat = feat[:, (t * V + j) % 16]                              # (B,16,V,170): the .view scramble
-            seq_audio = torch.cat([pre_seq.reshape(B, 16, V, 3), audio_feat], dim=3)
-            feature = self.gwnet.forward_cl(seq_audio).permute(0, 3, 2, 1)      # (B,173,V,4) NCHW semantics
-            g_seq = feature[:, :3].reshape(B, 3 * V, 4).permute(0, 2, 1)        # channel-major xyz, HOP.py:225-226
-            beat = feature[:, 3:].reshape(B, 34, -1)                            # raw reinterpretation, HOP.py:223
-            pre = g_seq.new_zeros((B, 34, 3 * V + 1))
-            pre[:, 0:4, :-1] = g_seq
-            pre[:, 0:4, -1] = 1
+            pre, beat = self._audio_branch(in_audio, pre_seq, B, V)
         else:                                                                   # HOP.py:232-239
             pre = pre_seq.new_zeros((B, 34, pre_seq.shape[2] + 1))
             pre[:, 0:pre_seq.shape[1], :-1] = pre_seq

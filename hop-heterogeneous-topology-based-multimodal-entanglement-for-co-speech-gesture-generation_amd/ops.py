@@ -292,12 +292,13 @@ def _ptr(t):
 
 
 def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, want_y=True, want_fs=False,
-                 do_gcn=True, bn=None):
+                 do_gcn=True, bn=None, stats_keep=None):
     """One fused WaveNet layer (hopmi_wn_layer_fwd).  No autograd here: the differentiable wrapper is the
     stack-level Function.  xin (B,T_in,V,64) contiguous; utail: a (B,4,V,64) view whose last-dim stride
     is 1 (a channel slice of the (B,4,V,512) skip-tail buffer).  bn = (gamma, beta, running_mean,
     running_var, momentum, eps) for training-mode batch statistics -> returns scale/shift for the next
-    layer and (mean, rstd).  Returns (y, fs, scsh_out, mean_rstd)."""
+    layer and (mean, rstd).  `stats_keep`: a list that receives (partial-sum workspace, B, T_in, V, dilation) so
+    that the same running-statistics update can be applied again (wn_bn_replay).  Returns (y, fs, scsh_out, mean_rstd)."""
     B, T_in, V, _ = xin.shape
     T_out = T_in - dilation
     dev = xin.device
@@ -327,7 +328,20 @@ def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, wan
         _lib.check(L.hopmi_wn_bn_finalize(ws.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
                                           float(momentum), float(eps), scsh_out.data_ptr(), mean_rstd.data_ptr(),
                                           B, T_in, V, dilation, st), "hopmi_wn_bn_finalize")
+        if stats_keep is not None:
+            stats_keep.append((ws, B, T_in, V, dilation))
     return y, fs, scsh_out, mean_rstd
+
+
+def wn_bn_replay(kept, bn):
+    """Advance bn's running statistics once more with the batch statistics of an earlier wn_layer_fwd call
+    (the same hopmi_wn_bn_finalize on the same partial sums, so the update is bit-identical to recomputing)."""
+    ws, B, T_in, V, dilation = kept
+    scratch = torch.empty(256, dtype=torch.float32, device=ws.device)
+    _lib.check(_lib.lib().hopmi_wn_bn_finalize(ws.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                               bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum),
+                                               float(bn.eps), scratch.data_ptr(), scratch[128:].data_ptr(),
+                                               B, T_in, V, dilation, _stream()), "hopmi_wn_bn_finalize")
 
 
 def wn_layer_bwd(xin, scsh_in, fs, wtcn, prep, Wm, P0n, P1n, d_next, y, bn_coef, dutail, gamma_prev, mean_rstd_prev,

@@ -385,6 +385,34 @@ def test_model_eval_vs_reference_golden(golden, V):
     assert_close(out, g["out"], what="eval out")
 
 
+def test_step_cache_audio_branch_equals_recompute():
+    """Inside step_cache() the no-grad forward of a step reuses the audio branch (beat MLP + gwnet) of the previous
+    forward and replays its BatchNorm update: outputs and all BatchNorm buffers must equal a full recompute, bitwise."""
+    import copy
+    dev = _dev()
+    m1, bcfg = _make_model(9, dev)
+    m1.train()
+    m2 = copy.deepcopy(m1)
+    inp = _inputs(9, bcfg, dev)
+    args = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"][:, :16], inp["vid_indices"])
+
+    def two_forwards(m, cached):
+        torch.manual_seed(7)
+        with (m.step_cache() if cached else contextlib.nullcontext()):
+            out1, *_ = m(*args)
+            with torch.no_grad():
+                out2, *_ = m(*args)
+        return out1, out2
+
+    import contextlib
+    a1, a2 = two_forwards(m1, True)
+    b1, b2 = two_forwards(m2, False)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    for x, y in zip(m1.gwnet.bn, m2.gwnet.bn):
+        assert torch.equal(x.running_mean, y.running_mean) and torch.equal(x.running_var, y.running_var)
+        assert int(x.num_batches_tracked) == int(y.num_batches_tracked) == 2
+
+
 @pytest.mark.parametrize("V,use_gwnet,use_reprograme", [(9, False, True), (9, True, False), (42, False, False)])
 def test_model_ablation_branches_vs_reference_golden(golden, V, use_gwnet, use_reprograme):
     """HOP.py:205-206,232-239 -- `use_gwnet=False` (Conv1d audio encoder) and `use_reprograme=False` (LLM on the

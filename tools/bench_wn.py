@@ -27,7 +27,10 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--saves", action="store_true", help="also write the saved gates (training forward)")
     ap.add_argument("--warm", type=float, default=2.0)
+    ap.add_argument("--lib", default=None, help="alternative libhopmi.so (A/B runs)")
     a = ap.parse_args()
+    if a.lib:
+        hopmi._lib._LIB_PATH = os.path.abspath(a.lib)
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     A = torch.softmax(torch.randn(a.V, a.V, generator=g), 1).to(dev)
