@@ -163,14 +163,14 @@ def main():
             # the gwnet graph conv runs inside the fused WaveNet-layer kernel (BN-on-load, gated TCN, skip tail,
             # node mix, graph conv, residual, BN statistics): algorithmic bytes = xin read + y / saved gates /
             # skip tail written, per launch
-            "roofline": {"kernel": "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv, 8 layers x 2 forwards)",
+            "roofline": {"kernel": "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv; 8 layers of the training forward, gates saved)",
                          "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": gf["launches"], "avg_us": 1e3 * gf["total_ms"] / gf["launches"],
                          "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
                          "f32_mfma_tflops": tfl, "f32_mfma_frac": tfl / F32_MFMA_PEAK_TFLOPS,
                          "timing": "HIP events around each launch on the launch stream, inside the timed region"},
         }
-        for name in ("wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "gru_fwd", "gru_bwd"):
+        for name in ("wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "bert_attn_fwd", "bert_attn_bwd", "gru_fwd", "gru_bwd"):
             if name in ks and ks[name]["launches"]:
                 k = ks[name]
                 out["roofline"][name + "_avg_us"] = 1e3 * k["total_ms"] / k["launches"]

@@ -5,6 +5,8 @@ run_ted.py:177-195 as HF `BertModel` truncated to 6 layers).
 parameters with the same arithmetic (HF modeling_bert: absolute position + token-type-0 embeddings, LayerNorm
 eps from the config, post-LN encoder layers, erf-GELU, no attention mask), but
   * Q, K, V projections are one GEMM (N = 3*hidden) instead of three,
+  * the attention of one (clip, head) is one workgroup of a HIP kernel that reads the fused projection output and
+    writes the output-projection input in place of transposes + library attention (ops.bert_attention; head dim 64),
   * bias + dropout + residual + LayerNorm and bias + GELU are single HIP kernels (ops.bias_*),
   * the pooler (unused by HOP) and the output_attentions / output_hidden_states tuples are skipped,
   * no parameter gradients are produced (the LLM is frozen); activation gradients flow as usual.
@@ -71,9 +73,13 @@ class FrozenBertEncoder:
         for i, lay in enumerate(llm.encoder.layer):
             att = lay.attention
             wqkv, bqkv = self._fused_qkv(i, att.self)
-            qkv = F.linear(h, wqkv, bqkv).view(B, L, 3, H, D // H).permute(2, 0, 3, 1, 4)        # (3,B,H,L,dh)
-            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p_a)
-            a = a.transpose(1, 2).reshape(B, L, D)
+            qkv = F.linear(h, wqkv, bqkv).view(B, L, 3, H, D // H)
+            if D // H == 64 and L <= 64:
+                a = ops.bert_attention(qkv, p_a, self._seed())                                   # (B,L,D), HIP
+            else:                                                                                # other head sizes
+                qkv = qkv.permute(2, 0, 3, 1, 4)                                                 # (3,B,H,L,dh)
+                a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p_a)
+                a = a.transpose(1, 2).reshape(B, L, D)
             o = F.linear(a, att.output.dense.weight)
             h = ops.bias_dropout_residual_layernorm(o, att.output.dense.bias, h, att.output.LayerNorm.weight,
                                                     att.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())

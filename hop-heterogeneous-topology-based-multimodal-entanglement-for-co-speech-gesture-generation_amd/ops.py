@@ -238,6 +238,43 @@ def attn_keep_mask(seed: int, N: int, H: int, S: int, p_drop: float, device) -> 
     return x >= int(p_drop * 4294967296.0)
 
 
+class _BertAttnFn(torch.autograd.Function):
+    """BERT self-attention on the fused projection output (hopmi_bert_attn_fwd / _bwd): qkv (B,L,3,H,64) ->
+    (B,L,H*64); the backward recomputes the probabilities and returns the gradient in the qkv layout."""
+
+    @staticmethod
+    def forward(ctx, qkv, p_drop, seed):
+        qkv = _dev_f32(qkv, "qkv")
+        B, L, three, H, dh = qkv.shape
+        if three != 3 or dh != 64 or L > 64:
+            raise _lib.HopmiError(f"hopmi bert_attn: unsupported qkv shape {tuple(qkv.shape)} (need (B, L<=64, 3, H, 64))")
+        out = torch.empty(B, L, H * dh, dtype=torch.float32, device=qkv.device)
+        Lb, st = _lib.lib(), _stream()
+        _lib.check(_timed("bert_attn_fwd", 4 * 4 * B * L * H * dh, 4 * B * H * L * L * dh,
+                          lambda: Lb.hopmi_bert_attn_fwd(qkv.data_ptr(), out.data_ptr(), B, L, H, float(p_drop), int(seed), st)),
+                   "hopmi_bert_attn_fwd")
+        ctx.save_for_backward(qkv)
+        ctx.p_drop, ctx.seed = float(p_drop), int(seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        dout = _dev_f32(dout, "dout")
+        B, L, _, H, dh = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        Lb, st = _lib.lib(), _stream()
+        _lib.check(_timed("bert_attn_bwd", 4 * 7 * B * L * H * dh, 10 * B * H * L * L * dh,
+                          lambda: Lb.hopmi_bert_attn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, L, H,
+                                                         ctx.p_drop, ctx.seed, st)), "hopmi_bert_attn_bwd")
+        return dqkv, None, None
+
+
+def bert_attention(qkv: torch.Tensor, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """dropout(softmax(q k^T / 8)) v for every (clip, head) of qkv (B,L,3,H,64) -> (B,L,H*64)."""
+    return _BertAttnFn.apply(qkv, p_drop, seed)
+
+
 class _ReprogAttnFn(torch.autograd.Function):
     """softmax(q k^T * scale) (dropout) v over the S prototypes without materialising the scores
     (hopmi_reprog_attn_fwd).  q (B,L,H,E); k, v (S,H,E)."""
@@ -458,6 +495,56 @@ def gru_layer(gi: torch.Tensor, whh: torch.Tensor, bhh: torch.Tensor) -> torch.T
     return _GruLayerFn.apply(gi, whh, bhh)
 
 
+class _PackedAlias(torch.autograd.Function):
+    """`pack` is a buffer whose storage the parameters `parts` are views of (see _GruPack): hand it to the graph
+    as a function of the parameters without copying anything; the gradient goes back as views of one tensor."""
+
+    @staticmethod
+    def forward(ctx, pack, *parts):
+        return pack.view_as(pack)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, *g.contiguous().unbind(0))
+
+
+class _GruPack:
+    """cuDNN-style flattened weights for the HIP GRU: per layer, one buffer each for
+    [weight_ih | weight_ih_reverse] (2,3H,in), [bias_ih | ..] (2,3H), weight_hh (2,3H,H), bias_hh (2,3H).
+    The nn.GRU parameters are re-pointed (`param.data`) at slices of these buffers, so the optimizer's in-place
+    updates, state_dict() and load_state_dict() keep working on the individual parameters while the kernels and
+    GEMMs read both directions as one operand with no per-call concatenation.  `ensure()` re-packs when a
+    parameter has been moved (`.to()`, `.float()`, deepcopy)."""
+
+    NAMES = ("weight_ih", "bias_ih", "weight_hh", "bias_hh")
+
+    def __init__(self):
+        self.bufs = []          # [layer][name] -> tensor (2, ...)
+
+    def ensure(self, gru):
+        ok = len(self.bufs) == gru.num_layers
+        if ok:
+            for layer, lb in enumerate(self.bufs):
+                for n in self.NAMES:
+                    buf = lb[n]
+                    f, r = getattr(gru, f"{n}_l{layer}"), getattr(gru, f"{n}_l{layer}_reverse")
+                    if f.data_ptr() != buf.data_ptr() or r.data_ptr() != buf[1].data_ptr() or f.dtype != buf.dtype:
+                        ok = False
+        if ok:
+            return self.bufs
+        with torch.no_grad():
+            self.bufs = []
+            for layer in range(gru.num_layers):
+                lb = {}
+                for n in self.NAMES:
+                    f, r = getattr(gru, f"{n}_l{layer}"), getattr(gru, f"{n}_l{layer}_reverse")
+                    buf = torch.stack([f.detach(), r.detach()]).contiguous()
+                    f.data, r.data = buf[0], buf[1]
+                    lb[n] = buf
+                self.bufs.append(lb)
+        return self.bufs
+
+
 def gru_bidirectional(x: torch.Tensor, gru: torch.nn.GRU, dropout_p: float = 0.0, training: bool = False) -> torch.Tensor:
     """torch.nn.GRU(batch_first=True, bidirectional=True) forward with h0 = 0 on the HIP recurrence.
 
@@ -466,14 +553,16 @@ def gru_bidirectional(x: torch.Tensor, gru: torch.nn.GRU, dropout_p: float = 0.0
     if not (gru.bidirectional and gru.batch_first and gru.bias):
         raise _lib.HopmiError("hopmi gru: only batch_first, bidirectional, biased nn.GRU modules are supported")
     H = gru.hidden_size
+    pack = gru.__dict__.get("_hopmi_pack")
+    if pack is None:
+        pack = gru.__dict__["_hopmi_pack"] = _GruPack()
+    bufs = pack.ensure(gru)
     inp = x
     for layer in range(gru.num_layers):
-        p = lambda n: getattr(gru, f"{n}_l{layer}")
-        pr = lambda n: getattr(gru, f"{n}_l{layer}_reverse")
-        w_ih = torch.cat([p("weight_ih"), pr("weight_ih")], 0)
-        b_ih = torch.cat([p("bias_ih"), pr("bias_ih")], 0)
-        gi = torch.nn.functional.linear(inp, w_ih, b_ih).view(inp.shape[0], inp.shape[1], 2, 3 * H)
-        inp = gru_layer(gi, torch.stack([p("weight_hh"), pr("weight_hh")]), torch.stack([p("bias_hh"), pr("bias_hh")]))
+        al = lambda n: _PackedAlias.apply(bufs[layer][n], getattr(gru, f"{n}_l{layer}"), getattr(gru, f"{n}_l{layer}_reverse"))
+        w_ih, b_ih = al("weight_ih"), al("bias_ih")
+        gi = torch.nn.functional.linear(inp, w_ih.flatten(0, 1), b_ih.flatten()).view(inp.shape[0], inp.shape[1], 2, 3 * H)
+        inp = gru_layer(gi, al("weight_hh"), al("bias_hh"))
         if dropout_p > 0 and training and layer < gru.num_layers - 1:
             inp = torch.nn.functional.dropout(inp, dropout_p, True)
     return inp

@@ -134,6 +134,17 @@ int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const 
                           const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
                           float scale, float p_drop, unsigned seed, void* stream);
 
+/* ---- self-attention of the frozen BERT encoder (HOP.py:204 -> transformers BertSelfAttention.forward; replaces
+ *      the transpose_for_scores copies + the library scaled-dot-product attention + the output re-layout) ----
+ *   qkv   [B][L][3][H][64]  output of the fused Q|K|V projection (bias added), L <= 64, head dim 64
+ *   out   [B][L][H*64]      dropout(softmax(q k^T / 8)) v, laid out for the output projection
+ *   backward: d_out [B][L][H*64] -> dqkv [B][L][3][H][64] (gradient of the projection output); probabilities are
+ *   recomputed, nothing is saved.  Dropout keeps (b*L + l, h, key) iff hash(seed, b*L + l, h, key) >= p_drop * 2^32
+ *   (same stateless hash as hopmi_reprog_attn_fwd).  One workgroup per (b, h): no atomics, reproducible. */
+int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, void* stream);
+int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* dqkv, int B, int L, int H, float p_drop,
+                        unsigned seed, void* stream);
+
 /* ---- fused element-wise epilogues of the frozen BERT block (HOP.py:204 -> transformers BertIntermediate /
  *      BertSelfOutput / BertOutput), forward and backward w.r.t. activations (the LLM is frozen, HOP.py:90-91).
  *   bias_gelu:  out[M][N] = gelu_erf(x + bias)                     dx = dy * gelu'(x + bias)

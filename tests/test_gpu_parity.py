@@ -157,6 +157,40 @@ def test_fused_epilogues_vs_torch(M, D, p):
     assert_close(y, yr, 1e-5, "gelu"); assert_close(gy, gyr, 1e-4, "gelu dx")
 
 
+# ------------------------------------------------------------------------- BERT self-attention kernel
+@pytest.mark.parametrize("B,L,H,p_drop", [(3, 34, 12, 0.0), (2, 34, 12, 0.1), (2, 16, 2, 0.0), (1, 64, 3, 0.2), (4, 7, 1, 0.0),
+                                           (128, 34, 12, 0.1)])
+def test_bert_attention_vs_torch(B, L, H, p_drop):
+    """hopmi_bert_attn_fwd/_bwd vs plain fp32 torch ops on the CPU (softmax(q k^T / 8), the kernel's hash mask
+    applied as dropout, times v), forward and all three input gradients; ragged (L = 7), maximum (L = 64) and
+    BASELINE (B = 128, L = 34, 12 heads) sizes."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, L, 3, H, 64, generator=g)
+    gout = torch.randn(B, L, H * 64, generator=g)
+    x = qkv.to(dev).requires_grad_()
+    seed = 0x1234ABCD
+    out = ops.bert_attention(x, p_drop, seed)
+    (out * gout.to(dev)).sum().backward()
+    ref = qkv.clone().requires_grad_()
+    q, k, v = (ref[:, :, i].permute(0, 2, 1, 3) for i in range(3))                   # (B,H,L,64)
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1)
+    if p_drop > 0:
+        keep = ops.attn_keep_mask(seed, B * L, H, L, p_drop, "cpu").view(B, L, H, L).permute(0, 2, 1, 3).float()
+        assert 0.6 < keep.mean().item() < 0.97
+        p = p * keep / (1 - p_drop)
+    want = (p @ v).permute(0, 2, 1, 3).reshape(B, L, H * 64)
+    (want * gout).sum().backward()
+    assert_close(out, want, 1e-4, "out")
+    assert_close(x.grad, ref.grad, 1e-4, "dqkv")
+    # bitwise reproducible
+    x2 = qkv.to(dev).requires_grad_()
+    out2 = ops.bert_attention(x2, p_drop, seed)
+    (out2 * gout.to(dev)).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(x.grad, x2.grad)
+
+
 # ------------------------------------------------------------------------- reprogramming attention
 @pytest.mark.parametrize("tag,B,S,d_llm,p_drop", [("tiny", 2, 50, 48, 0.0), ("real", 1, 1500, 768, 0.0),
                                                      ("tiny", 5, 50, 48, 0.1), ("real", 3, 1500, 768, 0.1)])

@@ -68,6 +68,27 @@ def main():
     for _ in range(3):
         run()
     torch.cuda.synchronize()
+    if os.environ.get("HOST", "0") == "1":
+        # host issue time (step entry -> the step's single device->host copy) vs wall time per step
+        import time
+        from hopmi import steps as _steps
+        marks = []
+        orig = _steps._ret_dict
+        def ret(*a, **k):
+            marks.append(time.perf_counter())
+            return orig(*a, **k)
+        _steps._ret_dict = ret
+        t_host = t_wall = 0.0
+        n = 20
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            t1 = time.perf_counter()
+            t_host += marks[-1] - t0
+            t_wall += t1 - t0
+        print(f"host issue {t_host / n * 1e3:.2f} ms/step, wall {t_wall / n * 1e3:.2f} ms/step")
+        return
     if os.environ.get("SITES", "1") == "1":
         host_sites(run)
         return
