@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="clips per GPU (configs[1]: 128)")
     ap.add_argument("--dataset", default="TED", choices=["TED", "TED_expressive"])
     ap.add_argument("--epoch", type=int, default=0, help="> 10 adds the GAN discriminator step")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the headline configuration (configs[1]); bf16 = library GEMMs under autocast (configs 2/4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -99,6 +101,7 @@ def main():
 
     V = 9 if args.dataset == "TED" else 42
     B = args.batch
+    hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
     torch.manual_seed(0)                                       # identical replicas
     model = hopmi.Model(synth.model_configs(args.dataset), synth.build_bert(6), synth.SyntheticTokenizer(),
                         synth.SpeakerVocab(1370)).float().to(dev)
@@ -154,9 +157,10 @@ def main():
             "metric": "training clips/sec (34-frame, 10-joint TED)" if V == 9 else "training clips/sec (34-frame, 43-joint TED-Expressive)",
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 GEMMs (autocast) + f32 HIP kernels, f32 master weights", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{1 if V == 9 else 3}] per GPU: {args.dataset} {V + 1}-joint ({V} graph nodes), "
-                                   f"34-frame clips, batch {B}/GPU, fp32, full train_llm step "
+                                   f"34-frame clips, batch {B}/GPU, {args.dtype}, full train_llm step "
                                    f"({'GAN phase' if args.epoch > 10 else 'epoch<=10: 2 generator forwards + backward + Adam'})",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "llm": "BERT-base geometry, 6 layers, random init, frozen", "losses": last},

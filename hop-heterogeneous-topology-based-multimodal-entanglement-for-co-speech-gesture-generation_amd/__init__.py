@@ -14,4 +14,4 @@ __version__ = "0.1.0"
 from .model import Model, ReprogrammingLayer          # noqa: F401
 from .gwnet import gwnet, gcn, nconv, linear          # noqa: F401
 from .nets import ConvDiscriminator, PoseGenerator    # noqa: F401
-from .steps import train_llm, train_iter_gan          # noqa: F401
+from .steps import train_llm, train_iter_gan, mixed_precision   # noqa: F401

@@ -327,7 +327,7 @@ __device__ __forceinline__ void stage_rows_sc1(float* dst, int ldk, int nrows, i
   }
 }
 
-constexpr int GRU_SPIN_LIMIT = 1 << 20;            // ~1 s of polling before giving up
+constexpr int GRU_SPIN_LIMIT = 1 << 23;            // ~8 s of polling before giving up (a peer rank's collective may hold CUs)
 
 // returns false on timeout (uniform over the workgroup)
 __device__ __forceinline__ bool gru_wait(const int* cnt, int want, int* status, int* flag_lds) {

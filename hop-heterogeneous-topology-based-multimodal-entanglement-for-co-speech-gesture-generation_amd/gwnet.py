@@ -29,6 +29,7 @@ class _WaveNetStackFn(torch.autograd.Function):
     the per-layer statistics workspaces (gwnet.replay_bn_update)."""
 
     @staticmethod
+    @ops._fwd32
     def forward(ctx, x0, A1, A2, prep, bns, keep, *params):
         n = len(DILATIONS)
         tcn = [params[4 * i:4 * i + 4] for i in range(n)]
@@ -49,7 +50,7 @@ class _WaveNetStackFn(torch.autograd.Function):
             y, fs, scsh_out, mean_rstd = ops.wn_layer_fwd(
                 xin, scsh, wtcn, btcn, prep, mlp[i][0], mlp[i][1], tails[..., 64 * i:64 * (i + 1)], d,
                 want_y=not last, want_fs=True, do_gcn=True,
-                bn=(aff[i][0], aff[i][1], bn.running_mean, bn.running_var, bn.momentum, bn.eps), stats_keep=keep)
+                bn=(aff[i][0], aff[i][1], bn.running_mean, bn.running_var, bn.momentum, bn.eps), stats_keep=keep.items)
             saved_fs.append(fs); saved_scsh.append(scsh); saved_wtcn.append(wtcn)
             if not last:
                 saved_y.append(y); saved_mr.append(mean_rstd); saved_x.append(y)
@@ -60,6 +61,7 @@ class _WaveNetStackFn(torch.autograd.Function):
         return tails
 
     @staticmethod
+    @ops._bwd32
     def backward(ctx, dtails):
         n = len(DILATIONS)
         sv = list(ctx.saved_tensors)
@@ -92,6 +94,14 @@ class _WaveNetStackFn(torch.autograd.Function):
         dx0 = F.pad(P0n, (0, 0, 0, 0, 0, d0)) + F.pad(P1n, (0, 0, 0, 0, d0, 0))
         flat = [t for tup in g_tcn for t in tup] + [t for tup in g_mlp for t in tup] + [t for tup in g_aff for t in tup]
         return (dx0, dA1, dA2, None, None, None, *flat)
+
+
+class _Keep:
+    """Per-layer statistics workspaces of the latest training-mode forward (an object, not a list: the autocast
+    input caster rebuilds containers)."""
+
+    def __init__(self):
+        self.items = []
 
 
 _SCSH0 = {}
@@ -191,7 +201,7 @@ class gwnet(nn.Module):
         self.end_conv_1 = nn.Conv2d(skip_channels, end_channels, (1, 1), bias=True)
         self.end_conv_2 = nn.Conv2d(end_channels, out_dim, (1, 1), bias=True)
         self.receptive_field = receptive_field
-        self._bn_keep = []
+        self._bn_keep = _Keep()
         self.num_nodes, self.in_dim, self.out_dim = num_nodes, in_dim, out_dim
         self.skip_channels, self.end_channels = skip_channels, end_channels
 
@@ -233,7 +243,7 @@ class gwnet(nn.Module):
         scsh = _identity_scsh(x.device)
         xin = x.contiguous()
         last = len(DILATIONS) - 1
-        keep = self._bn_keep = []
+        keep = self._bn_keep = _Keep()
         for i, d in enumerate(DILATIONS):
             bn = self.bn[i]
             wtcn, btcn = self._packed_tcn(i)
@@ -244,7 +254,7 @@ class gwnet(nn.Module):
             bnargs = (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps) if self.training else None
             y, _, scsh_out, _ = ops.wn_layer_fwd(xin, scsh, wtcn, btcn, prep, mlp.weight, mlp.bias,
                                                  tails[..., 64 * i:64 * (i + 1)], d, want_y=(i != last),
-                                                 do_gcn=do_gcn, bn=bnargs, stats_keep=keep)
+                                                 do_gcn=do_gcn, bn=bnargs, stats_keep=keep.items)
             if i == last:
                 break
             if self.training:
@@ -264,9 +274,9 @@ class gwnet(nn.Module):
         """Apply the running-statistics update of the most recent training-mode fused forward once more: what a
         second forward over the same input with unchanged weights does to the BatchNorm buffers (the kernels
         are bitwise reproducible, so its batch statistics would be the same numbers)."""
-        if len(self._bn_keep) != len(self.bn):
+        if len(self._bn_keep.items) != len(self.bn):
             raise RuntimeError("hopmi gwnet: no training-mode fused forward to replay")
-        for kept, bn in zip(self._bn_keep, self.bn):
+        for kept, bn in zip(self._bn_keep.items, self.bn):
             ops.wn_bn_replay(kept, bn)
         self._count_batches()
 
@@ -282,11 +292,13 @@ class gwnet(nn.Module):
         """x (B,T>=13,V,in_dim) channels-last -> (B,4,V,out_dim) channels-last."""
         if x.shape[1] < self.receptive_field:
             x = F.pad(x, (0, 0, 0, 0, self.receptive_field - x.shape[1], 0))          # gwnet.py:145-146
-        x = F.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias)        # gwnet.py:149
-        A1, A2 = self.adjacency()
-        prep = ops.gcn_prepare(A1, A2)          # on-chip images of the mix matrices, shared by all layers
-        if not torch.is_grad_enabled() and self.dropout == 0:
-            return self._tail(self._skip_tails_fused(x, prep))
+        x = F.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias).float()    # gwnet.py:149
+        with torch.autocast("cuda", enabled=False):                                     # the kernels are fp32
+            A1, A2 = self.adjacency()
+            prep = ops.gcn_prepare(A1, A2)      # on-chip images of the mix matrices, shared by all layers
+            tails = self._skip_tails_fused(x, prep) if (not torch.is_grad_enabled() and self.dropout == 0) else None
+        if tails is not None:
+            return self._tail(tails)
         if self.training and self.dropout == 0:
             # differentiable fused stack: one forward and one backward kernel per WaveNet layer
             params = []
@@ -296,7 +308,7 @@ class gwnet(nn.Module):
                 params += [self.gconv[i].mlp.mlp.weight, self.gconv[i].mlp.mlp.bias]
             for i in range(len(DILATIONS)):
                 params += [self.bn[i].weight, self.bn[i].bias]
-            keep = self._bn_keep = []
+            keep = self._bn_keep = _Keep()
             tails = _WaveNetStackFn.apply(x, A1, A2, prep, list(self.bn), keep, *params)
             self._count_batches()
             return self._tail(tails)

@@ -45,6 +45,7 @@ class WavEncoder(nn.Module):
         """BatchNorm1d on (B,C,L) composed from reductions + element-wise ops so that autograd differentiates the
         plain formula: the library's fused training-mode backward loses 1-9 % on these 8k-sample rows in fp32
         (tools/probes/wavenc_probe.py), which would break the 1e-3 parity bar on this branch."""
+        x = x.float()
         if training:
             var, mean = torch.var_mean(x, dim=(0, 2), unbiased=False)
             with torch.no_grad():
@@ -183,7 +184,9 @@ class Model(nn.Module):
             # batched GEMM (no copies) and add the partial products in a fixed order.
             W, E = self.mapping_layer.weight, self.word_embeddings
             ks = next((c for c in (6, 8, 4, 3, 2) if self.vocab_size % c == 0 and self.vocab_size // c >= 1024), 1)
-            if ks > 1 and W.is_cuda:
+            # (fp32 only: the bf16 strided-batched GEMM backward of these views faults inside the BLAS library, and a
+            # bf16 GEMM of this size does not need the split)
+            if ks > 1 and W.is_cuda and not torch.is_autocast_enabled():
                 kc = self.vocab_size // ks
                 part = torch.bmm(W.view(W.shape[0], ks, kc).transpose(0, 1), E.view(ks, kc, E.shape[1]))
                 S = part.sum(0) + self.mapping_layer.bias.unsqueeze(1)

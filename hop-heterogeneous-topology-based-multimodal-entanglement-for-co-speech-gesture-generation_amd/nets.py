@@ -178,6 +178,7 @@ class ConvDiscriminator(nn.Module):
     @staticmethod
     def _bn_cl(x, bn, training):
         """BatchNorm1d on channels-last x (B,T,C), torch semantics (batch stats over B and T)."""
+        x = x.float()
         if training:
             var, mean = torch.var_mean(x, dim=(0, 1), unbiased=False)
             with torch.no_grad():

@@ -55,6 +55,12 @@ def gcn_flops(n_slabs: int, V: int) -> int:
     return n_slabs * (V * 2 * 192 * 64 + 4 * 64 * V * V)
 
 
+# Mixed precision (steps.mixed_precision / torch.autocast): the library GEMMs run in bf16, the HIP kernels stay
+# fp32 -- every Function below casts its floating inputs to fp32 and runs with autocast disabled.
+_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd32 = torch.amp.custom_bwd(device_type="cuda")
+
+
 def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.HopmiError(f"hopmi: `{name}` is on {t.device}; the hot path only runs on a ROCm device "
@@ -88,6 +94,7 @@ class _GcnFn(torch.autograd.Function):
     """h = Wm.[x ; xA1 ; xA2] + bm on channels-last slabs (gwnet.py:24-46)."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, A1, A2, Wm, bm, prep):
         x, Wm, bm = (_dev_f32(t, n) for t, n in ((x, "x"), (Wm, "Wm"), (bm, "bm")))
         V = A1.shape[0]
@@ -108,6 +115,7 @@ class _GcnFn(torch.autograd.Function):
         return h
 
     @staticmethod
+    @_bwd32
     def backward(ctx, dh):
         x, prep, Wm = ctx.saved_tensors
         dh = _dev_f32(dh, "dh")
@@ -142,6 +150,7 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
 # ------------------------------------------------------- fused BERT epilogues (frozen LLM: no parameter grads)
 class _BiasGeluFn(torch.autograd.Function):
     @staticmethod
+    @_fwd32
     def forward(ctx, x, bias):
         x, bias = _dev_f32(x, "x"), _dev_f32(bias.detach(), "bias")
         N = x.shape[-1]
@@ -155,6 +164,7 @@ class _BiasGeluFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd32
     def backward(ctx, dy):
         x, bias = ctx.saved_tensors
         dy = _dev_f32(dy, "dy")
@@ -175,6 +185,7 @@ def bias_gelu(x, bias):
 
 class _BiasDropResLnFn(torch.autograd.Function):
     @staticmethod
+    @_fwd32
     def forward(ctx, x, bias, res, gamma, beta, eps, p_drop, seed):
         x, res = _dev_f32(x, "x"), _dev_f32(res, "res")
         bias, gamma, beta = (_dev_f32(t.detach(), n) for t, n in ((bias, "bias"), (gamma, "gamma"), (beta, "beta")))
@@ -197,6 +208,7 @@ class _BiasDropResLnFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd32
     def backward(ctx, dout):
         xhat, rstd, gamma = ctx.saved_tensors
         dout = _dev_f32(dout, "dout")
@@ -243,6 +255,7 @@ class _BertAttnFn(torch.autograd.Function):
     (B,L,H*64); the backward recomputes the probabilities and returns the gradient in the qkv layout."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, qkv, p_drop, seed):
         qkv = _dev_f32(qkv, "qkv")
         B, L, three, H, dh = qkv.shape
@@ -258,6 +271,7 @@ class _BertAttnFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd32
     def backward(ctx, dout):
         (qkv,) = ctx.saved_tensors
         dout = _dev_f32(dout, "dout")
@@ -280,6 +294,7 @@ class _ReprogAttnFn(torch.autograd.Function):
     (hopmi_reprog_attn_fwd).  q (B,L,H,E); k, v (S,H,E)."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, q, k, v, scale, p_drop, seed):
         q, k, v = _dev_f32(q, "q"), _dev_f32(k, "k"), _dev_f32(v, "v")
         B, Lq, H, E = q.shape
@@ -299,6 +314,7 @@ class _ReprogAttnFn(torch.autograd.Function):
         return o
 
     @staticmethod
+    @_bwd32
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
         B, Lq, H, E = q.shape
@@ -442,6 +458,7 @@ class _GruLayerFn(torch.autograd.Function):
     gi (B,T,2,3H) = input projections of both directions; whh (2,3H,H); bhh (2,3H) -> y (B,T,2H)."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, gi, whh, bhh):
         gi, whh, bhh = _dev_f32(gi, "gi"), _dev_f32(whh, "whh"), _dev_f32(bhh, "bhh")
         B, T, two, H3 = gi.shape
@@ -462,6 +479,7 @@ class _GruLayerFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd32
     def backward(ctx, dy):
         y, gates, whh = ctx.saved_tensors
         dy = _dev_f32(dy, "dy")

@@ -8,6 +8,9 @@
 Same order and count of generator / discriminator forwards (BatchNorm running statistics
 and RNG draws are side effects the reference's training trajectory depends on), same loss
 recipe (literal `epoch > 10` gate, `+1e-8` terms, beta = 0.05 / 0.1), same dict keys.
+`mixed_precision("bf16")` (or `args.mixed_precision = "bf16"`) runs the forwards and losses of a step under
+torch.autocast: library GEMMs in bf16 (BASELINE.json configs 2 and 4), HIP kernels, reductions and losses in fp32,
+fp32 master weights and optimizer.  The default is the reference's fp32 (run_ted.py:275).
 What differs (numerics-preserving): the two generator forwards whose outputs
 the reference only ever uses detached run under `no_grad` (still in training mode), the
 batch-independent prototype branch is computed once per step, and the scalar losses are
@@ -19,6 +22,26 @@ import torch
 import torch.nn.functional as F
 
 from . import ops as _ops
+
+
+_MIXED = None
+
+
+def mixed_precision(mode):
+    """Select the step's compute precision for every later train_llm / train_iter_gan call: None / "no" = fp32
+    (default), "bf16" = bf16 GEMMs under autocast.  Returns the previous setting."""
+    global _MIXED
+    if mode not in (None, "no", "fp32", "bf16"):
+        raise ValueError(f"hopmi: unknown mixed_precision mode {mode!r}")
+    prev, _MIXED = _MIXED, (None if mode in (None, "no", "fp32") else mode)
+    return prev
+
+
+def _amp(args, tensor):
+    mode = getattr(args, "mixed_precision", None) or _MIXED
+    if mode == "bf16" and tensor.is_cuda:
+        return torch.autocast("cuda", dtype=torch.bfloat16)
+    return contextlib.nullcontext()
 
 
 # random draws go through these three so tests can replay the reference's CPU stream on the GPU
@@ -93,34 +116,38 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
     with _step_cache(model):
         if gan:                                                                # train_llm.py:15-36
             dis_optimizer.zero_grad()
-            with torch.no_grad():                                              # only used detached (:24)
-                outputs, *_ = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
-            dis_real = discriminator(add_noise(target_dir_vec), text_token_padded)
-            dis_fake = discriminator(add_noise(outputs.detach()), text_token_padded)
-            dis_error = torch.sum(-torch.mean(torch.log(dis_real + 1e-8) + torch.log(1 - dis_fake + 1e-8)))
+            with _amp(args, target_dir_vec):
+                with torch.no_grad():                                          # only used detached (:24)
+                    outputs, *_ = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
+                dis_real = discriminator(add_noise(target_dir_vec), text_token_padded)
+                dis_fake = discriminator(add_noise(outputs.detach().float()), text_token_padded)
+                dis_error = torch.sum(-torch.mean(torch.log(dis_real.float() + 1e-8) + torch.log(1 - dis_fake.float() + 1e-8)))
             accelerator.backward(dis_error)
             dis_optimizer.step()
 
         model_optim.zero_grad()
-        outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
-        dis_output = discriminator(outputs, text_token_padded)
-        gen_error = -torch.mean(torch.log(dis_output + 1e-8))
-        huber_loss = F.smooth_l1_loss(outputs / 0.1, target_dir_vec / 0.1) * 0.1
-        kld = div_reg = None
-        if (args.z_type == "speaker" or args.z_type == "random") and args.loss_reg_weight > 0.0:
-            rand_vids = None
-            if args.z_type == "speaker":
-                rand_vids = vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)]
-            with torch.no_grad():                                              # only used detached (:60,65)
-                out_rand, z_rand, _, _ = model(in_audio, log_melspec, text_token_padded, pre_seq, rand_vids)
-            div_reg, kld = _regularisers(args, outputs, z_context, z_mu, z_logvar, out_rand, z_rand)
-            loss = huber_loss * args.loss_regression_weight + div_reg * args.loss_reg_weight
-            if kld is not None:
-                loss = loss + kld * args.loss_kld_weight
-        else:
-            loss = huber_loss * args.loss_regression_weight
-        if epoch > 10:                                                         # literal gate, train_llm.py:81
-            loss = loss + gen_error * args.loss_gan_weight
+        with _amp(args, target_dir_vec):
+            outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
+            dis_output = discriminator(outputs, text_token_padded)
+            outputs = outputs.float()                                          # losses in fp32
+            gen_error = -torch.mean(torch.log(dis_output.float() + 1e-8))
+            huber_loss = F.smooth_l1_loss(outputs / 0.1, target_dir_vec / 0.1) * 0.1
+            kld = div_reg = None
+            if (args.z_type == "speaker" or args.z_type == "random") and args.loss_reg_weight > 0.0:
+                rand_vids = None
+                if args.z_type == "speaker":
+                    rand_vids = vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)]
+                with torch.no_grad():                                          # only used detached (:60,65)
+                    out_rand, z_rand, _, _ = model(in_audio, log_melspec, text_token_padded, pre_seq, rand_vids)
+                div_reg, kld = _regularisers(args, outputs, z_context.float(), z_mu.float(), z_logvar.float(),
+                                             out_rand.float(), z_rand.float())
+                loss = huber_loss * args.loss_regression_weight + div_reg * args.loss_reg_weight
+                if kld is not None:
+                    loss = loss + kld * args.loss_kld_weight
+            else:
+                loss = huber_loss * args.loss_regression_weight
+            if epoch > 10:                                                     # literal gate, train_llm.py:81
+                loss = loss + gen_error * args.loss_gan_weight
         accelerator.backward(loss)
         model_optim.step()
     return _ret_dict(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)

@@ -525,6 +525,44 @@ def test_train_llm_vs_reference_golden(golden, V, epoch, monkeypatch):
             assert checksum_close(checksum(sd[str(n)]), want, RTOL, atol), (n, checksum(sd[str(n)]), want)
 
 
+@pytest.mark.parametrize("V,epoch", [(9, 0), (42, 11)])
+def test_train_llm_bf16_mixed_precision_tracks_reference(golden, V, epoch, monkeypatch):
+    """BASELINE.json configs 2 / 4 (bf16): library GEMMs under autocast, HIP kernels and losses in fp32.  The
+    losses of one step must track the fp32 reference golden to bf16 accuracy (2e-2), the parameters must stay
+    fp32 and finite, and the mode switch must not leak into later fp32 steps."""
+    import hopmi
+    from hopmi import steps
+    from oracle import fill
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    g = golden(f"train_llm_V{V}_e{epoch}")
+    m, bcfg = _make_model(V, dev)
+    d = hopmi.ConvDiscriminator(3 * V)
+    d.gru.dropout = 0.0
+    fill.fill_state_(d, salt=1)
+    d.to(dev)
+    m.train(); d.train()
+    monkeypatch.setattr(steps, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
+    monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    inp = _inputs(V, bcfg, dev)
+    torch.manual_seed(777)
+    prev = hopmi.mixed_precision("bf16")
+    try:
+        ret = hopmi.train_llm(step_args(V), epoch, inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"],
+                              inp["vid_indices"], m, d, g_opt, d_opt, Accel())
+    finally:
+        hopmi.mixed_precision(prev)
+    assert sorted(ret.keys()) == [str(k) for k in g["ret_keys"]]
+    for k, want in zip(g["ret_keys"], g["ret_vals"]):
+        tol = 2e-2 * max(abs(want), 1e-6) if str(k) != "DIV_REG" else 0.25 * abs(want) + 1e-6   # ratio of two small L1 terms
+        assert abs(ret[str(k)] - want) <= tol, (k, ret[str(k)], want)
+    for n, p in list(m.named_parameters()) + list(d.named_parameters()):
+        assert p.dtype == torch.float32 and torch.isfinite(p).all(), n
+    assert not torch.is_autocast_enabled()
+
+
 @pytest.mark.parametrize("P", [27, 126])
 def test_discriminator_vs_reference_golden(golden, P):
     import hopmi
