@@ -1,0 +1,37 @@
+// Device helpers shared by the two attention kernels (attn.hip, bert_attn.hip): DPP row reductions and the
+// stateless dropout hash.
+#pragma once
+#include "common.h"
+
+namespace hopmi {
+
+// Reductions over the 16 lanes of a DPP row (= the 16 key columns j a lane quad-group holds), on the VALU
+// with DPP modifiers instead of ds_bpermute round trips: xor 1, xor 2 (quad_perm), then row_half_mirror
+// (lane i <-> 7 - i of each half: the two quads of a half), then row_mirror (i <-> 15 - i: the two halves).
+// Every lane of the row ends up with the row's result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_<0x141>(v));     // row_half_mirror
+  v = fmaxf(v, dpp_<0x140>(v));     // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_<0xB1>(v);
+  v += dpp_<0x4E>(v);
+  v += dpp_<0x141>(v);
+  v += dpp_<0x140>(v);
+  return v;
+}
+
+__device__ __forceinline__ unsigned attn_hash(unsigned seed, unsigned row, unsigned head, unsigned key) {
+  unsigned x = seed ^ (row * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (head * 0xC2B2AE3Du);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;      // murmur3 fmix32
+  return x;
+}
+
+}  // namespace hopmi

@@ -3,14 +3,16 @@
 //
 //   P = dropout(softmax(Q K^T / 8));  O = P V        per (clip b, head h), L <= 64 tokens
 //
-// The library path ran this as a generic memory-efficient attention (40 us forward / 121 us backward per
-// layer for 0.45 GFLOP) plus layout copies on both sides.  Here one workgroup owns one (b, h): Q, K, V
-// (L x 64 each) are read straight out of the fused QKV GEMM output [B][L][3][H][64], everything lives in LDS,
-// O is written in the [B][L][H*64] layout the output projection wants, and the backward recomputes P and
-// writes dQ, dK, dV straight into the [B][L][3][H][64] gradient of the QKV GEMM: no transposes, no
-// concatenations, no saved probabilities, no cross-workgroup reductions (bitwise reproducible).
-// All contractions on exact-fp32 MFMA (16x16x4); dropout is the stateless (seed,row,head,key) hash of attn.hip.
-#include "common.h"
+// The library path ran this as a generic memory-efficient attention (41 us forward / 121 us backward per layer
+// for 0.45 GFLOP) plus layout copies on both sides.  Here one workgroup owns one (b, h), one wave per 16 query
+// rows (forward) or per 16 rows / 16 keys (backward): Q, K, V are read straight out of the fused QKV GEMM output
+// [B][L][3][H][64]; score strips stay in accumulator registers, the softmax reduces over DPP rows, O is written
+// in the [B][L][H*64] layout the output projection wants, and the backward recomputes P and writes dQ, dK, dV
+// straight into the [B][L][3][H][64] gradient of the QKV GEMM: no transposes, no concatenations, no saved
+// probabilities, no cross-workgroup reductions (bitwise reproducible).  All contractions on exact-fp32 MFMA
+// (16x16x4, outputs transposed so that every global store is 16 bytes per lane); dropout is the stateless
+// (seed,row,head,key) hash of attn.hip.
+#include "attn_dev.h"
 
 namespace hopmi {
 
@@ -18,214 +20,253 @@ constexpr int BD = 64;             // head dim
 constexpr int BLD = BD + 4;        // LDS row stride of the Q / K / V / dO images
 constexpr int BMAXL = 64;
 
-__device__ __forceinline__ unsigned bert_hash(unsigned seed, unsigned row, unsigned head, unsigned key) {
-  unsigned x = seed ^ (row * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (head * 0xC2B2AE3Du);
-  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-  return x;
-}
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 // rows [0, LP) x 64 floats of one of q/k/v (or d_o) of (b, h) -> LDS image [LP][BLD], rows >= L zeroed
+template <int NT>
 __device__ __forceinline__ void stage_head(float* dst, const float* __restrict__ src, size_t row_stride, int L, int LP, int tid) {
-  for (int idx = tid; idx < LP * 16; idx += 256) {
+  for (int idx = tid; idx < LP * 16; idx += NT) {
     const int row = idx >> 4, c4 = idx & 15;
     const float4 v = reinterpret_cast<const float4*>(src + (size_t)min(row, L - 1) * row_stride)[c4];
     *reinterpret_cast<float4*>(dst + row * BLD + 4 * c4) = (row < L) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
-// One 16x16 output tile D = sum_k A[i][k] B[k][j] over K = 4*ksteps, both operands K-contiguous in LDS:
-// A[i][k] = a[i*lda + k], B[k][j] = b[j*ldb + k].  K is visited in the permuted order k = 16ii + 4q + e so
-// that each lane's four consecutive k are one 16-byte LDS read (K must be a multiple of 16).
-__device__ __forceinline__ f32x4 tile_kk(const float* a, int lda, const float* b, int ldb, int K, int q, int j, f32x4 acc) {
-  const float* ap = a + j * lda + 4 * q;
-  const float* bp = b + j * ldb + 4 * q;
-  for (int ii = 0; ii < K / 16; ++ii) {
-    const float4 av = *reinterpret_cast<const float4*>(ap + 16 * ii);
-    const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * ii);
-    acc = mfma16(av.x, bv.x, acc);
-    acc = mfma16(av.y, bv.y, acc);
-    acc = mfma16(av.z, bv.z, acc);
-    acc = mfma16(av.w, bv.w, acc);
-  }
-  return acc;
-}
+#define HOPMI_MFMA4(acc_, a_, b_)          \
+  acc_ = mfma16((a_).x, (b_).x, acc_);     \
+  acc_ = mfma16((a_).y, (b_).y, acc_);     \
+  acc_ = mfma16((a_).z, (b_).z, acc_);     \
+  acc_ = mfma16((a_).w, (b_).w, acc_);
 
-// D = sum_k A[i][k] B[k][j] with A K-contiguous (a[i*lda + k]) and B row-major over k (b[k*ldb + j])
-__device__ __forceinline__ f32x4 tile_kn(const float* a, int lda, const float* b, int ldb, int K, int q, int j, f32x4 acc) {
-  const float* ap = a + j * lda + 4 * q;
-  for (int ii = 0; ii < K / 16; ++ii) {
-    const float4 av = *reinterpret_cast<const float4*>(ap + 16 * ii);
-    const float* bp = b + (16 * ii + 4 * q) * ldb + j;
-    acc = mfma16(av.x, bp[0], acc);
-    acc = mfma16(av.y, bp[ldb], acc);
-    acc = mfma16(av.z, bp[2 * ldb], acc);
-    acc = mfma16(av.w, bp[3 * ldb], acc);
-  }
-  return acc;
-}
-
-// D = sum_k A[i][k] B[k][j] with both operands row-major over k: A[i][k] = a[k*lda + i], B[k][j] = b[k*ldb + j]
-__device__ __forceinline__ f32x4 tile_nn(const float* a, int lda, const float* b, int ldb, int K, int q, int j, f32x4 acc) {
-  for (int ks = 0; ks < K / 4; ++ks) {
-    const int k = 4 * ks + q;
-    acc = mfma16(a[k * lda + j], b[k * ldb + j], acc);
-  }
-  return acc;
-}
-
-// scores -> probabilities in place: Ss[row][key] (pre-scaled scores) -> softmax over key < L; optionally also
-// the dropped-out copy Pd = P * keep / (1 - p).  Wave w handles rows w, w+4, ...; lane = key.
-__device__ __forceinline__ void softmax_rows(float* Ss, float* Pd, int lds, int L, int LP, int w, int lane, unsigned seed,
-                                             unsigned row0, unsigned head, unsigned thresh, float dscale) {
-  for (int row = w; row < LP; row += 4) {
-    const bool in = lane < L && row < L;
-    const float s = in ? Ss[row * lds + lane] : -1e30f;
-    const float m = wave_max(s);
-    const float e = in ? __expf(s - m) : 0.f;
-    const float sum = wave_sum(e);
-    const float p = in ? e / sum : 0.f;
-    if (lane < LP) {
-      Ss[row * lds + lane] = p;
-      if (Pd != nullptr) {
-        const bool keep = thresh == 0u || bert_hash(seed, row0 + row, head, lane) >= thresh;
-        Pd[row * lds + lane] = keep ? p * dscale : 0.f;
-      }
+// C^T tile product used for every "probabilities x values"-shaped contraction:
+//   out[di] (D[i = d][j = n]) += sum_k X[k][16 di + i] * T[n = j][k],   k = 0 .. 16*MT
+// X: an LDS head image (row-major over k, stride BLD), T: the wave's private [16][PLD] tile (K-contiguous).
+// The lane ends up with 4 consecutive d of row/key n = j: a 16-byte store.
+template <int MT>
+__device__ __forceinline__ void xt_product(f32x4 (&o)[4], const float* X, const float* Tw, int PLD, int q, int j) {
+#pragma unroll
+  for (int di = 0; di < 4; ++di) o[di] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ii = 0; ii < MT; ++ii) {
+    const float4 bv = *reinterpret_cast<const float4*>(Tw + j * PLD + 16 * ii + 4 * q);
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const float* ap = X + (16 * ii + 4 * q) * BLD + 16 * di + j;
+      o[di] = mfma16(ap[0], bv.x, o[di]);
+      o[di] = mfma16(ap[BLD], bv.y, o[di]);
+      o[di] = mfma16(ap[2 * BLD], bv.z, o[di]);
+      o[di] = mfma16(ap[3 * BLD], bv.w, o[di]);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void bert_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int H,
-                                                            unsigned thresh, float dscale, unsigned seed) {
+// Forward.  Workgroup = (b, h), MT = ceil(L / 16) waves; wave w owns query rows [16w, 16w + 16) end to end:
+// its score strip stays in accumulator registers, the softmax reduces over the 16 lanes of a DPP row, the
+// dropped-out probabilities pass through a wave-private LDS tile to become an MFMA operand.  One barrier.
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int H,
+                                                                unsigned thresh, float dscale, unsigned seed) {
+  constexpr int LP = 16 * MT, PLD = LP + 4, NT = 64 * MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LP = (L + 15) & ~15, lds = LP + 4;
-  float* Qs = smem;
-  float* Ks = Qs + LP * BLD;
+  float* Ks = smem;
   float* Vs = Ks + LP * BLD;
-  float* Ss = Vs + LP * BLD;                       // [LP][lds] scores -> probabilities
-  float* Pd = Ss + LP * lds;                       // [LP][lds] dropped-out probabilities
+  float* Pw = Vs + LP * BLD + (threadIdx.x >> 6) * 16 * PLD;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
   const size_t rs = (size_t)3 * H * BD;
   const float* base = qkv + (size_t)b * L * rs + (size_t)h * BD;
-  stage_head(Qs, base, rs, L, LP, tid);
-  stage_head(Ks, base + (size_t)H * BD, rs, L, LP, tid);
-  stage_head(Vs, base + (size_t)2 * H * BD, rs, L, LP, tid);
-  __syncthreads();
-  const int MT = LP >> 4;
-  // S = Q K^T / 8
-  for (int t = w; t < MT * MT; t += 4) {
-    const int mi = t / MT, ni = t % MT;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = tile_kk(Qs + 16 * mi * BLD, BLD, Ks + 16 * ni * BLD, BLD, BD, q, j, acc);
+  stage_head<NT>(Ks, base + (size_t)H * BD, rs, L, LP, tid);
+  stage_head<NT>(Vs, base + (size_t)2 * H * BD, rs, L, LP, tid);
+  float4 qf[4];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(base + (size_t)min(16 * w + j, L - 1) * rs + 4 * q);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ss[(16 * mi + 4 * q + r) * lds + 16 * ni + j] = acc[r] * 0.125f;
+    for (int ii = 0; ii < 4; ++ii) qf[ii] = qp[4 * ii];
   }
   __syncthreads();
-  softmax_rows(Ss, Pd, lds, L, LP, w, lane, seed, (unsigned)(b * L), (unsigned)h, thresh, dscale);
-  __syncthreads();
-  // O^T = V^T Pd^T: D[i = d][j = row] = sum_key V[key][d] Pd[row][key]  -> lane holds 4 consecutive d of one row
-  for (int t = w; t < 4 * MT; t += 4) {
-    const int di = t / MT, mi = t % MT;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // A[i][k] = Vs[k][16di + i] (row-major over k), B[k][j] = Pd[(16mi + j)][k] (K-contiguous)
-    const float* bp = Pd + (16 * mi + j) * lds + 4 * q;
-    for (int ii = 0; ii < LP / 16; ++ii) {
-      const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * ii);
-      const float* ap = Vs + (16 * ii + 4 * q) * BLD + 16 * di + j;
-      acc = mfma16(ap[0], bv.x, acc);
-      acc = mfma16(ap[BLD], bv.y, acc);
-      acc = mfma16(ap[2 * BLD], bv.z, acc);
-      acc = mfma16(ap[3 * BLD], bv.w, acc);
+  f32x4 s[MT];
+#pragma unroll
+  for (int nt = 0; nt < MT; ++nt) s[nt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) {
+      const float4 kb = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * BLD + 16 * ii + 4 * q);
+      HOPMI_MFMA4(s[nt], qf[ii], kb)
     }
-    const int row = 16 * mi + j;
-    if (row < L)
-      *reinterpret_cast<float4*>(out + ((size_t)(b * L + row) * H + h) * BD + 16 * di + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  // s[nt][r] = scores of row 16w + 4q + r, key 16nt + j
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float m = -1e30f;
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) {
+      s[nt][r] = (16 * nt + j < L) ? s[nt][r] * 0.125f : -1e30f;
+      m = fmaxf(m, s[nt][r]);
+    }
+    m = row16_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) {
+      s[nt][r] = (16 * nt + j < L) ? __expf(s[nt][r] - m) : 0.f;
+      sum += s[nt][r];
+    }
+    const float inv = dscale / row16_sum(sum);
+    const unsigned row = (unsigned)(b * L + 16 * w + 4 * q + r);
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) {
+      const bool keep = thresh == 0u || attn_hash(seed, row, (unsigned)h, (unsigned)(16 * nt + j)) >= thresh;
+      Pw[(4 * q + r) * PLD + 16 * nt + j] = keep ? s[nt][r] * inv : 0.f;
+    }
+  }
+  f32x4 o[4];
+  xt_product<MT>(o, Vs, Pw, PLD, q, j);
+  const int row = 16 * w + j;
+  if (row < L) {
+    float* op = out + ((size_t)(b * L + row) * H + h) * BD + 4 * q;
+#pragma unroll
+    for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
   }
 }
 
-__global__ __launch_bounds__(256) void bert_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                            float* __restrict__ dqkv, int L, int H, unsigned thresh, float dscale,
-                                                            unsigned seed) {
+// Backward, two passes over the same LDS images of Q, K, V, dO:
+//   pass 1, wave = 16 query rows: scores, softmax statistics (kept in LDS for pass 2), dPd = dO V^T,
+//           delta = rowsum(Pd * dPd), dS, dQ = dS K / 8;
+//   pass 2, wave = 16 keys: recomputes its columns of P and dPd (as transposed strips, from the statistics),
+//           dV = Pd^T dO, dK = dS^T Q / 8.
+// Every output element has one owner wave and a fixed summation order: no atomics, bitwise reproducible.
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                float* __restrict__ dqkv, int L, int H, unsigned thresh,
+                                                                float dscale, unsigned seed) {
+  constexpr int LP = 16 * MT, PLD = LP + 4, NT = 64 * MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LP = (L + 15) & ~15, lds = LP + 4;
   float* Qs = smem;
   float* Ks = Qs + LP * BLD;
   float* Vs = Ks + LP * BLD;
   float* Gs = Vs + LP * BLD;                       // dO
-  float* Ss = Gs + LP * BLD;                       // P, later dS
-  float* Pd = Ss + LP * lds;                       // dropped-out P
-  float* Ds = Pd + LP * lds;                       // dP
+  float* m_s = Gs + LP * BLD;                      // row max of the scaled scores
+  float* il_s = m_s + LP;                          // 1 / row sum
+  float* dl_s = il_s + LP;                         // delta
+  float* Tw = dl_s + LP + (threadIdx.x >> 6) * 16 * PLD;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
   const size_t rs = (size_t)3 * H * BD;
   const float* base = qkv + (size_t)b * L * rs + (size_t)h * BD;
-  stage_head(Qs, base, rs, L, LP, tid);
-  stage_head(Ks, base + (size_t)H * BD, rs, L, LP, tid);
-  stage_head(Vs, base + (size_t)2 * H * BD, rs, L, LP, tid);
-  stage_head(Gs, dout + (size_t)b * L * H * BD + (size_t)h * BD, (size_t)H * BD, L, LP, tid);
-  __syncthreads();
-  const int MT = LP >> 4;
-  // S = Q K^T / 8 and dPd = dO V^T (both K-contiguous over d)
-  for (int t = w; t < 2 * MT * MT; t += 4) {
-    const int which = t / (MT * MT), tt = t % (MT * MT);
-    const int mi = tt / MT, ni = tt % MT;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (which == 0) {
-      acc = tile_kk(Qs + 16 * mi * BLD, BLD, Ks + 16 * ni * BLD, BLD, BD, q, j, acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ss[(16 * mi + 4 * q + r) * lds + 16 * ni + j] = acc[r] * 0.125f;
-    } else {
-      acc = tile_kk(Gs + 16 * mi * BLD, BLD, Vs + 16 * ni * BLD, BLD, BD, q, j, acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ds[(16 * mi + 4 * q + r) * lds + 16 * ni + j] = acc[r];
-    }
-  }
-  __syncthreads();
-  softmax_rows(Ss, Pd, lds, L, LP, w, lane, seed, (unsigned)(b * L), (unsigned)h, thresh, dscale);
+  stage_head<NT>(Qs, base, rs, L, LP, tid);
+  stage_head<NT>(Ks, base + (size_t)H * BD, rs, L, LP, tid);
+  stage_head<NT>(Vs, base + (size_t)2 * H * BD, rs, L, LP, tid);
+  stage_head<NT>(Gs, dout + (size_t)b * L * H * BD + (size_t)h * BD, (size_t)H * BD, L, LP, tid);
   __syncthreads();
   float* dst = dqkv + (size_t)b * L * rs + (size_t)h * BD;
-  // dV = Pd^T dO: D[i = key][j = d] = sum_row Pd[row][key] dO[row][d]   (both row-major over k = row)
-  for (int t = w; t < 4 * MT; t += 4) {
-    const int mi = t / 4, di = t % 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = tile_nn(Pd + 16 * mi, lds, Gs + 16 * di, BLD, LP, q, j, acc);
+
+  // ---------------- pass 1: rows 16w .. 16w + 15 ----------------------------------------------------------
+  {
+    f32x4 s[MT], d[MT];
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) { s[nt] = {0.f, 0.f, 0.f, 0.f}; d[nt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const float4 qa = *reinterpret_cast<const float4*>(Qs + (16 * w + j) * BLD + 16 * ii + 4 * q);
+      const float4 ga = *reinterpret_cast<const float4*>(Gs + (16 * w + j) * BLD + 16 * ii + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < MT; ++nt) {
+        const float4 kb = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * BLD + 16 * ii + 4 * q);
+        const float4 vb = *reinterpret_cast<const float4*>(Vs + (16 * nt + j) * BLD + 16 * ii + 4 * q);
+        HOPMI_MFMA4(s[nt], qa, kb)
+        HOPMI_MFMA4(d[nt], ga, vb)
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int key = 16 * mi + 4 * q + r;
-      if (key < L) dst[(size_t)key * rs + 2 * H * BD + 16 * di + j] = acc[r];
+      float m = -1e30f;
+#pragma unroll
+      for (int nt = 0; nt < MT; ++nt) {
+        s[nt][r] = (16 * nt + j < L) ? s[nt][r] * 0.125f : -1e30f;
+        m = fmaxf(m, s[nt][r]);
+      }
+      m = row16_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < MT; ++nt) {
+        s[nt][r] = (16 * nt + j < L) ? __expf(s[nt][r] - m) : 0.f;
+        sum += s[nt][r];
+      }
+      const float il = 1.f / row16_sum(sum);
+      const int rl = 16 * w + 4 * q + r;
+      const unsigned row = (unsigned)(b * L + rl);
+      float pd[MT], dl = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < MT; ++nt) {
+        const bool keep = thresh == 0u || attn_hash(seed, row, (unsigned)h, (unsigned)(16 * nt + j)) >= thresh;
+        s[nt][r] *= il;                                              // P
+        pd[nt] = keep ? s[nt][r] * dscale : 0.f;                     // dropped-out P
+        dl += pd[nt] * d[nt][r];
+      }
+      dl = row16_sum(dl);
+      if (j == 0) { m_s[rl] = m; il_s[rl] = il; dl_s[rl] = dl; }
+#pragma unroll
+      for (int nt = 0; nt < MT; ++nt) Tw[(4 * q + r) * PLD + 16 * nt + j] = (pd[nt] * d[nt][r] - s[nt][r] * dl) * 0.125f;   // dS / 8
+    }
+    f32x4 o[4];
+    xt_product<MT>(o, Ks, Tw, PLD, q, j);                            // dQ^T = K^T dS^T
+    const int row = 16 * w + j;
+    if (row < L) {
+      float* op = dst + (size_t)row * rs + 4 * q;
+#pragma unroll
+      for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
     }
   }
-  // dS = P * (keep/(1-p) * dPd - rowsum(P * keep/(1-p) * dPd)) / 8: since Pd = P * keep/(1-p), P*dP = Pd*dPd
-  for (int row = w; row < LP; row += 4) {
-    const float pd = lane < LP ? Pd[row * lds + lane] : 0.f;
-    const float p = lane < LP ? Ss[row * lds + lane] : 0.f;
-    const float dpd = lane < LP ? Ds[row * lds + lane] : 0.f;
-    const float delta = wave_sum(pd * dpd);
-    if (lane < LP) Ss[row * lds + lane] = (pd * dpd - p * delta) * 0.125f;
-  }
-  __syncthreads();
-  // dQ = dS K: D[i = row][j = d] = sum_key dS[row][key] K[key][d];  dK = dS^T Q: D[i = key][j = d] = sum_row dS[row][key] Q[row][d]
-  for (int t = w; t < 8 * MT; t += 4) {
-    const int which = t / (4 * MT), tt = t % (4 * MT);
-    const int mi = tt / 4, di = tt % 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (which == 0) acc = tile_kn(Ss + 16 * mi * lds, lds, Ks + 16 * di, BLD, LP, q, j, acc);
-    else acc = tile_nn(Ss + 16 * mi, lds, Qs + 16 * di, BLD, LP, q, j, acc);
+  __syncthreads();                                                   // statistics of every row visible
+
+  // ---------------- pass 2: keys 16w .. 16w + 15 ----------------------------------------------------------
+  {
+    f32x4 st[MT], dt[MT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * mi + 4 * q + r;
-      if (row < L) dst[(size_t)row * rs + which * H * BD + 16 * di + j] = acc[r];
+    for (int nt = 0; nt < MT; ++nt) { st[nt] = {0.f, 0.f, 0.f, 0.f}; dt[nt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const float4 ka = *reinterpret_cast<const float4*>(Ks + (16 * w + j) * BLD + 16 * ii + 4 * q);
+      const float4 va = *reinterpret_cast<const float4*>(Vs + (16 * w + j) * BLD + 16 * ii + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < MT; ++nt) {
+        const float4 qb = *reinterpret_cast<const float4*>(Qs + (16 * nt + j) * BLD + 16 * ii + 4 * q);
+        const float4 gb = *reinterpret_cast<const float4*>(Gs + (16 * nt + j) * BLD + 16 * ii + 4 * q);
+        HOPMI_MFMA4(st[nt], ka, qb)
+        HOPMI_MFMA4(dt[nt], va, gb)
+      }
+    }
+    // st[nt][r] = score of (row 16nt + j, key 16w + 4q + r); dt likewise for dPd
+    float ds[MT][4];
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) {
+      const int rl = 16 * nt + j;
+      const float m = m_s[rl], il = il_s[rl], dl = dl_s[rl];
+      const unsigned row = (unsigned)(b * L + rl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * w + 4 * q + r;
+        const float p = (rl < L && key < L) ? __expf(st[nt][r] * 0.125f - m) * il : 0.f;
+        const bool keep = thresh == 0u || attn_hash(seed, row, (unsigned)h, (unsigned)key) >= thresh;
+        const float pd = keep ? p * dscale : 0.f;
+        ds[nt][r] = (pd * dt[nt][r] - p * dl) * 0.125f;
+        Tw[(4 * q + r) * PLD + rl] = pd;                             // [key in strip][row]
+      }
+    }
+    const int key = 16 * w + j;
+    f32x4 o[4];
+    xt_product<MT>(o, Gs, Tw, PLD, q, j);                            // dV^T = dO^T Pd
+    if (key < L) {
+      float* op = dst + (size_t)key * rs + 2 * H * BD + 4 * q;
+#pragma unroll
+      for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tw[(4 * q + r) * PLD + 16 * nt + j] = ds[nt][r];
+    xt_product<MT>(o, Qs, Tw, PLD, q, j);                            // dK^T = Q^T dS / 8
+    if (key < L) {
+      float* op = dst + (size_t)key * rs + H * BD + 4 * q;
+#pragma unroll
+      for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
     }
   }
 }
@@ -249,11 +290,17 @@ using namespace hopmi;
 extern "C" int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, void* stream) {
   if (int e = bert_attn_validate("hopmi_bert_attn_fwd", B, L, H, p_drop)) return e;
   if (!qkv || !out) { set_error("hopmi_bert_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
-  const int LP = (L + 15) & ~15;
-  const size_t lds = ((size_t)3 * LP * BLD + 2 * (size_t)LP * (LP + 4)) * sizeof(float);
+  const int MT = (L + 15) / 16, LP = 16 * MT;
+  const size_t lds = ((size_t)2 * LP * BLD + (size_t)LP * (LP + 4)) * sizeof(float);
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
-  hipLaunchKernelGGL(bert_attn_fwd_kernel, dim3(B * H), dim3(256), lds, static_cast<hipStream_t>(stream), qkv, out, L, H, thresh,
-                     1.f / (1.f - p_drop), seed);
+  const float dscale = 1.f / (1.f - p_drop);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (MT) {
+    case 1: hipLaunchKernelGGL(bert_attn_fwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
+    case 2: hipLaunchKernelGGL(bert_attn_fwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
+    case 3: hipLaunchKernelGGL(bert_attn_fwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
+    default: hipLaunchKernelGGL(bert_attn_fwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
+  }
   return check_launch("hopmi_bert_attn_fwd");
 }
 
@@ -261,10 +308,16 @@ extern "C" int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* 
                                    unsigned seed, void* stream) {
   if (int e = bert_attn_validate("hopmi_bert_attn_bwd", B, L, H, p_drop)) return e;
   if (!qkv || !d_out || !dqkv) { set_error("hopmi_bert_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
-  const int LP = (L + 15) & ~15;
-  const size_t lds = ((size_t)4 * LP * BLD + 3 * (size_t)LP * (LP + 4)) * sizeof(float);
+  const int MT = (L + 15) / 16, LP = 16 * MT;
+  const size_t lds = ((size_t)4 * LP * BLD + 3 * (size_t)LP + (size_t)LP * (LP + 4)) * sizeof(float);
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
-  hipLaunchKernelGGL(bert_attn_bwd_kernel, dim3(B * H), dim3(256), lds, static_cast<hipStream_t>(stream), qkv, d_out, dqkv, L, H,
-                     thresh, 1.f / (1.f - p_drop), seed);
+  const float dscale = 1.f / (1.f - p_drop);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (MT) {
+    case 1: hipLaunchKernelGGL(bert_attn_bwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
+    case 2: hipLaunchKernelGGL(bert_attn_bwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
+    case 3: hipLaunchKernelGGL(bert_attn_bwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
+    default: hipLaunchKernelGGL(bert_attn_bwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
+  }
   return check_launch("hopmi_bert_attn_bwd");
 }

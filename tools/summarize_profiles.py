@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""rocprofv3 raw CSVs (gpurun_out/prof_{stats,fetch,write}) -> the summaries committed under profiles/:
+   <tag>_bench_kernel_stats.csv   per-kernel calls / total / average duration (rows >= 0.05 % of kernel time)
+   <tag>_traffic.json             HBM bytes per launch of the hand-written kernels from the two PMC passes
+                                  (gfx950: FETCH_SIZE counts 128-B requests at 64 B -> bytes = (2*FETCH + WRITE) KB)"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+tag, root = sys.argv[1], sys.argv[2]
+out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+
+
+def find(sub, pat):
+    hits = glob.glob(os.path.join(root, sub, "**", pat), recursive=True)
+    if not hits:
+        raise SystemExit(f"no {pat} under {root}/{sub}")
+    return sorted(hits, key=os.path.getsize)[-1]
+
+
+# ---- kernel stats
+rows = list(csv.DictReader(open(find("prof_stats", "*kernel_stats.csv"))))
+total = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (1x MI355X)\n")
+    f.write(f"# 7 train_llm steps profiled (B=128, TED V=9, fp32); total kernel time {total / 1e6:.2f} ms; Name truncated to 120 chars; rows >= 0.05 %\n")
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+        if float(r["TotalDurationNs"]) >= 5e-4 * total:
+            w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+# ---- PMC traffic
+KEYS = {"wn_layer_fwd": "wn_layer_fwd_kernel", "wn_layer_bwd": "wn_layer_bwd_kernel", "wn_bwd_reduce": "wn_bwd_reduce_kernel",
+        "reprog_attn_fwd": "reprog_attn_fwd_kernel", "reprog_attn_bwd_dq": "reprog_attn_bwd_dq", "reprog_attn_bwd_dkv": "reprog_attn_bwd_dkv",
+        "bert_attn_fwd": "bert_attn_fwd_kernel", "bert_attn_bwd": "bert_attn_bwd_kernel",
+        "bias_drop_res_ln_fwd": "bias_drop_res_ln_fwd", "bias_gelu_fwd": "bias_gelu_fwd",
+        "gru_fwd_persistent": "gru_fwd_persistent_kernel", "gru_bwd_persistent": "gru_bwd_persistent_kernel"}
+
+
+def counter(sub, name):
+    acc = defaultdict(lambda: [0, 0.0])
+    path = find(sub, "*counter_collection.csv")
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != name:
+            continue
+        kn = r["Kernel_Name"]
+        for k, pat in KEYS.items():
+            if pat in kn:
+                acc[k][0] += 1
+                acc[k][1] += float(r["Counter_Value"])
+                break
+    return acc
+
+
+fetch, write = counter("prof_fetch", "FETCH_SIZE"), counter("prof_write", "WRITE_SIZE")
+res = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py --steps 3 --warmup 1 "
+              "--no-cpu-baseline; per-kernel average over launches; gfx950 correction of MI355X_MICROARCH.md (HBM): FETCH_SIZE counts "
+              "128-B requests at 64 B, so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
+for k in KEYS:
+    if fetch[k][0] and write[k][0]:
+        fk, wk = fetch[k][1] / fetch[k][0], write[k][1] / write[k][0]
+        res["kernels"][k] = {"launches_sampled": fetch[k][0], "FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_avg": wk,
+                             "hbm_bytes_per_launch": (2 * fk + wk) * 1024}
+json.dump(res, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 2) for k, v in res["kernels"].items()}))
