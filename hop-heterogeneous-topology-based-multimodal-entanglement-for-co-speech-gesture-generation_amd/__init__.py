@@ -15,3 +15,4 @@ from .model import Model, ReprogrammingLayer          # noqa: F401
 from .gwnet import gwnet, gcn, nconv, linear          # noqa: F401
 from .nets import ConvDiscriminator, PoseGenerator    # noqa: F401
 from .steps import train_llm, train_iter_gan, mixed_precision   # noqa: F401
+from .infer import generate_long                      # noqa: F401

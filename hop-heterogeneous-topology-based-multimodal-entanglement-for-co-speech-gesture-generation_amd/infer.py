@@ -1,0 +1,42 @@
+"""Long-sequence inference of the reference's demo / evaluation scripts (test_checkpoint.py:395-472):
+
+    for each window a (stride = 34 - n_pre frames):
+        pre_seq  = first 16 target frames (a = 0)  |  last 16 generated frames of window a-1      (:448-451)
+        outputs  = model(in_audio[a], log_melspec[a], text[a], pre_seq, vid)                       (:459)
+        the first 4 frames of window a are cross-faded with the last 4 of window a-1               (:462-470)
+    result = windows stacked, each but the last shortened by its 4 blended frames                  (:472)
+
+`generate_long` keeps the whole loop on the device (feedback slice, cross-fade and concatenation are tensor ops,
+one device->host copy at the end instead of one per window) and runs the model in eval mode under no_grad, which
+puts gwnet on the fused no-autograd kernels with folded BatchNorm.  Audio / mel / token preparation
+(librosa, tokenizer) stays with the caller, as in the reference.
+"""
+import torch
+
+
+@torch.no_grad()
+def generate_long(model, in_audio, log_melspec, text_tokens, pre_seq, vid_indices=None, n_blend=4):
+    """in_audio (W, 36267), log_melspec (W, 34, 128), text_tokens (W, 34): one row per window; pre_seq (1, 16, 3V) the
+    seed poses of window 0; vid_indices (1,) speaker id.  Returns (W*(34 - n_blend) + n_blend, 3V) direction vectors."""
+    if in_audio.shape[0] != log_melspec.shape[0] or in_audio.shape[0] != text_tokens.shape[0]:
+        raise ValueError("hopmi generate_long: one audio / mel / text row per window expected")
+    was_training = model.training
+    model.eval()
+    try:
+        W = in_audio.shape[0]
+        pre = pre_seq.float()
+        chunks = []
+        for a in range(W):
+            out, *_ = model(in_audio[a:a + 1], log_melspec[a:a + 1], text_tokens[a:a + 1], pre, vid_indices)
+            seq = out[0]
+            pre = out[:, -16:]                                              # test_checkpoint.py:449
+            if chunks:
+                last = chunks[-1][-n_blend:]
+                chunks[-1] = chunks[-1][:-n_blend]                          # :463-464
+                jn = torch.arange(n_blend, device=seq.device, dtype=seq.dtype).unsqueeze(1)
+                head = last * (n_blend - jn) / (n_blend + 1) + seq[:n_blend] * (jn + 1) / (n_blend + 1)   # :466-470
+                seq = torch.cat([head, seq[n_blend:]], 0)
+            chunks.append(seq)
+        return torch.cat(chunks, 0)
+    finally:
+        model.train(was_training)

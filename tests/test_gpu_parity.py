@@ -586,6 +586,44 @@ def test_discriminator_vs_reference_golden(golden, P):
     assert_close(d.pre_conv[1].running_var, g["bn1_rv"], what="bn1 rv")
 
 
+def test_generate_long_matches_reference_loop():
+    """test_checkpoint.py:395-472 restated on the host (per-window model call, numpy cross-fade of 4 frames, vstack)
+    against hopmi.generate_long (device-side loop); the eval-mode forward itself is pinned by the *_eval goldens."""
+    import numpy as np
+    import hopmi
+    dev = _dev()
+    m, bcfg = _make_model(9, dev)
+    m.eval()
+    W = 3
+    g = torch.Generator().manual_seed(3)
+    audio = torch.randn(W, 36267, generator=g).to(dev)
+    mel = torch.randn(W, 34, 128, generator=g).to(dev)
+    text = torch.randint(0, bcfg.vocab_size, (W, 34), generator=g).to(dev)
+    pre0 = (0.1 * torch.randn(1, 16, 27, generator=g)).to(dev)
+    vid = torch.tensor([3], device=dev)
+    torch.manual_seed(99)
+    got = hopmi.generate_long(m, audio, mel, text, pre0, vid)
+    # the reference's loop
+    torch.manual_seed(99)
+    out_list, pre = [], pre0
+    with torch.no_grad():
+        for a in range(W):
+            if a > 0:
+                pre = outputs[:, -16:]
+            outputs, *_ = m(audio[a:a + 1], mel[a:a + 1], text[a:a + 1], pre.float(), vid)
+            out_seq = outputs[0].cpu().numpy()
+            if out_list:
+                last = out_list[-1][-4:]
+                out_list[-1] = out_list[-1][:-4]
+                for j in range(4):
+                    out_seq[j] = last[j] * (4 - j) / 5 + out_seq[j] * (j + 1) / 5
+            out_list.append(out_seq)
+    want = torch.from_numpy(np.vstack(out_list))
+    assert got.shape == (W * 30 + 4, 27)
+    assert_close(got, want, 1e-5, "generate_long")
+    assert not m.training
+
+
 def test_native_library_is_loaded():
     """The driver records which in-tree .so the GPU tests loaded: make sure it is ours."""
     from hopmi import _lib
