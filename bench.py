@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--epoch", type=int, default=0, help="> 10 adds the GAN discriminator step")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the headline configuration (configs[1]); bf16 = library GEMMs under autocast (configs 2/4)")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -102,6 +103,8 @@ def main():
     V = 9 if args.dataset == "TED" else 42
     B = args.batch
     hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
+    # (the bf16 mode is host-bound at these sizes: the per-call table lookup costs more than the selection gains)
+    tuned = (not args.no_tuned_gemms) and args.dtype == "fp32" and hopmi.use_tuned_gemms()
     torch.manual_seed(0)                                       # identical replicas
     model = hopmi.Model(synth.model_configs(args.dataset), synth.build_bert(6), synth.SyntheticTokenizer(),
                         synth.SpeakerVocab(1370)).float().to(dev)
@@ -163,7 +166,9 @@ def main():
                                    f"34-frame clips, batch {B}/GPU, {args.dtype}, full train_llm step "
                                    f"({'GAN phase' if args.epoch > 10 else 'epoch<=10: 2 generator forwards + backward + Adam'})",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "llm": "BERT-base geometry, 6 layers, random init, frozen", "losses": last},
+                       "llm": "BERT-base geometry, 6 layers, random init, frozen",
+                       "library_gemm_selection": "shipped TunableOp table (replay only)" if tuned else "library default",
+                       "losses": last},
             # the gwnet graph conv runs inside the fused WaveNet-layer kernel (BN-on-load, gated TCN, skip tail,
             # node mix, graph conv, residual, BN statistics): algorithmic bytes = xin read + y / saved gates /
             # skip tail written, per launch
