@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the headline configuration (configs[1]); bf16 = library GEMMs under autocast (configs 2/4)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
+    ap.add_argument("--rehearse-sync", action="store_true",
+                    help="N=1 only: run GradSync's bucketed RCCL path on a 1-rank group (overhead rehearsal of the N>1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -82,6 +84,7 @@ def cpu_baseline(args, V):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must precede the first HIP call
     import torch
     import torch.distributed as dist
 
@@ -93,8 +96,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
+    elif args.rehearse_sync:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     import hopmi
     from hopmi import ops, synth
@@ -114,7 +120,7 @@ def main():
     lr = 0.01 if args.dataset == "TED" else 0.005              # run_ted.py:103 / run_expressive.py:100
     g_opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr, betas=(0.5, 0.999), fused=True)
     d_opt = torch.optim.Adam(disc.parameters(), lr=lr * 0.1, betas=(0.5, 0.999), fused=True)
-    sync = GradSync([model, disc])
+    sync = GradSync([model, disc], force=args.rehearse_sync)
     sargs = synth.step_args(args.dataset)
     batch = synth.synthetic_batch(B, V, 1234 + rank, dev)
 
@@ -193,6 +199,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

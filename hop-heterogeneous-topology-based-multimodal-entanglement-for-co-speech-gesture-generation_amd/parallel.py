@@ -22,10 +22,17 @@ import torch.distributed as dist
 
 
 class _Bucket:
+    """One flat all-reduce buffer and its per-parameter views.  After the exchange the parameters' `.grad` ARE these
+    views (no copy back); the copy in is one multi-tensor launch."""
+
     def __init__(self, params: List[torch.nn.Parameter], dtype):
         self.params = params
         self.numel = sum(p.numel() for p in params)
         self.flat = torch.empty(self.numel, dtype=dtype or params[0].dtype, device=params[0].device)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
         self.pending = len(params)
         self.handle = None
 
@@ -47,9 +54,15 @@ class GradSync:
     With world_size == 1 (or torch.distributed not initialised) it is a plain backward.
     """
 
-    def __init__(self, modules, bucket_mb: float = 64.0, grad_dtype: Optional[torch.dtype] = None, group=None):
+    def __init__(self, modules, bucket_mb: float = 64.0, grad_dtype: Optional[torch.dtype] = None, group=None,
+                 force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # `force` runs the bucketed path even with one rank (a 1-rank RCCL group): used to exercise hooks, streams and
+        # collectives on a single-GPU box
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        # RCCL averages in the collective; gloo (CPU tests) has no AVG: sum, then one in-place scale per bucket
+        self._avg = self.active and dist.get_backend(group) == "nccl"
         self.grad_dtype = grad_dtype                 # e.g. torch.bfloat16 halves the xGMI bytes
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.groups: List[_Group] = []
@@ -66,7 +79,7 @@ class GradSync:
         self._group_of = {}
         self._in_backward = False
         self.bytes_reduced = 0                       # for tests / reporting
-        if self.world > 1:
+        if self.active:
             for g in self.groups:
                 for p in g.params:
                     self._group_of[id(p)] = g
@@ -75,7 +88,7 @@ class GradSync:
     # -- bucket plan of a group: built from the first backward that reaches it -----------------------
     def _plan(self, g: _Group):
         live = [p for p in g.params if p.grad is not None]
-        if self.world > 1:                                        # same plan on every rank, or hang
+        if self.active:                                           # same plan on every rank, or hang
             n = torch.tensor([len(live), sum(p.numel() for p in live)], device=g.params[0].device)
             lo, hi = n.clone(), n.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
@@ -103,13 +116,17 @@ class GradSync:
                 self._bucket_of[id(p)] = b
 
     def _launch(self, b: _Bucket):
-        off = 0
-        for p in b.params:
+        dst, src = [], []
+        for p, v in zip(b.params, b.views):
             if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
-            off += p.numel()
-        b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():          # (already the view: accumulated in place by autograd)
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)                   # one multi-tensor launch, converts to grad_dtype if set
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        b.handle = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
         self.bytes_reduced += b.flat.numel() * b.flat.element_size()
 
     def _on_grad(self, p):
@@ -127,16 +144,21 @@ class GradSync:
 
     def _collect(self, b: _Bucket):
         b.handle.wait()
-        inv = 1.0 / self.world
-        off = 0
-        for p in b.params:
-            p.grad.copy_((b.flat[off:off + p.numel()] * inv).view_as(p.grad))
-            off += p.numel()
+        if not self._avg:
+            b.flat.mul_(1.0 / self.world)
+        if b.flat.dtype == b.params[0].dtype:
+            for p, v in zip(b.params, b.views):
+                p.grad = v                                   # gradient lives in the bucket until the next zero_grad
+        else:                                                # compressed exchange: widen back into fp32 gradients
+            for p in b.params:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+            torch._foreach_copy_([p.grad for p in b.params], b.views)
         b.handle = None
 
     # -- accelerator.backward shape (train_llm.py:34,85) -----------------------------------------------
     def backward(self, loss):
-        if self.world == 1:
+        if not self.active:
             loss.backward()
             return
         for g in self.groups:

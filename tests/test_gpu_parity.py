@@ -624,6 +624,57 @@ def test_generate_long_matches_reference_loop():
     assert not m.training
 
 
+def test_gradsync_on_rccl_single_rank_group(monkeypatch):
+    """The bucketed all-reduce path (autograd hooks, RCCL stream hand-offs, copy-back) on the real device with a
+    1-rank RCCL group: two train_llm steps (epoch 11: discriminator + generator backward) must leave exactly the
+    parameters of a run without the exchange (mean over one rank = identity).  The N > 1 arithmetic is covered by the
+    world-size-2 gloo test."""
+    import copy
+    import os
+    import torch.distributed as dist
+    import hopmi
+    from hopmi import steps
+    from hopmi.parallel import GradSync
+    from oracle import fill
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        m1, bcfg = _make_model(9, dev)
+        d1 = hopmi.ConvDiscriminator(27)
+        d1.gru.dropout = 0.0
+        fill.fill_state_(d1, salt=1)
+        d1.to(dev)
+        m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
+        inp = _inputs(9, bcfg, dev)
+        monkeypatch.setattr(steps, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
+        monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))
+
+        def run(m, d, acc):
+            m.train(); d.train()
+            g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+            d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+            torch.manual_seed(5)
+            for _ in range(3):
+                ret = hopmi.train_llm(step_args(9), 11, inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"],
+                                      inp["vid_indices"], m, d, g_opt, d_opt, acc)
+            return ret
+
+        sync = GradSync([m1, d1], bucket_mb=0.25, force=True)
+        assert sync.active
+        r1 = run(m1, d1, sync)
+        r2 = run(m2, d2, Accel())
+        assert sync.bytes_reduced > 0 and len(sync.groups[0].buckets) > 1
+        assert r1 == r2
+        for (n, a), (_, b) in zip(list(m1.named_parameters()) + list(d1.named_parameters()),
+                                  list(m2.named_parameters()) + list(d2.named_parameters())):
+            assert torch.equal(a, b), n
+    finally:
+        dist.destroy_process_group()
+
+
 def test_native_library_is_loaded():
     """The driver records which in-tree .so the GPU tests loaded: make sure it is ours."""
     from hopmi import _lib
