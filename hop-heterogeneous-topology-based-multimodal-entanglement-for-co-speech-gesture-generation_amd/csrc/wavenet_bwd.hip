@@ -469,6 +469,12 @@ __global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restr
   }
 }
 
+constexpr size_t WNB_LDS_LIMIT = 160 * 1024;        // LDS per CU on gfx950
+
+static size_t wnb_lds_bytes(const GcnGeom& g) {
+  return ((size_t)g.rows_lds * (3 * LDD + 2 * LDH) + (size_t)g.KP * g.ldA + (size_t)g.K2P * g.ldB) * sizeof(float);
+}
+
 static int wnb_grid(const LayerGeom& L) {
   const int cap = wn_env_int("HOPMI_WN_BWD_GRID", 256);
   return L.g.ntiles < cap ? L.g.ntiles : cap;
@@ -480,7 +486,7 @@ static void launch_wn_bwd(const float* xin, const float* fs, const float* wtcn, 
                           float* P0, float* P1, float* part, const LayerGeom& L, int do_gcn, int d_next, int T_next,
                           int dutail_ld, int grid, hipStream_t st) {
   const GcnGeom& g = L.g;
-  const size_t lds = ((size_t)g.rows_lds * (3 * LDD + 2 * LDH) + (size_t)g.KP * g.ldA + (size_t)g.K2P * g.ldB) * sizeof(float);
+  const size_t lds = wnb_lds_bytes(g);
   hipLaunchKernelGGL(wn_layer_bwd_kernel<MT>, dim3(grid), dim3(256), lds, st, xin, fs, wtcn, prep, Wm, P0n, P1n, y, coef,
                      dutail, P0, P1, part, L, do_gcn, d_next, T_next, dutail_ld / 4);
 }
@@ -492,6 +498,7 @@ using namespace hopmi;
 extern "C" size_t hopmi_wn_layer_bwd_ws_floats(int B, int T_in, int V, int dilation) {
   if (wn_validate(B, T_in, V, dilation)) return 0;
   const LayerGeom L = make_layer_geom(B, T_in, V, dilation, wn_env_int("HOPMI_WN_BWD_GRID", 256), WNB_MAX_MT);
+  if (wnb_lds_bytes(L.g) > WNB_LDS_LIMIT) return 0;              // five tile images + both mix images do not fit (V > 42)
   return (size_t)wnb_grid(L) * part_floats(V);
 }
 
@@ -519,6 +526,11 @@ extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const 
   const int T_out = T_in - dilation;
   if (do_gcn && (d_next < 1 || T_out - d_next < 4)) { set_error("hopmi_wn_layer_bwd: bad d_next=%d for T_out=%d", d_next, T_out); return HOPMI_EINVAL; }
   const LayerGeom L = make_layer_geom(B, T_in, V, dilation, wn_env_int("HOPMI_WN_BWD_GRID", 256), WNB_MAX_MT);
+  if (wnb_lds_bytes(L.g) > WNB_LDS_LIMIT) {
+    set_error("hopmi_wn_layer_bwd: V=%d needs %zu bytes of LDS per workgroup (limit %zu): the fused backward supports V <= 42",
+              V, wnb_lds_bytes(L.g), WNB_LDS_LIMIT);
+    return HOPMI_EINVAL;
+  }
   const int grid = wnb_grid(L);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int T_next = T_out - d_next;

@@ -299,7 +299,7 @@ class gwnet(nn.Module):
             tails = self._skip_tails_fused(x, prep) if (not torch.is_grad_enabled() and self.dropout == 0) else None
         if tails is not None:
             return self._tail(tails)
-        if self.training and self.dropout == 0:
+        if self.training and self.dropout == 0 and ops.wn_fused_training_supported(x.shape[2]):
             # differentiable fused stack: one forward and one backward kernel per WaveNet layer
             params = []
             for i in range(len(DILATIONS)):

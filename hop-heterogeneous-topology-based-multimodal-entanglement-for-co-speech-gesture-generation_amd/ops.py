@@ -401,6 +401,12 @@ def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, wan
     return y, fs, scsh_out, mean_rstd
 
 
+def wn_fused_training_supported(V: int) -> bool:
+    """The fused backward keeps five tile images and both mix-matrix images in LDS: that fits for V <= 42 (the
+    reference's two skeletons are 9 and 42 nodes).  Larger graphs train through the composed path (gcn kernel + GEMMs)."""
+    return _lib.lib().hopmi_wn_layer_bwd_ws_floats(1, 16, int(V), 1) > 0
+
+
 def wn_bn_replay(kept, bn):
     """Advance bn's running statistics once more with the batch statistics of an earlier wn_layer_fwd call
     (the same hopmi_wn_bn_finalize on the same partial sums, so the update is bit-identical to recomputing)."""

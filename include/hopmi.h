@@ -105,7 +105,9 @@ int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const float* beta,
  *   gamma_prev, mean_rstd_prev: BatchNorm_{i-1} (nullable for the first layer)
  * Outputs: P0, P1 [B][T_out][V][64] (for the previous layer / the start conv), dwtcn [4][64][64], dbtcn [128],
  *   dWm [64][192], dbm [64], dA1, dA2 [V][V] (do_gcn only), dgamma_prev, dbeta_prev [64], coef_prev [3][64].
- *   ws: hopmi_wn_layer_bwd_ws_floats(...) floats.  Two launches (layer kernel + fixed-order reduce). */
+ *   ws: hopmi_wn_layer_bwd_ws_floats(...) floats.  Two launches (layer kernel + fixed-order reduce).
+ *   The kernel keeps five tile images and both mix images in LDS: V <= 42 (hopmi_wn_layer_bwd_ws_floats returns 0 and
+ *   hopmi_wn_layer_bwd HOPMI_EINVAL for larger graphs; hopmi_gcn_bwd covers those). */
 size_t hopmi_wn_layer_bwd_ws_floats(int B, int T_in, int V, int dilation);
 int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wtcn,
                        const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,

@@ -93,11 +93,15 @@ def gated_tcn(x, wf, bf, wg, bg, d):
     return torch.tanh(conv(wf, bf)) * torch.sigmoid(conv(wg, bg))
 
 
-def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True) -> Tuple[torch.Tensor, SD]:
+def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True, relu_masks=None) -> Tuple[torch.Tensor, SD]:
     """gwnet.py:143-249 (gcn_bool, addaptadj, supports=[]).  x: (B,173,V,16) -> (B,173,V,4).
 
     Returns (out, bn_updates) where bn_updates holds the new running_mean / running_var /
     num_batches_tracked of all 8 BatchNorm2d layers (empty in eval mode).
+
+    `relu_masks` = (mask_skip (B,256,V,4), mask_end (B,512,V,4)) of {0,1}: evaluate the two ReLUs of gwnet.py:240-242 as
+    `x * mask` -- gradient checks at sizes with ~1e6 pre-activations would otherwise depend on which side of zero
+    an implementation's rounding puts the few values that lie within 1e-7 of the kink.
     """
     p = lambda n: sd[prefix + n]
     x = conv1x1_nchw(x, p("start_conv.weight"), p("start_conv.bias"))
@@ -120,8 +124,10 @@ def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True) -> Tuple[torch.Tens
         else:
             x = batchnorm_eval(y, p(f"bn.{i}.weight"), p(f"bn.{i}.bias"),
                                p(f"bn.{i}.running_mean"), p(f"bn.{i}.running_var"))
-    x = torch.relu(skip)                                                   # gwnet.py:240
-    x = torch.relu(conv1x1_nchw(x, p("end_conv_1.weight"), p("end_conv_1.bias")))
+    relu1 = torch.relu if relu_masks is None else (lambda t: t * relu_masks[0].to(t.dtype))
+    relu2 = torch.relu if relu_masks is None else (lambda t: t * relu_masks[1].to(t.dtype))
+    x = relu1(skip)                                                        # gwnet.py:240
+    x = relu2(conv1x1_nchw(x, p("end_conv_1.weight"), p("end_conv_1.bias")))
     x = conv1x1_nchw(x, p("end_conv_2.weight"), p("end_conv_2.bias"))
     return x, updates
 

@@ -299,6 +299,62 @@ def test_gwnet_vs_reference_golden(golden, V, training):
         assert_close(m.bn[i].running_var, g[f"bn{i}_rv"], what=f"bn{i} running_var")
 
 
+@pytest.mark.parametrize("V,B", [(17, 3), (5, 1), (9, 37), (9, 29), (42, 5), (48, 2), (9, 128), (42, 64)])
+def test_gwnet_training_vs_oracle_ragged_and_full_size(V, B, monkeypatch):
+    """Fused forward + backward WaveNet-layer kernels against the oracle's autograd: node counts without a
+    specialised node-mix instantiation (5, 17, the maximum 48), batch 1, tile tails (B = 29, 37) and the BASELINE.json
+    sizes (V=9 B=128, V=42 B=64) -- output, input gradient, every parameter gradient, BatchNorm running statistics.
+    The two ReLUs behind the skip sum have ~1e6 pre-activations at these sizes, a few of them within rounding of zero;
+    the oracle is therefore evaluated with the ReLU masks the device path actually took (captured here), which makes
+    the gradient comparison independent of which side of the kink either implementation rounds to."""
+    import sys
+    import hopmi
+    from oracle import fill, ref_cpu, spec
+    gw = sys.modules["hopmi.gwnet"]
+    dev = _dev()
+    m = hopmi.gwnet(None, V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173,
+                    out_dim=173, residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512)
+    fill.fill_state_(m)
+    m.to(dev).train()
+    x0 = fill.uniform("gwnet.x0", (B, 173, V, 16))
+    gout = fill.uniform("gwnet.gout", (B, 173, V, 4))
+    masks = []
+    real_relu = torch.nn.functional.relu
+
+    def recording_relu(t, *a, **k):
+        masks.append((t > 0).detach().cpu())
+        return real_relu(t, *a, **k)
+
+    monkeypatch.setattr(gw.F, "relu", recording_relu)
+    xg = x0.to(dev).requires_grad_()
+    out = m(xg)
+    monkeypatch.setattr(gw.F, "relu", real_relu)
+    (out * gout.to(dev)).sum().backward()
+    # gwnet.adjacency's relu (V x V) is recorded first; the tail's two follow, channels-last (B,4,V,C) -> NCHW (B,C,V,4)
+    assert len(masks) == 3 and masks[1].shape == (B, 4, V, 256) and masks[2].shape == (B, 4, V, 512)
+    relu_masks = [mk.permute(0, 3, 2, 1).float() for mk in masks[1:]]
+    sd = spec.build_sd(spec.gwnet_spec(V, prefix=""))
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    xo = x0.clone().requires_grad_()
+    want, upd = ref_cpu.gwnet_forward(sd, xo, prefix="", training=True, relu_masks=relu_masks)
+    (want * gout).sum().backward()
+    assert_close(out, want, what="out")
+    assert_close(xg.grad, xo.grad, what="dx0")
+    for n, p in m.named_parameters():
+        if sd[n].grad is None:
+            assert p.grad is None, n
+            continue
+        if n.endswith("mlp.mlp.bias"):           # analytically zero (feeds a training-mode BatchNorm): rounding noise
+            assert p.grad.abs().max().item() <= 1e-3 * m.gconv[0].mlp.mlp.weight.grad.abs().max().item() + 1e-6, n
+            continue
+        assert_close(p.grad, sd[n].grad, what=n)
+    for i in range(8):
+        assert_close(m.bn[i].running_mean, upd[f"bn.{i}.running_mean"], what=f"bn{i} rm")
+        assert_close(m.bn[i].running_var, upd[f"bn.{i}.running_var"], what=f"bn{i} rv")
+
+
 @pytest.mark.parametrize("V,B", [(9, 2), (42, 2), (9, 37), (42, 7)])
 @pytest.mark.parametrize("training", [True, False])
 def test_gwnet_fused_layers_nograd(golden, V, B, training):
