@@ -193,7 +193,8 @@ def test_bert_attention_vs_torch(B, L, H, p_drop):
 
 # ------------------------------------------------------------------------- reprogramming attention
 @pytest.mark.parametrize("tag,B,S,d_llm,p_drop", [("tiny", 2, 50, 48, 0.0), ("real", 1, 1500, 768, 0.0),
-                                                     ("tiny", 5, 50, 48, 0.1), ("real", 3, 1500, 768, 0.1)])
+                                                     ("tiny", 5, 50, 48, 0.1), ("real", 3, 1500, 768, 0.1),
+                                                     ("real", 128, 1500, 768, 0.1)])            # BASELINE.json batch
 def test_reprogramming_layer_vs_oracle(golden, tag, B, S, d_llm, p_drop):
     """ReprogrammingLayer with the flash-style HIP attention vs the oracle (and the reference golden at
     p_drop = 0, B as in the fixture); with dropout the oracle is given the kernel's hash mask."""
@@ -238,7 +239,8 @@ def test_reprogramming_layer_vs_oracle(golden, tag, B, S, d_llm, p_drop):
 
 # ------------------------------------------------------------------------------------ GRU kernels
 @pytest.mark.parametrize("persistent", ["1", "0"])
-@pytest.mark.parametrize("B,T,I,H,L", [(3, 5, 7, 6, 2), (37, 34, 20, 350, 2), (5, 28, 8, 64, 4), (130, 9, 12, 18, 1)])
+@pytest.mark.parametrize("B,T,I,H,L", [(3, 5, 7, 6, 2), (37, 34, 20, 350, 2), (5, 28, 8, 64, 4), (130, 9, 12, 18, 1),
+                                       (128, 34, 24, 350, 1), (128, 28, 8, 64, 2)])      # last two: BASELINE.json sizes
 def test_gru_fwd_bwd_vs_oracle(B, T, I, H, L, persistent, monkeypatch):
     """hopmi_gru_fwd / hopmi_gru_bwd (through ops.gru_bidirectional) vs the oracle's explicit GRU cell, both as the
     persistent one-launch-per-layer kernels and as the per-time-step launches (HOPMI_GRU_PERSISTENT=0)."""
