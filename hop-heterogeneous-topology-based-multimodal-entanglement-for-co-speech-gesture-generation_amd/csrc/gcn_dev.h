@@ -121,19 +121,21 @@ constexpr int rows_nit(int mt) { return ((16 * mt + 4) * 16 + 255) / 256; }
 
 // Node mix of the `nsl` slabs of a tile, wave `w` doing channels [16w, 16w+16):
 // Hc[s*V + node][64*(1+blk) + c] = sum_v A{blk+1}[v][node] * Hc[s*V + v][c].
-// KS = K steps ceil(V/4), MTN = row tiles ceil(2V/16) of the stacked mix matrix: the matrix stays
-// in registers for all slabs and the result rows are stored unconditionally (rows m >= 2V of the
-// padded M go to a dump row in the tile's padding: columns >= 64 of row `dump_row` are never read).
+// KS = K steps ceil(V/4), MTN = 16-wide tiles ceil(2V/16) of the stacked mix matrix: the matrix stays
+// in registers for all slabs and the results are stored unconditionally (stacked nodes m >= 2V of the
+// padding go to a dump row in the tile's padding: columns >= 64 of row `dump_row` are never read).
 template <int KS, int MTN, int SG>
-__device__ __forceinline__ void node_mix_group(float* hs, float* Hc, const float (&am)[MTN][KS], const int (&woff)[MTN][4],
-                                               int V, int w, int q, int j) {
+__device__ __forceinline__ void node_mix_group(float* hs, float* Hc, const float (&am)[MTN][KS], const int (&woff)[MTN],
+                                               const bool (&in_slab)[MTN], int V, int w, int q, int j) {
   // SG slabs at once: SG*MTN independent accumulator chains keep the matrix pipe fed while the LDS reads of
-  // the group and the previous group's result writes are in flight
+  // the group and the previous group's result writes are in flight.  The product is taken transposed,
+  // D[i = channel][j = stacked node m] = sum_v X[v][channel] * A[v][m], so that a lane ends up with 4 consecutive
+  // channels of one node: one 16-byte LDS write per tile instead of four 4-byte ones.
   float xb[SG][KS];
 #pragma unroll
   for (int sg = 0; sg < SG; ++sg)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xb[sg][ks] = hs[(sg * V + 4 * ks + q) * LDH + 16 * w + j];   // B[k][n = c]
+    for (int ks = 0; ks < KS; ++ks) xb[sg][ks] = hs[(sg * V + 4 * ks + q) * LDH + 16 * w + j];   // A[i = c][k = v]
   f32x4 acc[SG][MTN];
 #pragma unroll
   for (int sg = 0; sg < SG; ++sg)
@@ -144,16 +146,15 @@ __device__ __forceinline__ void node_mix_group(float* hs, float* Hc, const float
 #pragma unroll
     for (int sg = 0; sg < SG; ++sg)
 #pragma unroll
-      for (int mt = 0; mt < MTN; ++mt) acc[sg][mt] = mfma16(am[mt][ks], xb[sg][ks], acc[sg][mt]);
+      for (int mt = 0; mt < MTN; ++mt) acc[sg][mt] = mfma16(xb[sg][ks], am[mt][ks], acc[sg][mt]);
 #pragma unroll
   for (int sg = 0; sg < SG; ++sg)
 #pragma unroll
-    for (int mt = 0; mt < MTN; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // rows m >= 2V of the padded M go to the dump row (absolute offset), the rest into slab sg
-        ((16 * mt + 4 * q + r) < 2 * V ? hs + sg * V * LDH : Hc)[woff[mt][r]] = acc[sg][mt][r];
-      }
+    for (int mt = 0; mt < MTN; ++mt) {
+      // stacked nodes m >= 2V of the padded N go to the dump row (absolute offset), the rest into slab sg
+      float* dst = (in_slab[mt] ? hs + sg * V * LDH : Hc) + woff[mt];
+      *reinterpret_cast<f32x4*>(dst) = acc[sg][mt];
+    }
 }
 
 template <int KS, int MTN, int SG>
@@ -161,22 +162,20 @@ __device__ __forceinline__ void node_mix(float* Hc, const float* AT, const GcnGe
                                          int w, int q, int j) {
   const int V = g.V;
   float am[MTN][KS];
-  int woff[MTN][4];
+  int woff[MTN];
+  bool in_slab[MTN];
 #pragma unroll
   for (int mt = 0; mt < MTN; ++mt) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) am[mt][ks] = AT[(4 * ks + q) * g.ldA + 16 * mt + j];   // A[i = m][k]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = 16 * mt + 4 * q + r;
-      const int blk = (m >= V) ? 1 : 0;
-      woff[mt][r] = (m < 2 * V) ? ((m - blk * V) * LDH + C * (1 + blk) + 16 * w + j)
-                                : (dump_row * LDH + C + 16 * w + j);
-    }
+    for (int ks = 0; ks < KS; ++ks) am[mt][ks] = AT[(4 * ks + q) * g.ldA + 16 * mt + j];   // B[k = v][n = m]
+    const int m = 16 * mt + j;
+    const int blk = (m >= V) ? 1 : 0;
+    in_slab[mt] = m < 2 * V;
+    woff[mt] = in_slab[mt] ? ((m - blk * V) * LDH + C * (1 + blk) + 16 * w + 4 * q) : (dump_row * LDH + C + 16 * w + 4 * q);
   }
   int s = 0;
-  for (; s + SG <= nsl; s += SG) node_mix_group<KS, MTN, SG>(Hc + s * V * LDH, Hc, am, woff, V, w, q, j);
-  for (; s < nsl; ++s) node_mix_group<KS, MTN, 1>(Hc + s * V * LDH, Hc, am, woff, V, w, q, j);
+  for (; s + SG <= nsl; s += SG) node_mix_group<KS, MTN, SG>(Hc + s * V * LDH, Hc, am, woff, in_slab, V, w, q, j);
+  for (; s < nsl; ++s) node_mix_group<KS, MTN, 1>(Hc + s * V * LDH, Hc, am, woff, in_slab, V, w, q, j);
 }
 
 // generic V (runtime loops)

@@ -73,10 +73,13 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
   const int V = g.V, c4 = tid & 15;
   const int shift4 = L.d * V * 16;                 // tap-1 row offset in float4 units
 
-  const float bf = btcn[16 * w + j], bg = btcn[C + 16 * w + j];
-  float bias = 0.f;
+  // MFMA products are taken transposed (D[i = channel][j = row]): a lane holds 4 consecutive channels
+  // 16w + 4q + r of one row, so gate outputs, saved gates and y move as 16-byte LDS / global accesses
+  const float4 bf4 = *reinterpret_cast<const float4*>(btcn + 16 * w + 4 * q);
+  const float4 bg4 = *reinterpret_cast<const float4*>(btcn + C + 16 * w + 4 * q);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (do_gcn) {
-    bias = bm[16 * w + j];
+    bias4 = *reinterpret_cast<const float4*>(bm + 16 * w + 4 * q);
     PrepRegs mr;
     prep_issue(mr, prep, g.KP * g.ldA, tid);
     prep_commit(AT, mr, g.KP * g.ldA, tid);
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
   }
   const float4 sc4 = reinterpret_cast<const float4*>(scsh)[c4];
   const float4 sh4 = reinterpret_cast<const float4*>(scsh + C)[c4];
-  float st1 = 0.f, st2 = 0.f;                      // BatchNorm partial sums of channel 16w + j
+  f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};   // BatchNorm partial sums of channels 16w + 4q + r
   // the 4 padding rows behind the tile are read by the node mix's K padding (times zero): keep them finite
   for (int idx = tid; idx < 4 * C; idx += 256) Hc[(16 * MT + idx / C) * LDH + idx % C] = 0.f;
 
@@ -160,31 +163,32 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
           for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(ra + 16 * mt * LDD + 16 * i);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            af[mt] = mfma16(a[mt].x, wt[0][tap][i].x, af[mt]);
-            ag[mt] = mfma16(a[mt].x, wt[1][tap][i].x, ag[mt]);
-            af[mt] = mfma16(a[mt].y, wt[0][tap][i].y, af[mt]);
-            ag[mt] = mfma16(a[mt].y, wt[1][tap][i].y, ag[mt]);
-            af[mt] = mfma16(a[mt].z, wt[0][tap][i].z, af[mt]);
-            ag[mt] = mfma16(a[mt].z, wt[1][tap][i].z, ag[mt]);
-            af[mt] = mfma16(a[mt].w, wt[0][tap][i].w, af[mt]);
-            ag[mt] = mfma16(a[mt].w, wt[1][tap][i].w, ag[mt]);
+            af[mt] = mfma16(wt[0][tap][i].x, a[mt].x, af[mt]);
+            ag[mt] = mfma16(wt[1][tap][i].x, a[mt].x, ag[mt]);
+            af[mt] = mfma16(wt[0][tap][i].y, a[mt].y, af[mt]);
+            ag[mt] = mfma16(wt[1][tap][i].y, a[mt].y, ag[mt]);
+            af[mt] = mfma16(wt[0][tap][i].z, a[mt].z, af[mt]);
+            ag[mt] = mfma16(wt[1][tap][i].z, a[mt].z, ag[mt]);
+            af[mt] = mfma16(wt[0][tap][i].w, a[mt].w, af[mt]);
+            ag[mt] = mfma16(wt[1][tap][i].w, a[mt].w, ag[mt]);
           }
         }
       }
       HOPMI_STAMP(3);
+      // af[mt][r] = filter pre-activation of row 16mt + j, channel 16w + 4q + r
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + 4 * q + r;
-          const float f = tanh_(af[mt][r] + bf), sg = sigmoid_(ag[mt][r] + bg);
-          Hc[row * LDH + 16 * w + j] = f * sg;
-          if (fs != nullptr && row < R) {
-            float* fp = fs + (orow0 + row) * (2 * C) + 16 * w + j;
-            fp[0] = f;
-            fp[C] = sg;
-          }
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = 16 * mt + j;
+        const float4 f = make_float4(tanh_(af[mt][0] + bf4.x), tanh_(af[mt][1] + bf4.y), tanh_(af[mt][2] + bf4.z), tanh_(af[mt][3] + bf4.w));
+        const float4 sg = make_float4(sigmoid_(ag[mt][0] + bg4.x), sigmoid_(ag[mt][1] + bg4.y), sigmoid_(ag[mt][2] + bg4.z),
+                                      sigmoid_(ag[mt][3] + bg4.w));
+        *reinterpret_cast<float4*>(Hc + row * LDH + 16 * w + 4 * q) = make_float4(f.x * sg.x, f.y * sg.y, f.z * sg.z, f.w * sg.w);
+        if (fs != nullptr && row < R) {
+          float* fp = fs + (orow0 + row) * (2 * C) + 16 * w + 4 * q;
+          *reinterpret_cast<float4*>(fp) = f;
+          *reinterpret_cast<float4*>(fp + C) = sg;
         }
+      }
     }
     if (!HOIST && do_gcn) load_wm_slice(wreg, Wm, w, q, j, woff);
     __syncthreads();
@@ -215,35 +219,42 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
         for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(ha + 16 * mt * LDH + 16 * i);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          acc[mt] = mfma16(a[mt].x, wreg[i].x, acc[mt]);
-          acc[mt] = mfma16(a[mt].y, wreg[i].y, acc[mt]);
-          acc[mt] = mfma16(a[mt].z, wreg[i].z, acc[mt]);
-          acc[mt] = mfma16(a[mt].w, wreg[i].w, acc[mt]);
+          acc[mt] = mfma16(wreg[i].x, a[mt].x, acc[mt]);
+          acc[mt] = mfma16(wreg[i].y, a[mt].y, acc[mt]);
+          acc[mt] = mfma16(wreg[i].z, a[mt].z, acc[mt]);
+          acc[mt] = mfma16(wreg[i].w, a[mt].w, acc[mt]);
         }
       }
       HOPMI_STAMP(6);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + 4 * q + r;
-          if (row < R) {
-            const float yv = acc[mt][r] + bias + R1[row * LDD + 16 * w + j];      // gwnet.py:233
-            if (y != nullptr) y[(orow0 + row) * C + 16 * w + j] = yv;
-            st1 += yv;
-            st2 += yv * yv;
-          }
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = 16 * mt + j;
+        if (row < R) {
+          const float4 res = *reinterpret_cast<const float4*>(R1 + row * LDD + 16 * w + 4 * q);       // gwnet.py:233
+          const f32x4 yv = {acc[mt][0] + bias4.x + res.x, acc[mt][1] + bias4.y + res.y, acc[mt][2] + bias4.z + res.z,
+                            acc[mt][3] + bias4.w + res.w};
+          if (y != nullptr) *reinterpret_cast<f32x4*>(y + (orow0 + row) * C + 16 * w + 4 * q) = yv;
+          st1 += yv;
+          st2 += yv * yv;
         }
+      }
     }
   }
 
   HOPMI_STAMP(7);
   if (stats_part != nullptr) {
-    st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
-    st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
-    if (q == 0) {
-      stats_part[blockIdx.x * 2 * C + 16 * w + j] = st1;
-      stats_part[blockIdx.x * 2 * C + C + 16 * w + j] = st2;
+    // sum over the 16 rows j of the DPP row (xor 1, 2, 4, 8), fixed order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        st1[r] += __shfl_xor(st1[r], o);
+        st2[r] += __shfl_xor(st2[r], o);
+      }
+    }
+    if (j == 0) {
+      *reinterpret_cast<f32x4*>(stats_part + blockIdx.x * 2 * C + 16 * w + 4 * q) = st1;
+      *reinterpret_cast<f32x4*>(stats_part + blockIdx.x * 2 * C + C + 16 * w + 4 * q) = st2;
     }
   }
 }
