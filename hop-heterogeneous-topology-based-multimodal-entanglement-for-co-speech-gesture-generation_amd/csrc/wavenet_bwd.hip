@@ -423,24 +423,46 @@ __global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restr
                                                             float* __restrict__ dA1, float* __restrict__ dA2,
                                                             float* __restrict__ dgamma_prev, float* __restrict__ dbeta_prev,
                                                             float* __restrict__ coef_prev) {
+  // A workgroup owns 64 consecutive columns of the partial layout; its 4 thread groups add the workgroup partials
+  // b = grp (mod 4) in increasing order (8 loads in flight each), the 4 group sums are then added in a fixed order:
+  // bitwise reproducible.  All section boundaries of the layout that matter here are multiples of 64.
+  __shared__ float red[2][4][64];
+  __shared__ float dred[256];
   const int psz = part_floats(V);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= psz) return;
-  auto colsum = [&](int idx) {
-    float s = 0.f;
-    for (int b0 = 0; b0 < nblk; b0 += 8) {
-      float v[8];
+  const int tid = threadIdx.x, lc = tid & 63, grp = tid >> 6;
+  const int col0 = blockIdx.x * 64, col = col0 + lc;
+  const bool is_dwt = col0 < PO_DBT;                 // dW_tcn block: 64 input channels c of one (k, o)
+  const bool is_st = col0 == PO_ST;                  // S1 block: the same threads also need S2 (next 64 columns)
+  float s = 0.f, s2 = 0.f;
+  for (int b0 = grp; b0 < nblk; b0 += 32) {
+    float v[8], v2[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (b0 + u < nblk) ? part[(size_t)(b0 + u) * psz + idx] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 4 * u;
+      const bool ok = b < nblk && col < psz;
+      v[u] = ok ? part[(size_t)b * psz + col] : 0.f;
+      v2[u] = (ok && is_st) ? part[(size_t)b * psz + col + C] : 0.f;
     }
-    return s;
-  };
-  const float s = colsum(i);
-  if (i < PO_DBT) {                                  // dW_tcn element (4, o, c)
-    const int c = i & 63, go = (i >> 6) & 63, k = i >> 12;            // k = 2*tap + gate
-    const float dbt = colsum(PO_DBT + (k & 1) * C + go);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += v[u]; s2 += v2[u]; }
+  }
+  red[0][grp][lc] = s;
+  red[1][grp][lc] = s2;
+  if (is_dwt) {                                      // sum of db_tcn[gate][o] over the workgroup partials, one per thread
+    const int go = (col0 >> 6) & 63, k = col0 >> 12;
+    const int idx = PO_DBT + (k & 1) * C + go;
+    float x = 0.f;
+    for (int b = tid; b < nblk; b += 256) x += part[(size_t)b * psz + idx];
+    dred[tid] = x;
+  }
+  __syncthreads();
+  if (tid >= 64 || col >= psz) return;
+  const int i = col;
+  s = ((red[0][0][lc] + red[0][1][lc]) + red[0][2][lc]) + red[0][3][lc];
+  if (i < PO_DBT) {                                  // dW_tcn element (k = 2*tap + gate, o, c)
+    float dbt = 0.f;
+    for (int t = 0; t < 256; ++t) dbt += dred[t];
+    const int c = i & 63;
     dwtcn[i] = scsh_in[c] * s + scsh_in[C + c] * dbt;
   } else if (i < PO_DWM) {
     dbtcn[i - PO_DBT] = s;
@@ -450,8 +472,8 @@ __global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restr
     if (dbm != nullptr) dbm[i - PO_DBM] = s;
   } else if (i < PO_DA) {
     const int c = i - PO_ST;
-    if (c < C && gamma_prev != nullptr) {            // thread c: S1 (this element) and S2
-      const float S1 = s, S2 = colsum(PO_ST + C + c);
+    if (c < C && gamma_prev != nullptr) {            // thread c: S1 (this column) and S2
+      const float S1 = s, S2 = ((red[1][0][lc] + red[1][1][lc]) + red[1][2][lc]) + red[1][3][lc];
       const float mean = mean_rstd_prev[c], rstd = mean_rstd_prev[C + c], gam = gamma_prev[c];
       const float dgam = rstd * (S2 - mean * S1);
       dgamma_prev[c] = dgam;
@@ -468,6 +490,9 @@ __global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restr
     if (dA2 != nullptr) dA2[i - PO_DA - V * V] = s;
   }
 }
+
+static_assert(PO_DBT % 64 == 0 && PO_DWM % 64 == 0 && PO_DBM % 64 == 0 && PO_ST % 64 == 0 && PO_DA % 64 == 0,
+              "wn_bwd_reduce_kernel: 64-column workgroup blocks must not straddle sections that need special handling");
 
 constexpr size_t WNB_LDS_LIMIT = 160 * 1024;        // LDS per CU on gfx950
 
@@ -542,7 +567,7 @@ extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const 
   }
   if (int e = check_launch("hopmi_wn_layer_bwd")) return e;
   const int psz = part_floats(V);
-  hipLaunchKernelGGL(wn_bwd_reduce_kernel, dim3((psz + 255) / 256), dim3(256), 0, st, ws, grid, V, scsh_in, gamma_prev,
+  hipLaunchKernelGGL(wn_bwd_reduce_kernel, dim3((psz + 63) / 64), dim3(256), 0, st, ws, grid, V, scsh_in, gamma_prev,
                      mean_rstd_prev, (double)B * T_in * V, dwtcn, dbtcn, dWm, dbm, dA1, dA2, dgamma_prev, dbeta_prev, coef_prev);
   return check_launch("hopmi_wn_bwd_reduce");
 }

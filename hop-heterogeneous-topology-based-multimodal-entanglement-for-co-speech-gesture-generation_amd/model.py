@@ -70,6 +70,29 @@ class WavEncoder(nn.Module):
         return x.transpose(1, 2)
 
 
+class _SplitKAffine(torch.autograd.Function):
+    """S = W @ E + b[:, None] with the huge reduction dimension (vocab) split `ks` ways as one strided batched GEMM
+    on views of W and E (no copies) and the partial products added in a fixed order.  The backward is the plain
+    dW = dS @ E^T (its reduction dimension is the small one) written straight in W's layout, which avoids the 183 MB
+    re-layout copy autograd's view/bmm backward would make."""
+
+    @staticmethod
+    def forward(ctx, W, E, b, ks):
+        kc = W.shape[1] // ks
+        S = torch.bmm(W.view(W.shape[0], ks, kc).transpose(0, 1), E.view(ks, kc, E.shape[1])).sum(0)
+        S += b.unsqueeze(1)
+        ctx.save_for_backward(W, E)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        W, E = ctx.saved_tensors
+        dW = dS @ E.t() if ctx.needs_input_grad[0] else None
+        dE = W.t() @ dS if ctx.needs_input_grad[1] else None
+        db = dS.sum(1) if ctx.needs_input_grad[2] else None
+        return dW, dE, db, None
+
+
 class ReprogrammingLayer(nn.Module):
     """HOP.py:255-299: audio(mel)->text-prototype cross-attention, ReLU, out-projection."""
 
@@ -187,9 +210,7 @@ class Model(nn.Module):
             # (fp32 only: the bf16 strided-batched GEMM backward of these views faults inside the BLAS library, and a
             # bf16 GEMM of this size does not need the split)
             if ks > 1 and W.is_cuda and not torch.is_autocast_enabled():
-                kc = self.vocab_size // ks
-                part = torch.bmm(W.view(W.shape[0], ks, kc).transpose(0, 1), E.view(ks, kc, E.shape[1]))
-                S = part.sum(0) + self.mapping_layer.bias.unsqueeze(1)
+                S = _SplitKAffine.apply(W, E, self.mapping_layer.bias, ks)
             else:
                 S = torch.addmm(self.mapping_layer.bias.unsqueeze(1), W, E)
             kv = self.reprogramming_layer.project_source(S, S)
