@@ -24,7 +24,10 @@ constexpr int GRU_BM = 32;     // batch rows per workgroup (2 MFMA row tiles)
 constexpr int GRU_NU = 16;     // hidden units per workgroup (one MFMA column tile per gate)
 constexpr int RED_LD = 49;     // LDS stride of the [32][48] partial tiles
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// gate non-linearities on the hardware exp / rcp (v_exp_f32, v_rcp_f32): absolute error ~1e-7, far inside the 1e-3 bar;
+// the libm expf / tanhf made the gate epilogue 30 % of a recurrence step (tools/probes/gru_stamps.py)
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
 
 // XCD-aware work mapping (speed only; any placement is correct).  Workgroups are dealt round-robin over
 // the 8 XCDs by linear id, and each XCD has a private 4 MiB L2.  A "slice" = (unit block jb, direction):
@@ -47,13 +50,13 @@ __device__ __forceinline__ GruWork gru_decode(int nJ, int nbb) {
 // Row r of the panel comes from src_of(r) (nullptr -> all-zero row).  One wave per row at a time,
 // lane l takes the float2 at k = 2l, 2l + 128, ...: every load instruction covers 512 contiguous bytes.
 // All loads of a wave's rows are issued before the first LDS store (one memory round trip).
-template <int MAXROWS_PER_WAVE, int MAXK2, typename SrcOf>
+template <int MAXROWS_PER_WAVE, int MAXK2, int NW = 4, typename SrcOf>
 __device__ __forceinline__ void stage_rows(float* dst, int ldk, int nrows, int K, int KP, SrcOf src_of, int w, int lane) {
-  // rows w, w+4, w+8, ... ; per row MAXK2 float2 slots per lane
+  // rows w, w+NW, w+2NW, ... (NW waves per workgroup); per row MAXK2 float2 slots per lane
   float2 v[MAXROWS_PER_WAVE][MAXK2];
 #pragma unroll
   for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
-    const int r = w + 4 * rr;
+    const int r = w + NW * rr;
     const float* src = src_of(min(r, nrows - 1));
     const bool row_ok = (r < nrows) && (src != nullptr);
     const float* sp = src ? src : dst;            // never dereferenced when !row_ok (clamped below)
@@ -68,7 +71,7 @@ __device__ __forceinline__ void stage_rows(float* dst, int ldk, int nrows, int K
   }
 #pragma unroll
   for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
-    const int r = w + 4 * rr;
+    const int r = w + NW * rr;
 #pragma unroll
     for (int c = 0; c < MAXK2; ++c) {
       const int k = 2 * lane + 128 * c;
@@ -99,6 +102,27 @@ __device__ __forceinline__ void panel_mfma(f32x4 (&acc)[2][NG], const float* As,
         acc[mt][g] = mfma16(a[mt].z, wv[g].z, acc[mt][g]);
         acc[mt][g] = mfma16(a[mt].w, wv[g].w, acc[mt][g]);
       }
+  }
+}
+
+// same for ONE 16-row tile: acc[g] += As[i][k] * Ws[16g + i][k] (As already points at the tile's first row)
+template <int NG>
+__device__ __forceinline__ void panel_mfma_1(f32x4 (&acc)[NG], const float* As, const float* Ws, int ldk, int c0, int nc, int q, int i) {
+  const float* ap = As + i * ldk + 4 * q;
+  const float* wp = Ws + i * ldk + 4 * q;
+#pragma unroll 3
+  for (int c = c0; c < c0 + nc; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
+    float4 wv[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const float4*>(wp + 16 * g * ldk + 16 * c);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc[g] = mfma16(a.x, wv[g].x, acc[g]);
+      acc[g] = mfma16(a.y, wv[g].y, acc[g]);
+      acc[g] = mfma16(a.z, wv[g].z, acc[g]);
+      acc[g] = mfma16(a.w, wv[g].w, acc[g]);
+    }
   }
 }
 
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
       }
       const float r = sigmoidf_(e_gi[pass][0] + gh[0]);
       const float z = sigmoidf_(e_gi[pass][1] + gh[1]);
-      const float n = tanhf(e_gi[pass][2] + r * gh[2]);
+      const float n = tanhf_(e_gi[pass][2] + r * gh[2]);
       const float hp = (s > 0) ? As[row * ldk + j] : 0.f;       // h_prev[b][j] is in the staged panel
       y[((size_t)b * T + t) * ystride + d * H + j] = (1.f - z) * n + z * hp;
       float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
@@ -300,12 +324,12 @@ __device__ __forceinline__ void st_sc1_f(float* p, float v) {
 }
 
 // stage `nrows` rows (row r from src_of(r), nullptr -> zeros) with sc1 8-B loads; same shape as stage_rows
-template <int MAXROWS_PER_WAVE, int MAXK2, typename SrcOf>
+template <int MAXROWS_PER_WAVE, int MAXK2, int NW = 4, typename SrcOf>
 __device__ __forceinline__ void stage_rows_sc1(float* dst, int ldk, int nrows, int K, int KP, SrcOf src_of, int w, int lane) {
   float2 v[MAXROWS_PER_WAVE][MAXK2];
 #pragma unroll
   for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
-    const int r = w + 4 * rr;
+    const int r = w + NW * rr;
     const float* src = src_of(min(r, nrows - 1));
     const bool row_ok = (r < nrows) && (src != nullptr);
 #pragma unroll
@@ -318,7 +342,7 @@ __device__ __forceinline__ void stage_rows_sc1(float* dst, int ldk, int nrows, i
   }
 #pragma unroll
   for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
-    const int r = w + 4 * rr;
+    const int r = w + NW * rr;
 #pragma unroll
     for (int c = 0; c < MAXK2; ++c) {
       const int k = 2 * lane + 128 * c;
@@ -326,6 +350,24 @@ __device__ __forceinline__ void stage_rows_sc1(float* dst, int ldk, int nrows, i
     }
   }
 }
+
+// Diagnostic build only (-DHOPMI_STAMPS, tools/probes/gru_stamps.py): s_memtime stamps of one mid-sequence step.
+#ifdef HOPMI_STAMPS
+static __device__ long long* g_gru_stamps = nullptr;
+#define GRU_STAMP(slot)                                                                          \
+  do {                                                                                           \
+    if (s == T / 2) {                                                                            \
+      unsigned long long t_;                                                                     \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+      if (g_gru_stamps && threadIdx.x == 0) g_gru_stamps[blockIdx.x * 8 + (slot)] = (long long)t_; \
+    }                                                                                            \
+  } while (0)
+extern "C" int hopmi_debug_set_stamps_gru(long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gru_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#else
+#define GRU_STAMP(slot) do { } while (0)
+#endif
 
 constexpr int GRU_SPIN_LIMIT = 1 << 23;            // ~8 s of polling before giving up (a peer rank's collective may hold CUs)
 
@@ -343,8 +385,10 @@ __device__ __forceinline__ bool gru_wait(const int* cnt, int want, int* status, 
   return *flag_lds != 0;
 }
 
+// 8 waves: wave w owns K quarter (w & 3) of batch-row tile (w >> 2), so a step's 144 MFMAs per SIMD become 72 and the
+// gate epilogue is one element per thread (tools/probes/gru_stamps.py: the MFMA phase was 37 % of a step).
 template <int MAXK2>
-__global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+__global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
                                                                  const float* __restrict__ bhh, float* y,
                                                                  float* __restrict__ gates, int* cnt, int* status, int B, int T,
                                                                  int H, int KP, int nJ, int nJp, int nbb) {
@@ -355,15 +399,17 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __
   const int ldk = KP + 4;
   float* As = smem;                                // [32][ldk]  h_prev rows
   float* Ws = As + GRU_BM * ldk;                   // [48][ldk]  resident W_hh slice
-  float* red = Ws + 3 * GRU_NU * ldk;              // [4][32][RED_LD]
+  float* red = Ws + 3 * GRU_NU * ldk;              // [4 K quarters][32][RED_LD]
   int* flag = reinterpret_cast<int*>(red + 4 * GRU_BM * RED_LD);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
+  const int kq = w & 3, mh = w >> 2;
   const int j0 = jb * GRU_NU, b0 = bb * GRU_BM;
   const size_t ystride = (size_t)2 * H;
   const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
+  const int row = tid >> 4, b = b0 + row, bc = min(b, B - 1);     // the thread's element in the gate epilogue
   int* gcnt = cnt + (size_t)group * T;
 
-  stage_rows<3 * GRU_NU / 4, MAXK2>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
+  stage_rows<3 * GRU_NU / 8, MAXK2, 8>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
     const int g = r >> 4, ju = j0 + (r & 15);
     return ju < H ? whh + ((size_t)(d * 3 + g) * H + ju) * H : nullptr;
   }, w, lane);
@@ -374,62 +420,59 @@ __global__ __launch_bounds__(256) void gru_fwd_persistent_kernel(const float* __
 
   for (int s = 0; s < T; ++s) {
     const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
-    float e_gi[2][3];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int bc = min(b0 + (tid >> 4) + 16 * pass, B - 1);
+    GRU_STAMP(0);
+    float e_gi[3];
+    {
       const float* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
 #pragma unroll
-      for (int g = 0; g < 3; ++g) e_gi[pass][g] = gip[g * H];
+      for (int g = 0; g < 3; ++g) e_gi[g] = gip[g * H];
     }
     if (s > 0) {
       if (!gru_wait(gcnt + (s - 1), nJ, status, flag)) return;     // h_{s-1} of this group complete
-      stage_rows_sc1<GRU_BM / 4, MAXK2>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
-        const int b = b0 + r;
-        return b < B ? y + ((size_t)b * T + tp) * ystride + d * H : nullptr;
+      GRU_STAMP(1);
+      stage_rows_sc1<GRU_BM / 8, MAXK2, 8>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
+        const int br = b0 + r;
+        return br < B ? y + ((size_t)br * T + tp) * ystride + d * H : nullptr;
       }, w, lane);
       __syncthreads();
-      f32x4 acc[2][3];
+      GRU_STAMP(2);
+      f32x4 acc[3];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int g = 0; g < 3; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+      panel_mfma_1<3>(acc, As + 16 * mh * ldk, Ws, ldk, kq * nc, nc, q, i);
+      GRU_STAMP(3);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[mt][g] = {0.f, 0.f, 0.f, 0.f};
-      panel_mfma<3>(acc, As, Ws, ldk, w * nc, nc, q, i);
+      for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) red[(w * GRU_BM + 16 * mt + 4 * q + r) * RED_LD + 16 * g + i] = acc[mt][g][r];
+        for (int r = 0; r < 4; ++r) red[(kq * GRU_BM + 16 * mh + 4 * q + r) * RED_LD + 16 * g + i] = acc[g][r];
       __syncthreads();
+      GRU_STAMP(4);
     }
+    if (b < B && j < H) {
+      float gh[3];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = (tid >> 4) + 16 * pass, b = b0 + row;
-      if (b < B && j < H) {
-        float gh[3];
+      for (int g = 0; g < 3; ++g) {
+        float v = e_bhh[g];
+        if (s > 0) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          float v = e_bhh[g];
-          if (s > 0) {
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) v += red[(ww * GRU_BM + row) * RED_LD + 16 * g + jj];
-          }
-          gh[g] = v;
+          for (int ww = 0; ww < 4; ++ww) v += red[(ww * GRU_BM + row) * RED_LD + 16 * g + jj];
         }
-        const float r = sigmoidf_(e_gi[pass][0] + gh[0]);
-        const float z = sigmoidf_(e_gi[pass][1] + gh[1]);
-        const float n = tanhf(e_gi[pass][2] + r * gh[2]);
-        const float hp = (s > 0) ? As[row * ldk + j] : 0.f;
-        st_sc1_f(y + ((size_t)b * T + t) * ystride + d * H + j, (1.f - z) * n + z * hp);      // handed off: write-through
-        float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
-        gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = gh[2];
+        gh[g] = v;
       }
+      const float r = sigmoidf_(e_gi[0] + gh[0]);
+      const float z = sigmoidf_(e_gi[1] + gh[1]);
+      const float n = tanhf_(e_gi[2] + r * gh[2]);
+      const float hp = (s > 0) ? As[row * ldk + j] : 0.f;
+      st_sc1_f(y + ((size_t)b * T + t) * ystride + d * H + j, (1.f - z) * n + z * hp);      // handed off: write-through
+      float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
+      gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = gh[2];
     }
+    GRU_STAMP(5);
     if (s + 1 < T) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
       __syncthreads();                                             // (also: As / red free for the next step)
       if (tid == 0) __hip_atomic_fetch_add(gcnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      GRU_STAMP(6);
     }
   }
 }
@@ -588,7 +631,7 @@ template <int MAXK2>
 static void launch_gru_fwd_persistent(int grid, size_t lds, hipStream_t st, const float* gi, const float* whh,
                                       const float* bhh, float* y, float* gates, int* cnt, int* status, int B, int T, int H,
                                       int KP, int nJ, int nJp, int nbb) {
-  hipLaunchKernelGGL(gru_fwd_persistent_kernel<MAXK2>, dim3(grid), dim3(256), lds, st, gi, whh, bhh, y, gates, cnt, status, B,
+  hipLaunchKernelGGL(gru_fwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, cnt, status, B,
                      T, H, KP, nJ, nJp, nbb);
 }
 
