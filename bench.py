@@ -185,8 +185,9 @@ def main():
                          "event_pair_overhead_us": 1e3 * gf["event_overhead_ms"],
                          "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
                          "f32_mfma_tflops": tfl, "f32_mfma_frac": tfl / F32_MFMA_PEAK_TFLOPS,
-                         "timing": "HIP events around each launch on the launch stream, inside the timed region; the median interval of "
-                                   "empty event pairs recorded in the same region is subtracted per launch"},
+                         "timing": "start/stop HIP events attached to each wn_layer_fwd dispatch (hipExtLaunchKernelGGL) on the launch "
+                                   "stream, inside the timed region; the other kernels' *_avg_us are event pairs minus the "
+                                   "smallest empty-pair interval"},
         }
         for name in ("wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "bert_attn_fwd", "bert_attn_bwd", "gru_fwd", "gru_bwd"):
             if name in ks and ks[name]["launches"]:

@@ -30,6 +30,7 @@ SIGNATURES = {
     "hopmi_reprog_attn_fwd": (_I, [_VP] * 5 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP]),
     "hopmi_reprog_attn_bwd_splits": (_I, []),
     "hopmi_reprog_attn_bwd": (_I, [_VP] * 9 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP]),
+    "hopmi_time_next_launch": (_I, [_VP, _VP]),
     "hopmi_bert_attn_fwd": (_I, [_VP] * 2 + [_I] * 3 + [ctypes.c_float, ctypes.c_uint, _VP]),
     "hopmi_bert_attn_bwd": (_I, [_VP] * 3 + [_I] * 3 + [ctypes.c_float, ctypes.c_uint, _VP]),
     "hopmi_bias_gelu_fwd": (_I, [_VP] * 3 + [_I, _I, _VP]),

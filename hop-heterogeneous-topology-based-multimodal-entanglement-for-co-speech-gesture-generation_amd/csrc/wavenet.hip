@@ -17,6 +17,8 @@
 // gate; node mix on MFMA; channel contraction on MFMA; epilogue adds bias + residual (from the R1 panel),
 // stores y and accumulates the BatchNorm partial sums.  A tiny second kernel turns the per-workgroup
 // partials into mean / rstd / running stats / the next layer's scale+shift in a fixed order (reproducible).
+#include <hip/hip_ext.h>
+
 #include "wn_dev.h"
 
 namespace hopmi {
@@ -317,18 +319,22 @@ static int wn_grid(const LayerGeom& L) {
   return L.g.ntiles < cap ? L.g.ntiles : cap;
 }
 
+static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;    // hopmi_time_next_launch
+
 template <int MT>
 static void launch_wn_fwd(const float* xin, const float* scsh, const float* wtcn, const float* btcn, const float* prep,
                           const float* Wm, const float* bm, float* y, float* fs, float* utail, int utail_ld, float* part,
                           const LayerGeom& L, int do_gcn, int grid, hipStream_t st) {
   const GcnGeom& g = L.g;
   const size_t lds = ((size_t)g.rows_lds * (2 * LDD + LDH) + (size_t)g.KP * g.ldA) * sizeof(float);
+  const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;      // null unless a measurement asked for this launch
+  t_ev_start = t_ev_stop = nullptr;
   if (g.ntiles > grid)
-    hipLaunchKernelGGL((wn_layer_fwd_kernel<MT, true>), dim3(grid), dim3(256), lds, st, xin, scsh, wtcn, btcn, prep, Wm, bm, y,
-                       fs, utail, part, L, do_gcn, utail_ld / 4);
+    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, true>), dim3(grid), dim3(256), lds, st, e0, e1, 0, xin, scsh, wtcn, btcn, prep,
+                          Wm, bm, y, fs, utail, part, L, do_gcn, utail_ld / 4);
   else
-    hipLaunchKernelGGL((wn_layer_fwd_kernel<MT, false>), dim3(grid), dim3(256), lds, st, xin, scsh, wtcn, btcn, prep, Wm, bm, y,
-                       fs, utail, part, L, do_gcn, utail_ld / 4);
+    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, false>), dim3(grid), dim3(256), lds, st, e0, e1, 0, xin, scsh, wtcn, btcn, prep,
+                          Wm, bm, y, fs, utail, part, L, do_gcn, utail_ld / 4);
 }
 
 }  // namespace hopmi
@@ -340,6 +346,13 @@ extern "C" int hopmi_debug_set_stamps_wn(long long* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+extern "C" int hopmi_time_next_launch(void* start_event, void* stop_event) {
+  if ((start_event == nullptr) != (stop_event == nullptr)) { set_error("hopmi_time_next_launch: need both events or none"); return HOPMI_EINVAL; }
+  t_ev_start = static_cast<hipEvent_t>(start_event);
+  t_ev_stop = static_cast<hipEvent_t>(stop_event);
+  return HOPMI_OK;
+}
 
 extern "C" size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation) {
   if (wn_validate(B, T_in, V, dilation)) return 0;

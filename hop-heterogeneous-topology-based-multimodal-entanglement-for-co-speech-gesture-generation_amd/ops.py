@@ -18,14 +18,27 @@ class KernelTimer:
     live.  Enable with `ops.TIMER = KernelTimer()`; read with `.summary()` after a synchronize.
 
     An event pair costs several microseconds of its own (the two marker packets), which matters for 10-20 us
-    kernels: every 8th timed launch is followed by an EMPTY pair (two records, nothing between) and the median empty
-    interval is reported as `event_overhead_ms`; `total_ms` is the raw sum, `kernel_ms` has launches x overhead
-    taken off (this is the figure that agrees with rocprofv3's kernel durations)."""
+    kernels: every 8th timed launch is followed by an EMPTY pair (two records, nothing between) and the SMALLEST empty
+    interval is reported as `event_overhead_ms` (a lower bound of the pair's cost, so the corrected kernel time is an
+    upper bound); `total_ms` is the raw sum, `kernel_ms` has launches x overhead taken off (this is the figure that
+    agrees with rocprofv3's kernel durations)."""
 
     def __init__(self):
         self.spans = {}
         self.empty = []
+        self.exact = set()
         self._n = 0
+
+    def launch_exact(self, name, nbytes, flops, fn):
+        """For entry points that support hopmi_time_next_launch: the events are recorded by the dispatch itself
+        (kernel begin / end), so there is no pair overhead to take off."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()                     # materialise the hipEvent_t handles
+        _lib.check(_lib.lib().hopmi_time_next_launch(e0.cuda_event, e1.cuda_event), "hopmi_time_next_launch")
+        rc = fn()
+        self.spans.setdefault(name, []).append((e0, e1, nbytes, flops))
+        self.exact.add(name)
+        return rc
 
     def launch(self, name, nbytes, flops, fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,20 +56,23 @@ class KernelTimer:
 
     def summary(self):
         gaps = sorted(a.elapsed_time(b) for a, b in self.empty)
-        over = gaps[len(gaps) // 2] if gaps else 0.0
+        over = gaps[0] if gaps else 0.0
         out = {}
         for name, spans in self.spans.items():
             ms = sum(a.elapsed_time(b) for a, b, _, _ in spans)
-            out[name] = dict(launches=len(spans), total_ms=ms, kernel_ms=max(ms - len(spans) * over, 0.0),
-                             event_overhead_ms=over, bytes=sum(s[2] for s in spans), flops=sum(s[3] for s in spans))
+            o = 0.0 if name in self.exact else over
+            out[name] = dict(launches=len(spans), total_ms=ms, kernel_ms=max(ms - len(spans) * o, 0.0),
+                             event_overhead_ms=o, bytes=sum(s[2] for s in spans), flops=sum(s[3] for s in spans))
         return out
 
 
 TIMER = None
 
 
-def _timed(name, nbytes, flops, fn):
-    return fn() if TIMER is None else TIMER.launch(name, nbytes, flops, fn)
+def _timed(name, nbytes, flops, fn, exact=False):
+    if TIMER is None:
+        return fn()
+    return TIMER.launch_exact(name, nbytes, flops, fn) if exact else TIMER.launch(name, nbytes, flops, fn)
 
 
 def gcn_algorithmic_bytes(n_slabs: int, V: int) -> int:
@@ -391,7 +407,7 @@ def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, wan
                       lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), wtcn.data_ptr(), btcn.data_ptr(),
                                                    _ptr(prep), _ptr(Wm), _ptr(bm), _ptr(y), _ptr(fs), utail.data_ptr(),
                                                    utail.stride(2), _ptr(ws), B, T_in, V, dilation,
-                                                   1 if do_gcn else 0, st)), "hopmi_wn_layer_fwd")
+                                                   1 if do_gcn else 0, st), exact=True), "hopmi_wn_layer_fwd")
     if bn is not None:
         _lib.check(L.hopmi_wn_bn_finalize(ws.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
                                           float(momentum), float(eps), scsh_out.data_ptr(), mean_rstd.data_ptr(),

@@ -37,6 +37,11 @@ extern "C" {
 const char* hopmi_version(void);
 const char* hopmi_last_error(void);
 
+/* Measurement hook: the next hopmi_wn_layer_fwd call of this host thread records the two hipEvent_t EXACTLY around its
+ * layer kernel (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps, what a profiler's
+ * kernel trace reports), then the hook clears itself.  Pass NULLs to clear.  bench.py uses it for the live roofline. */
+int hopmi_time_next_launch(void* start_event, void* stop_event);
+
 /* ---- graph convolution: model/gwnet.py:24-46 (gcn.forward) + :8-14 (nconv) + :16-22 (linear)
  *
  *   h = Wm . [x ; x A1 ; x A2] + bm        with A1 = adp, A2 = adp @ adp
