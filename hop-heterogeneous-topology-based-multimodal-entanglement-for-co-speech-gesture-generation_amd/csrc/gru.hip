@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __
 // Persistent BPTT: same structure; the workgroup keeps its 16 x 3H slice of W_hh^T in LDS (three gate blocks) and
 // hands dgh_t over (sc1 stores / sc1 loads + arrival counters); dgi, dhz stay private to the workgroup.
 template <int MAXK2>
-__global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+__global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ gates, const float* __restrict__ whhT,
                                                                  float* __restrict__ dgi, float* dgh, float* dhz, int* cnt,
                                                                  int* status, int B, int T, int H, int KP, int nJ, int nJp, int nbb) {
@@ -491,15 +491,17 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
   const int ldk = KP + 4;
   float* As = smem;                                // [32][ldk]      dgh rows of one gate block
   float* Ws = As + GRU_BM * ldk;                   // [3][16][ldk]   resident W_hh^T slice, one image per gate block
-  float* red = Ws + 3 * GRU_NU * ldk;              // [4][32][RED_LD]
+  float* red = Ws + 3 * GRU_NU * ldk;              // [4 K quarters][32][RED_LD]
   int* flag = reinterpret_cast<int*>(red + 4 * GRU_BM * RED_LD);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
+  const int kq = w & 3, mh = w >> 2;               // 8 waves: K quarter x batch-row tile, as in the forward kernel
   const int j0 = jb * GRU_NU, b0 = bb * GRU_BM;
   const int K = 3 * H;
   const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
+  const int row = tid >> 4, b = b0 + row, bc = min(b, B - 1);      // the thread's element in the epilogue
   int* gcnt = cnt + (size_t)group * T;
 
-  stage_rows<3 * GRU_NU / 4, MAXK2>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
+  stage_rows<3 * GRU_NU / 8, MAXK2, 8>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
     const int g = r >> 4, ju = j0 + (r & 15);
     return ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr;
   }, w, lane);
@@ -510,50 +512,43 @@ __global__ __launch_bounds__(256) void gru_bwd_persistent_kernel(const float* __
     const int tn = d ? t - 1 : t + 1, tp = d ? t + 1 : t - 1;
     const float* dhz_in = dhz + ((size_t)((s + 1) & 1) * 2 + d) * B * H;
     float* dhz_out = dhz + ((size_t)(s & 1) * 2 + d) * B * H;
-    float e_dy[2], e_dhz[2], e_g[2][4], e_hp[2];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int bc = min(b0 + (tid >> 4) + 16 * pass, B - 1);
-      e_dy[pass] = dy[((size_t)bc * T + t) * 2 * H + d * H + jc];
-      e_dhz[pass] = dhz_in[(size_t)bc * H + jc];                   // this workgroup's own write of the previous step
+    float e_dy, e_dhz, e_g[4], e_hp;
+    {
+      e_dy = dy[((size_t)bc * T + t) * 2 * H + d * H + jc];
+      e_dhz = dhz_in[(size_t)bc * H + jc];                         // this workgroup's own write of the previous step
       const float* gp = gates + (((size_t)bc * T + t) * 2 + d) * 4 * H + jc;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) e_g[pass][g] = gp[g * H];
+      for (int g = 0; g < 4; ++g) e_g[g] = gp[g * H];
       const int tpc = min(max(tp, 0), T - 1);
-      e_hp[pass] = y[((size_t)bc * T + tpc) * 2 * H + d * H + jc];
+      e_hp = y[((size_t)bc * T + tpc) * 2 * H + d * H + jc];
     }
     if (s > 0) {
       if (!gru_wait(gcnt + (s - 1), nJ, status, flag)) return;     // dgh of the previous BPTT step complete
-      f32x4 acc[2][1];
-      acc[0][0] = {0.f, 0.f, 0.f, 0.f};
-      acc[1][0] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[1];
+      acc[0] = {0.f, 0.f, 0.f, 0.f};
       for (int g = 0; g < 3; ++g) {
         if (g) __syncthreads();
-        stage_rows_sc1<GRU_BM / 4, MAXK2>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
-          const int b = b0 + r;
-          return b < B ? dgh + (((size_t)b * T + tn) * 2 + d) * K + g * H : nullptr;
+        stage_rows_sc1<GRU_BM / 8, MAXK2, 8>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
+          const int br = b0 + r;
+          return br < B ? dgh + (((size_t)br * T + tn) * 2 + d) * K + g * H : nullptr;
         }, w, lane);
         __syncthreads();
-        panel_mfma<1>(acc, As, Ws + g * GRU_NU * ldk, ldk, w * nc, nc, q, i);
+        panel_mfma_1<1>(acc, As + 16 * mh * ldk, Ws + g * GRU_NU * ldk, ldk, kq * nc, nc, q, i);
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(w * GRU_BM + 16 * mt + 4 * q + r) * RED_LD + i] = acc[mt][0][r];
+      for (int r = 0; r < 4; ++r) red[(kq * GRU_BM + 16 * mh + 4 * q + r) * RED_LD + i] = acc[0][r];
       __syncthreads();
     }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = (tid >> 4) + 16 * pass, b = b0 + row;
+    {
       if (b < B && j < H) {
-        float D = e_dy[pass];
+        float D = e_dy;
         if (s > 0) {
-          D += e_dhz[pass];
+          D += e_dhz;
 #pragma unroll
           for (int ww = 0; ww < 4; ++ww) D += red[(ww * GRU_BM + row) * RED_LD + jj];
         }
-        const float r = e_g[pass][0], z = e_g[pass][1], n = e_g[pass][2], hn = e_g[pass][3];
-        const float hp = (s < T - 1) ? e_hp[pass] : 0.f;
+        const float r = e_g[0], z = e_g[1], n = e_g[2], hn = e_g[3];
+        const float hp = (s < T - 1) ? e_hp : 0.f;
         const float dn = D * (1.f - z) * (1.f - n * n);
         const float dz = D * (hp - n) * z * (1.f - z);
         const float dr = dn * hn * r * (1.f - r);
@@ -679,7 +674,7 @@ template <int MAXK2>
 static void launch_gru_bwd_persistent(int grid, size_t lds, hipStream_t st, const float* dy, const float* y,
                                       const float* gates, const float* whhT, float* dgi, float* dgh, float* dhz, int* cnt,
                                       int* status, int B, int T, int H, int KP, int nJ, int nJp, int nbb) {
-  hipLaunchKernelGGL(gru_bwd_persistent_kernel<MAXK2>, dim3(grid), dim3(256), lds, st, dy, y, gates, whhT, dgi, dgh, dhz, cnt,
+  hipLaunchKernelGGL(gru_bwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, dy, y, gates, whhT, dgi, dgh, dhz, cnt,
                      status, B, T, H, KP, nJ, nJp, nbb);
 }
 
