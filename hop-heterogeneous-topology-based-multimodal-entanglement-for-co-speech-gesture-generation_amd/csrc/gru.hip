@@ -89,7 +89,6 @@ __device__ __forceinline__ void panel_mfma(f32x4 (&acc)[2][NG], const float* As,
                                            int c0, int nc, int q, int i) {
   const float* ap = As + i * ldk + 4 * q;          // A[i = row][k = 16c + 4q + e]
   const float* wp = Ws + i * ldk + 4 * q;          // B[k][j = unit]
-#pragma unroll 2
   for (int c = c0; c < c0 + nc; ++c) {
     float4 a[2], wv[NG];
 #pragma unroll
@@ -108,17 +107,23 @@ __device__ __forceinline__ void panel_mfma(f32x4 (&acc)[2][NG], const float* As,
   }
 }
 
-// same for ONE 16-row tile: acc[g] += As[i][k] * Ws[16g + i][k] (As already points at the tile's first row)
+// same for ONE 16-row tile: acc[g] += As[i][k] * Ws[16g + i][k] (As already points at the tile's first row).
+// The operand reads of chunk c+1 are issued before the MFMAs of chunk c (register double buffer): the trip count is
+// a runtime value, which the compiler would not unroll / pipeline by itself.
 template <int NG>
 __device__ __forceinline__ void panel_mfma_1(f32x4 (&acc)[NG], const float* As, const float* Ws, int ldk, int c0, int nc, int q, int i) {
-  const float* ap = As + i * ldk + 4 * q;
-  const float* wp = Ws + i * ldk + 4 * q;
-#pragma unroll 3
-  for (int c = c0; c < c0 + nc; ++c) {
-    const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
-    float4 wv[NG];
+  const float* ap = As + i * ldk + 4 * q + 16 * c0;
+  const float* wp = Ws + i * ldk + 4 * q + 16 * c0;
+  float4 a = *reinterpret_cast<const float4*>(ap);
+  float4 wv[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const float4*>(wp + 16 * g * ldk + 16 * c);
+  for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const float4*>(wp + 16 * g * ldk);
+  for (int cc = 0; cc < nc; ++cc) {
+    const int cn = 16 * min(cc + 1, nc - 1);         // (the last iteration re-reads its own chunk: harmless)
+    const float4 an = *reinterpret_cast<const float4*>(ap + cn);
+    float4 wn[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wn[g] = *reinterpret_cast<const float4*>(wp + 16 * g * ldk + cn);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       acc[g] = mfma16(a.x, wv[g].x, acc[g]);
@@ -126,6 +131,9 @@ __device__ __forceinline__ void panel_mfma_1(f32x4 (&acc)[NG], const float* As, 
       acc[g] = mfma16(a.z, wv[g].z, acc[g]);
       acc[g] = mfma16(a.w, wv[g].w, acc[g]);
     }
+    a = an;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wv[g] = wn[g];
   }
 }
 
