@@ -118,3 +118,22 @@ def test_trimodal_api_matches_reference_golden(golden):
     sd = gen.state_dict()
     for n, want in zip(g["g_names"], g["g_cs"]):
         assert checksum_close(checksum(sd[str(n)]), want, 2e-4, 2.5e-3 * sd[str(n)].numel() if "bias" in str(n) else 1e-4), n
+
+
+def test_host_switches_without_a_device():
+    """Host-side switches of the package behave on a machine without a GPU: the GEMM table is not enabled, the
+    precision switch validates its argument and round-trips, and the shipped table is a TunableOp file for gfx950."""
+    import hopmi
+    from hopmi import tuning
+    if not torch.cuda.is_available():
+        assert hopmi.use_tuned_gemms() is False
+    assert os.path.isfile(tuning.DEFAULT_TABLE)
+    head = open(tuning.DEFAULT_TABLE).read(400)
+    assert "Validator,GCN_ARCH_NAME,gfx950" in head and "Validator,PT_VERSION" in head
+    prev = hopmi.mixed_precision("bf16")
+    try:
+        assert hopmi.mixed_precision(None) == "bf16"
+        with pytest.raises(ValueError):
+            hopmi.mixed_precision("fp8")
+    finally:
+        hopmi.mixed_precision(prev)
