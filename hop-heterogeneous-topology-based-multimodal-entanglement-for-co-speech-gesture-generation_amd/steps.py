@@ -14,7 +14,8 @@ fp32 master weights and optimizer.  The default is the reference's fp32 (run_ted
 What differs (numerics-preserving): the two generator forwards whose outputs
 the reference only ever uses detached run under `no_grad` (still in training mode), the
 batch-independent prototype branch is computed once per step, and the scalar losses are
-fetched with one device->host copy instead of up to five `.item()` syncs.
+fetched with one asynchronous device->host copy that is started before the generator backward is enqueued
+(`_LossFetch`) instead of up to five `.item()` syncs after it.
 """
 import contextlib
 
@@ -82,30 +83,51 @@ def _regularisers(args, outputs, z_context, z_mu, z_logvar, out_rand, z_rand):
     return div_reg, kld
 
 
-def _ret_dict(args, gan, huber, kld, div_reg, gen_error, dis_error):
-    """train_llm.py:88-98 with a single host sync.  `if kld:` / `if div_reg:` in the reference
-    are truthiness tests on the tensors: a term that is exactly 0.0 is left out."""
-    terms = [("loss", args.loss_regression_weight, huber)]
-    if kld is not None:
-        terms.append(("KLD", args.loss_kld_weight, kld))
-    if div_reg is not None:
-        terms.append(("DIV_REG", args.loss_reg_weight, div_reg))
-    if gan:
-        terms += [("gen", args.loss_gan_weight, gen_error), ("dis", 1.0, dis_error)]
-    stacked = [t.detach().float() for _, _, t in terms]
-    status = _ops.deferred_status() if stacked[0].is_cuda else None     # persistent-kernel hand-off status words
-    if status is not None:
-        stacked.append(status.to(stacked[0].device))
-    vals = torch.stack(stacked).cpu().tolist()
-    if status is not None and vals.pop() != 0.0:
-        raise RuntimeError("hopmi: a persistent GRU kernel timed out waiting for a hand-off during this step; "
-                           "set HOPMI_GRU_PERSISTENT=0 to use per-time-step launches")
-    ret = {}
-    for (k, wgt, _), v in zip(terms, vals):
-        if k in ("KLD", "DIV_REG") and v == 0.0:
-            continue
-        ret[k] = wgt * v
-    return ret
+class _LossFetch:
+    """The step's single device->host transfer, started as soon as every loss term exists (i.e. BEFORE the generator
+    backward and the optimizer step are enqueued) into pinned memory, and waited for at the end of the step.  The
+    values are the same floats; the host just no longer waits for the backward / optimizer kernels before it returns,
+    so it issues the next step while the device finishes this one (the reference's `.item()` calls drain the device
+    up to five times per step, train_llm.py:88-96).  The status words of persistent GRU launches ride along: those of
+    this step's forwards and of the PREVIOUS step's backward, so a hand-off time-out surfaces at most one step late."""
+
+    def __init__(self, args, gan, huber, kld, div_reg, gen_error, dis_error):
+        terms = [("loss", args.loss_regression_weight, huber)]
+        if kld is not None:
+            terms.append(("KLD", args.loss_kld_weight, kld))
+        if div_reg is not None:
+            terms.append(("DIV_REG", args.loss_reg_weight, div_reg))
+        if gan:
+            terms += [("gen", args.loss_gan_weight, gen_error), ("dis", 1.0, dis_error)]
+        self.terms = terms
+        stacked = [t.detach().float().reshape(()) for _, _, t in terms]
+        self.status = _ops.deferred_status() if stacked[0].is_cuda else None    # persistent-kernel hand-off status words
+        if self.status is not None:
+            stacked.append(self.status.to(stacked[0].device))
+        dev = torch.stack(stacked)
+        if dev.is_cuda:
+            self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+            self.host.copy_(dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host, self.event = dev, None
+
+    def result(self):
+        """train_llm.py:88-98.  `if kld:` / `if div_reg:` in the reference are truthiness tests on the tensors: a term
+        that is exactly 0.0 is left out."""
+        if self.event is not None:
+            self.event.synchronize()
+        vals = self.host.tolist()
+        if self.status is not None and vals.pop() != 0.0:
+            raise RuntimeError("hopmi: a persistent GRU kernel timed out waiting for a hand-off; "
+                               "set HOPMI_GRU_PERSISTENT=0 to use per-time-step launches")
+        ret = {}
+        for (k, wgt, _), v in zip(self.terms, vals):
+            if k in ("KLD", "DIV_REG") and v == 0.0:
+                continue
+            ret[k] = wgt * v
+        return ret
 
 
 def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,
@@ -148,9 +170,10 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
                 loss = huber_loss * args.loss_regression_weight
             if epoch > 10:                                                     # literal gate, train_llm.py:81
                 loss = loss + gen_error * args.loss_gan_weight
+        fetch = _LossFetch(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)
         accelerator.backward(loss)
         model_optim.step()
-    return _ret_dict(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)
+    return fetch.result()
 
 
 def train_iter_gan(args, epoch, in_text, in_audio, target_poses, vid_indices,
@@ -192,6 +215,7 @@ def train_iter_gan(args, epoch, in_text, in_audio, target_poses, vid_indices,
         loss = args.loss_regression_weight * huber_loss
     if epoch > warm_up_epochs:
         loss = loss + args.loss_gan_weight * gen_error
+    fetch = _LossFetch(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)
     loss.backward()
     pose_dec_optim.step()
-    return _ret_dict(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)
+    return fetch.result()

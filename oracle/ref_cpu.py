@@ -134,10 +134,13 @@ def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True, relu_masks=None) ->
 
 # ----------------------------------------------------------- reprogramming cross-attention
 def reprogramming_layer(sd: SD, target, source, value, n_heads, prefix="reprogramming_layer.",
-                        drop_mask: Optional[torch.Tensor] = None, p_drop: float = 0.0):
+                        drop_mask: Optional[torch.Tensor] = None, p_drop: float = 0.0,
+                        relu_mask: Optional[torch.Tensor] = None):
     """HOP.py:271-299.  target (B,L,d_model); source/value (S,d_llm) -> (B,L,d_llm).
 
-    `drop_mask` (B,H,L,S) of {0,1} reproduces nn.Dropout(p_drop) on the probabilities.
+    `drop_mask` (B,H,L,S) of {0,1} reproduces nn.Dropout(p_drop) on the probabilities.  `relu_mask` (B,L,H*E) of
+    {0,1} evaluates the ReLU of HOP.py:284 as `x * mask` (gradient checks with millions of pre-activations must not
+    depend on which side of zero rounding puts the few values within 1e-7 of the kink).
     """
     p = lambda n: sd[prefix + n]
     B, L, _ = target.shape
@@ -151,7 +154,8 @@ def reprogramming_layer(sd: SD, target, source, value, n_heads, prefix="reprogra
     if drop_mask is not None:
         attn = attn * drop_mask / (1.0 - p_drop)
     out = torch.einsum("bhls,she->blhe", attn, v).reshape(B, L, -1)
-    return linear(torch.relu(out), p("out_projection.weight"), p("out_projection.bias"))   # ReLU *before* out-proj
+    act = torch.relu(out) if relu_mask is None else out * relu_mask.to(out.dtype)
+    return linear(act, p("out_projection.weight"), p("out_projection.bias"))               # ReLU *before* out-proj
 
 
 # ------------------------------------------------------------------------- frozen BERT
