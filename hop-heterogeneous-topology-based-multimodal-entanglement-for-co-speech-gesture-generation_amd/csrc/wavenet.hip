@@ -36,16 +36,20 @@ struct RowMap {
   bool ok[NIT];     // row < R
 };
 
-// weight slices of wave w (16 output channels), K permuted as k = 16i + 4q + e
-__device__ __forceinline__ void load_tcn_slices(float4 (&wt)[2][2][4], const float* __restrict__ wtcn, int w, int q, int j, int off) {
+// weight slices of wave w (16 output channels), K permuted as k = 16i + 4q + e, read straight from the Conv2d
+// layout [out][in][1][tap]: the 8 floats at (o*64 + c)*2 hold both taps of 4 consecutive input channels
+__device__ __forceinline__ void load_tcn_slices(float4 (&wt)[2][2][4], const float* __restrict__ wf, const float* __restrict__ wg,
+                                                int w, int q, int j, int off) {
 #pragma unroll
-  for (int gate = 0; gate < 2; ++gate)
+  for (int gate = 0; gate < 2; ++gate) {
+    const float4* wp = reinterpret_cast<const float4*>((gate ? wg : wf) + (size_t)((16 * w + j) * C + 4 * q) * 2 + off);
 #pragma unroll
-    for (int tap = 0; tap < 2; ++tap) {
-      const float4* wp = reinterpret_cast<const float4*>(wtcn + (size_t)((2 * tap + gate) * 64 + 16 * w + j) * C + 4 * q + off);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wt[gate][tap][i] = wp[4 * i];
+    for (int i = 0; i < 4; ++i) {
+      const float4 v0 = wp[8 * i], v1 = wp[8 * i + 1];             // (c0t0 c0t1 c1t0 c1t1) (c2t0 c2t1 c3t0 c3t1)
+      wt[gate][0][i] = make_float4(v0.x, v0.z, v1.x, v1.z);
+      wt[gate][1][i] = make_float4(v0.y, v0.w, v1.y, v1.w);
     }
+  }
 }
 
 __device__ __forceinline__ void load_wm_slice(float4 (&wreg)[12], const float* __restrict__ Wm, int w, int q, int j, int off) {
@@ -59,7 +63,8 @@ __device__ __forceinline__ void load_wm_slice(float4 (&wreg)[12], const float* _
 // slice after the TCN phase, which starts the activation stream earlier (8 % faster at V=9, B=128).
 template <int MT, bool HOIST>
 __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
-                                                           const float* __restrict__ wtcn, const float* __restrict__ btcn,
+                                                           const float* __restrict__ wf, const float* __restrict__ wg,
+                                                           const float* __restrict__ bfp, const float* __restrict__ bgp,
                                                            const float* __restrict__ prep, const float* __restrict__ Wm,
                                                            const float* __restrict__ bm, float* __restrict__ y,
                                                            float* __restrict__ fs, float* __restrict__ utail,
@@ -77,8 +82,8 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
 
   // MFMA products are taken transposed (D[i = channel][j = row]): a lane holds 4 consecutive channels
   // 16w + 4q + r of one row, so gate outputs, saved gates and y move as 16-byte LDS / global accesses
-  const float4 bf4 = *reinterpret_cast<const float4*>(btcn + 16 * w + 4 * q);
-  const float4 bg4 = *reinterpret_cast<const float4*>(btcn + C + 16 * w + 4 * q);
+  const float4 bf4 = *reinterpret_cast<const float4*>(bfp + 16 * w + 4 * q);
+  const float4 bg4 = *reinterpret_cast<const float4*>(bgp + 16 * w + 4 * q);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (do_gcn) {
     bias4 = *reinterpret_cast<const float4*>(bm + 16 * w + 4 * q);
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
   float4 wt[2][2][4];                              // [gate f/g][tap][i]
   float4 wreg[12];
   if (HOIST) {
-    load_tcn_slices(wt, wtcn, w, q, j, 0);
+    load_tcn_slices(wt, wf, wg, w, q, j, 0);
     if (do_gcn) load_wm_slice(wreg, Wm, w, q, j, 0);
   }
   const float4 sc4 = reinterpret_cast<const float4*>(scsh)[c4];
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void wn_layer_fwd_kernel(const float* __restri
     int woff = 0;
     if (!HOIST) {
       asm volatile("" : "+v"(woff));               // keeps the weight loads inside the tile loop
-      load_tcn_slices(wt, wtcn, w, q, j, woff);
+      load_tcn_slices(wt, wf, wg, w, q, j, woff);
     }
     HOPMI_STAMP(1);
     {
@@ -322,7 +327,8 @@ static int wn_grid(const LayerGeom& L) {
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;    // hopmi_time_next_launch
 
 template <int MT>
-static void launch_wn_fwd(const float* xin, const float* scsh, const float* wtcn, const float* btcn, const float* prep,
+static void launch_wn_fwd(const float* xin, const float* scsh, const float* wf, const float* wg, const float* bf,
+                          const float* bg, const float* prep,
                           const float* Wm, const float* bm, float* y, float* fs, float* utail, int utail_ld, float* part,
                           const LayerGeom& L, int do_gcn, int grid, hipStream_t st) {
   const GcnGeom& g = L.g;
@@ -330,10 +336,10 @@ static void launch_wn_fwd(const float* xin, const float* scsh, const float* wtcn
   const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;      // null unless a measurement asked for this launch
   t_ev_start = t_ev_stop = nullptr;
   if (g.ntiles > grid)
-    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, true>), dim3(grid), dim3(256), lds, st, e0, e1, 0, xin, scsh, wtcn, btcn, prep,
+    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, true>), dim3(grid), dim3(256), lds, st, e0, e1, 0, xin, scsh, wf, wg, bf, bg, prep,
                           Wm, bm, y, fs, utail, part, L, do_gcn, utail_ld / 4);
   else
-    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, false>), dim3(grid), dim3(256), lds, st, e0, e1, 0, xin, scsh, wtcn, btcn, prep,
+    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, false>), dim3(grid), dim3(256), lds, st, e0, e1, 0, xin, scsh, wf, wg, bf, bg, prep,
                           Wm, bm, y, fs, utail, part, L, do_gcn, utail_ld / 4);
 }
 
@@ -360,11 +366,11 @@ extern "C" size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation)
   return (size_t)wn_grid(L) * 2 * C;
 }
 
-extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn, const float* btcn,
-                                  const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
+extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wf, const float* wg,
+                                  const float* bf, const float* bg, const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
                                   int utail_ld, float* ws, int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
   if (int e = wn_validate(B, T_in, V, dilation)) return e;
-  if (!xin || !scsh_in || !wtcn || !btcn || !utail) { set_error("hopmi_wn_layer_fwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (!xin || !scsh_in || !wf || !wg || !bf || !bg || !utail) { set_error("hopmi_wn_layer_fwd: null pointer argument"); return HOPMI_EINVAL; }
   if (utail_ld < C || (utail_ld & 3)) { set_error("hopmi_wn_layer_fwd: utail_ld=%d must be a multiple of 4 and >= 64", utail_ld); return HOPMI_EINVAL; }
   if (do_gcn && (!prep || !Wm || !bm)) { set_error("hopmi_wn_layer_fwd: do_gcn needs prep, Wm, bm"); return HOPMI_EINVAL; }
   const bool stats = ws != nullptr;
@@ -374,11 +380,11 @@ extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = stats ? ws : nullptr;
   switch (L.g.mtiles) {
-    case 1: launch_wn_fwd<1>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 2: launch_wn_fwd<2>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 3: launch_wn_fwd<3>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 4: launch_wn_fwd<4>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 5: launch_wn_fwd<5>(xin, scsh_in, wtcn, btcn, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 1: launch_wn_fwd<1>(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 2: launch_wn_fwd<2>(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 3: launch_wn_fwd<3>(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 4: launch_wn_fwd<4>(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 5: launch_wn_fwd<5>(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
     default: set_error("hopmi_wn_layer_fwd: internal: %d m-tiles", L.g.mtiles); return HOPMI_EINVAL;
   }
   return check_launch("hopmi_wn_layer_fwd");

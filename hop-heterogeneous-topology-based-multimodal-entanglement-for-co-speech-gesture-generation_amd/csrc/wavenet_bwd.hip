@@ -44,7 +44,7 @@ struct BwdRowMap {
 
 template <int MT>
 __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
-    const float* __restrict__ xin, const float* __restrict__ fs, const float* __restrict__ wtcn,
+    const float* __restrict__ xin, const float* __restrict__ fs, const float* __restrict__ wf, const float* __restrict__ wg,
     const float* __restrict__ prep, const float* __restrict__ Wm, const float* __restrict__ P0n,
     const float* __restrict__ P1n, const float* __restrict__ y, const float* __restrict__ bn_coef,
     const float* __restrict__ dutail, float* __restrict__ P0, float* __restrict__ P1, float* __restrict__ part,
@@ -310,11 +310,13 @@ __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
       const float* ga = DG + j * LDG + 4 * q;        // A[i = row][k = 16i + 4q + e], k in [0,128): da then dg
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        // B[k][n = c]: W[gate = i/4][o = 16(i%4) + 4q + e][c = 16w + j]
-        const float* w0 = wtcn + (size_t)((i >> 2) * C + 16 * (i & 3) + 4 * q) * C + 16 * w + j;          // tap 0
-        const float* w1 = w0 + (size_t)2 * C * C;                                                          // tap 1
-        const float4 b0 = make_float4(w0[0], w0[C], w0[2 * C], w0[3 * C]);
-        const float4 b1 = make_float4(w1[0], w1[C], w1[2 * C], w1[3 * C]);
+        // B[k][n = c]: W[gate = i/4][o = 16(i%4) + 4q + e][c = 16w + j], both taps of an element are adjacent in
+        // the Conv2d layout [out][in][1][tap]
+        const float* wp = ((i >> 2) ? wg : wf) + ((size_t)(16 * (i & 3) + 4 * q) * C + 16 * w + j) * 2;
+        const float2 t0 = *reinterpret_cast<const float2*>(wp), t1 = *reinterpret_cast<const float2*>(wp + 2 * C);
+        const float2 t2 = *reinterpret_cast<const float2*>(wp + 4 * C), t3 = *reinterpret_cast<const float2*>(wp + 6 * C);
+        const float4 b0 = make_float4(t0.x, t1.x, t2.x, t3.x);                                              // tap 0
+        const float4 b1 = make_float4(t0.y, t1.y, t2.y, t3.y);                                              // tap 1
         float4 a[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(ga + 16 * mt * LDG + 16 * i);
@@ -418,9 +420,10 @@ __global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ scsh_in,      // [128] of this layer's input
                                                             const float* __restrict__ gamma_prev,   // BN_{i-1} (nullable)
                                                             const float* __restrict__ mean_rstd_prev, double n_prev,
-                                                            float* __restrict__ dwtcn, float* __restrict__ dbtcn,
+                                                            float* __restrict__ dwf, float* __restrict__ dwg,
+                                                            float* __restrict__ dbtcn,
                                                             float* __restrict__ dWm, float* __restrict__ dbm,
-                                                            float* __restrict__ dA1, float* __restrict__ dA2,
+                                                            float* __restrict__ dA1, float* __restrict__ dA2, int acc_dA,
                                                             float* __restrict__ dgamma_prev, float* __restrict__ dbeta_prev,
                                                             float* __restrict__ coef_prev) {
   // A workgroup owns 64 consecutive columns of the partial layout; its 4 thread groups add the workgroup partials
@@ -462,8 +465,8 @@ __global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restr
   if (i < PO_DBT) {                                  // dW_tcn element (k = 2*tap + gate, o, c)
     float dbt = 0.f;
     for (int t = 0; t < 256; ++t) dbt += dred[t];
-    const int c = i & 63;
-    dwtcn[i] = scsh_in[c] * s + scsh_in[C + c] * dbt;
+    const int c = i & 63, o = (i >> 6) & 63, k = i >> 12;              // k = 2*tap + gate
+    ((k & 1) ? dwg : dwf)[(o * C + c) * 2 + (k >> 1)] = scsh_in[c] * s + scsh_in[C + c] * dbt;    // Conv2d layout
   } else if (i < PO_DWM) {
     dbtcn[i - PO_DBT] = s;
   } else if (i < PO_DBM) {
@@ -485,9 +488,9 @@ __global__ __launch_bounds__(256) void wn_bwd_reduce_kernel(const float* __restr
       coef_prev[2 * C + c] = -sc * S1 * inv_n + sc * mean * rstd * dgam * inv_n;   // ck
     }
   } else if (i < PO_DA + V * V) {
-    if (dA1 != nullptr) dA1[i - PO_DA] = s;
+    if (dA1 != nullptr) dA1[i - PO_DA] = acc_dA ? dA1[i - PO_DA] + s : s;
   } else {
-    if (dA2 != nullptr) dA2[i - PO_DA - V * V] = s;
+    if (dA2 != nullptr) dA2[i - PO_DA - V * V] = acc_dA ? dA2[i - PO_DA - V * V] + s : s;
   }
 }
 
@@ -506,13 +509,13 @@ static int wnb_grid(const LayerGeom& L) {
 }
 
 template <int MT>
-static void launch_wn_bwd(const float* xin, const float* fs, const float* wtcn, const float* prep, const float* Wm,
+static void launch_wn_bwd(const float* xin, const float* fs, const float* wf, const float* wg, const float* prep, const float* Wm,
                           const float* P0n, const float* P1n, const float* y, const float* coef, const float* dutail,
                           float* P0, float* P1, float* part, const LayerGeom& L, int do_gcn, int d_next, int T_next,
                           int dutail_ld, int grid, hipStream_t st) {
   const GcnGeom& g = L.g;
   const size_t lds = wnb_lds_bytes(g);
-  hipLaunchKernelGGL(wn_layer_bwd_kernel<MT>, dim3(grid), dim3(256), lds, st, xin, fs, wtcn, prep, Wm, P0n, P1n, y, coef,
+  hipLaunchKernelGGL(wn_layer_bwd_kernel<MT>, dim3(grid), dim3(256), lds, st, xin, fs, wf, wg, prep, Wm, P0n, P1n, y, coef,
                      dutail, P0, P1, part, L, do_gcn, d_next, T_next, dutail_ld / 4);
 }
 
@@ -527,15 +530,16 @@ extern "C" size_t hopmi_wn_layer_bwd_ws_floats(int B, int T_in, int V, int dilat
   return (size_t)wnb_grid(L) * part_floats(V);
 }
 
-extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wtcn,
+extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wf, const float* wg,
                                   const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
                                   const float* y, const float* bn_coef, const float* dutail, int dutail_ld,
                                   const float* gamma_prev, const float* mean_rstd_prev,
-                                  float* P0, float* P1, float* dwtcn, float* dbtcn, float* dWm, float* dbm, float* dA1,
-                                  float* dA2, float* dgamma_prev, float* dbeta_prev, float* coef_prev, float* ws,
+                                  float* P0, float* P1, float* dwf, float* dwg, float* dbtcn, float* dWm, float* dbm,
+                                  float* dA1, float* dA2, int accumulate_dA, float* dgamma_prev, float* dbeta_prev,
+                                  float* coef_prev, float* ws,
                                   int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
   if (int e = wn_validate(B, T_in, V, dilation)) return e;
-  if (!xin || !scsh_in || !fs || !wtcn || !dutail || !P0 || !P1 || !dwtcn || !dbtcn || !ws) {
+  if (!xin || !scsh_in || !fs || !wf || !wg || !dutail || !P0 || !P1 || !dwf || !dwg || !dbtcn || !ws) {
     set_error("hopmi_wn_layer_bwd: null pointer argument");
     return HOPMI_EINVAL;
   }
@@ -560,14 +564,15 @@ extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int T_next = T_out - d_next;
   switch (L.g.mtiles) {
-    case 1: launch_wn_bwd<1>(xin, fs, wtcn, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
-    case 2: launch_wn_bwd<2>(xin, fs, wtcn, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
-    case 3: launch_wn_bwd<3>(xin, fs, wtcn, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
+    case 1: launch_wn_bwd<1>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
+    case 2: launch_wn_bwd<2>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
+    case 3: launch_wn_bwd<3>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
     default: set_error("hopmi_wn_layer_bwd: internal: %d m-tiles", L.g.mtiles); return HOPMI_EINVAL;
   }
   if (int e = check_launch("hopmi_wn_layer_bwd")) return e;
   const int psz = part_floats(V);
   hipLaunchKernelGGL(wn_bwd_reduce_kernel, dim3((psz + 63) / 64), dim3(256), 0, st, ws, grid, V, scsh_in, gamma_prev,
-                     mean_rstd_prev, (double)B * T_in * V, dwtcn, dbtcn, dWm, dbm, dA1, dA2, dgamma_prev, dbeta_prev, coef_prev);
+                     mean_rstd_prev, (double)B * T_in * V, dwf, dwg, dbtcn, dWm, dbm, dA1, dA2, accumulate_dA, dgamma_prev, dbeta_prev,
+                     coef_prev);
   return check_launch("hopmi_wn_bwd_reduce");
 }

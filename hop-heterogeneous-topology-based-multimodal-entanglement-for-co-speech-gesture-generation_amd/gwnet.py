@@ -40,23 +40,22 @@ class _WaveNetStackFn(torch.autograd.Function):
         tails = torch.empty(B, 4, V, 64 * n, dtype=torch.float32, device=dev)
         scsh = _identity_scsh(dev)
         xin = x0.contiguous()
-        saved_x, saved_y, saved_fs, saved_scsh, saved_mr, saved_wtcn = [xin], [], [], [], [], []
+        saved_x, saved_y, saved_fs, saved_scsh, saved_mr = [xin], [], [], [], []
         for i, d in enumerate(DILATIONS):
             wf, bf, wg, bg = tcn[i]
-            wtcn = torch.stack([wf[:, :, 0, 0], wg[:, :, 0, 0], wf[:, :, 0, 1], wg[:, :, 0, 1]]).contiguous()
-            btcn = torch.cat([bf, bg])
             bn = bns[i]
             last = i == n - 1
             y, fs, scsh_out, mean_rstd = ops.wn_layer_fwd(
-                xin, scsh, wtcn, btcn, prep, mlp[i][0], mlp[i][1], tails[..., 64 * i:64 * (i + 1)], d,
+                xin, scsh, wf, wg, bf, bg, prep, mlp[i][0], mlp[i][1], tails[..., 64 * i:64 * (i + 1)], d,
                 want_y=not last, want_fs=True, do_gcn=True,
                 bn=(aff[i][0], aff[i][1], bn.running_mean, bn.running_var, bn.momentum, bn.eps), stats_keep=keep.items)
-            saved_fs.append(fs); saved_scsh.append(scsh); saved_wtcn.append(wtcn)
+            saved_fs.append(fs); saved_scsh.append(scsh)
             if not last:
                 saved_y.append(y); saved_mr.append(mean_rstd); saved_x.append(y)
                 scsh, xin = scsh_out, y
         ctx.n_x, ctx.n_y = len(saved_x), len(saved_y)
-        ctx.save_for_backward(prep, *saved_x, *saved_y, *saved_fs, *saved_scsh, *saved_mr, *saved_wtcn,
+        ctx.save_for_backward(prep, *saved_x, *saved_y, *saved_fs, *saved_scsh, *saved_mr,
+                              *[t[0] for t in tcn], *[t[2] for t in tcn],
                               *[m[0] for m in mlp], *[a[0] for a in aff])
         return tails
 
@@ -67,7 +66,8 @@ class _WaveNetStackFn(torch.autograd.Function):
         sv = list(ctx.saved_tensors)
         prep = sv.pop(0)
         take = lambda k: [sv.pop(0) for _ in range(k)]
-        xs, ys, fss, scshs, mrs, wtcns, Wms, gammas = take(n), take(n - 1), take(n), take(n), take(n - 1), take(n), take(n), take(n)
+        xs, ys, fss, scshs, mrs, wfs, wgs, Wms, gammas = (take(n), take(n - 1), take(n), take(n), take(n - 1), take(n), take(n),
+                                                          take(n), take(n))
         dtails = dtails.contiguous()
         V = xs[0].shape[2]
         dA1 = torch.zeros(V, V, dtype=torch.float32, device=dtails.device)
@@ -76,16 +76,13 @@ class _WaveNetStackFn(torch.autograd.Function):
         P0n = P1n = coef = None
         for i in range(n - 1, -1, -1):
             do_gcn = i < n - 1
-            r = ops.wn_layer_bwd(xs[i], scshs[i], fss[i], wtcns[i], prep if do_gcn else None, Wms[i] if do_gcn else None,
+            r = ops.wn_layer_bwd(xs[i], scshs[i], fss[i], wfs[i], wgs[i], prep if do_gcn else None, Wms[i] if do_gcn else None,
                                  P0n, P1n, DILATIONS[i + 1] if do_gcn else 1, ys[i] if do_gcn else None, coef,
                                  dtails[..., 64 * i:64 * (i + 1)], gammas[i - 1] if i > 0 else None,
-                                 mrs[i - 1] if i > 0 else None, DILATIONS[i], do_gcn=do_gcn)
-            dw = r["dwtcn"]
-            g_tcn[i] = (torch.stack([dw[0], dw[2]], -1).unsqueeze(2), r["dbtcn"][:64],
-                        torch.stack([dw[1], dw[3]], -1).unsqueeze(2), r["dbtcn"][64:])
+                                 mrs[i - 1] if i > 0 else None, DILATIONS[i], do_gcn=do_gcn, dA=(dA1, dA2))
+            g_tcn[i] = (r["dwf"], r["dbtcn"][:64], r["dwg"], r["dbtcn"][64:])       # already in the Conv2d layouts
             if do_gcn:
                 g_mlp[i] = (r["dWm"].view(64, 192, 1, 1), r["dbm"])
-                dA1 += r["dA1"]; dA2 += r["dA2"]
             if i > 0:
                 g_aff[i - 1] = (r["dgamma_prev"], r["dbeta_prev"])
             P0n, P1n, coef = r["P0"], r["P1"], r["coef_prev"]
@@ -227,13 +224,6 @@ class gwnet(nn.Module):
         scale = bn.weight * torch.rsqrt(var + bn.eps)
         return y * scale + (bn.bias - mean * scale)
 
-    def _packed_tcn(self, i):
-        """filter/gate Conv2d (1,2) weights of layer i as the fused kernel wants them:
-        [Wf tap0, Wg tap0, Wf tap1, Wg tap1] each (out, in), and [bf, bg]."""
-        wf, wg = self.filter_convs[i].weight, self.gate_convs[i].weight
-        wtcn = torch.stack([wf[:, :, 0, 0], wg[:, :, 0, 0], wf[:, :, 0, 1], wg[:, :, 0, 1]]).contiguous()
-        return wtcn, torch.cat([self.filter_convs[i].bias, self.gate_convs[i].bias])
-
     def _skip_tails_fused(self, x, prep):
         """The 8 WaveNet layers as 8 fused kernels (no autograd graph): x (B,T,V,64) start-conv output ->
         (B,4,V,8*64) gated activations of every layer's last 4 frames (all the skip path needs).
@@ -246,13 +236,13 @@ class gwnet(nn.Module):
         keep = self._bn_keep = _Keep()
         for i, d in enumerate(DILATIONS):
             bn = self.bn[i]
-            wtcn, btcn = self._packed_tcn(i)
+            fc, gc = self.filter_convs[i], self.gate_convs[i]
             mlp = self.gconv[i].mlp.mlp
             # the last layer's gcn/BN output is dead (gwnet.py:240); in training the reference still
             # advances bn[7]'s running statistics, which needs y_7's batch statistics.
             do_gcn = (i != last) or self.training
             bnargs = (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps) if self.training else None
-            y, _, scsh_out, _ = ops.wn_layer_fwd(xin, scsh, wtcn, btcn, prep, mlp.weight, mlp.bias,
+            y, _, scsh_out, _ = ops.wn_layer_fwd(xin, scsh, fc.weight, gc.weight, fc.bias, gc.bias, prep, mlp.weight, mlp.bias,
                                                  tails[..., 64 * i:64 * (i + 1)], d, want_y=(i != last),
                                                  do_gcn=do_gcn, bn=bnargs, stats_keep=keep.items)
             if i == last:

@@ -375,7 +375,14 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, want_y=True, want_fs=False,
+def _conv_w(w):
+    """Data pointer of a gated-TCN Conv2d weight (64, 64, 1, 2): the kernels read nn.Conv2d's own layout."""
+    if w.shape != (64, 64, 1, 2) or not w.is_contiguous() or w.dtype != torch.float32:
+        raise _lib.HopmiError(f"hopmi wn_layer: expected a contiguous float32 (64,64,1,2) Conv2d weight, got {tuple(w.shape)} {w.dtype}")
+    return w.data_ptr()
+
+
+def wn_layer_fwd(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, utail, dilation, *, want_y=True, want_fs=False,
                  do_gcn=True, bn=None, stats_keep=None):
     """One fused WaveNet layer (hopmi_wn_layer_fwd).  No autograd here: the differentiable wrapper is the
     stack-level Function.  xin (B,T_in,V,64) contiguous; utail: a (B,4,V,64) view whose last-dim stride
@@ -404,7 +411,7 @@ def wn_layer_fwd(xin, scsh_in, wtcn, btcn, prep, Wm, bm, utail, dilation, *, wan
     nbytes = 4 * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + n_out * 128 * (1 if want_fs else 0) + B * 4 * V * 64)
     flops = n_out * (2 * 2 * 2 * 64 * 64 + (2 * 192 * 64 + 4 * 64 * V if do_gcn else 0))
     _lib.check(_timed("wn_layer_fwd", nbytes, flops,
-                      lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), wtcn.data_ptr(), btcn.data_ptr(),
+                      lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), _conv_w(wf), _conv_w(wg), bf.data_ptr(), bg.data_ptr(),
                                                    _ptr(prep), _ptr(Wm), _ptr(bm), _ptr(y), _ptr(fs), utail.data_ptr(),
                                                    utail.stride(2), _ptr(ws), B, T_in, V, dilation,
                                                    1 if do_gcn else 0, st), exact=True), "hopmi_wn_layer_fwd")
@@ -434,17 +441,19 @@ def wn_bn_replay(kept, bn):
                                                B, T_in, V, dilation, _stream()), "hopmi_wn_bn_finalize")
 
 
-def wn_layer_bwd(xin, scsh_in, fs, wtcn, prep, Wm, P0n, P1n, d_next, y, bn_coef, dutail, gamma_prev, mean_rstd_prev,
-                 dilation, do_gcn=True):
+def wn_layer_bwd(xin, scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next, y, bn_coef, dutail, gamma_prev, mean_rstd_prev,
+                 dilation, do_gcn=True, dA=None):
     """Backward of one fused WaveNet layer (hopmi_wn_layer_bwd).  Returns a dict of the outputs the header
-    documents; entries that do not exist for this call (do_gcn=False, first layer) are None."""
+    documents; entries that do not exist for this call (do_gcn=False, first layer) are None.  `dA` = (dA1, dA2)
+    buffers to ACCUMULATE the adjacency gradients into (one pair for the whole stack) instead of fresh outputs."""
     B, T_in, V, _ = xin.shape
     T_out = T_in - dilation
     dev = xin.device
     new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-    out = dict(P0=new(B, T_out, V, 64), P1=new(B, T_out, V, 64), dwtcn=new(4, 64, 64), dbtcn=new(128),
+    out = dict(P0=new(B, T_out, V, 64), P1=new(B, T_out, V, 64), dwf=new(64, 64, 1, 2), dwg=new(64, 64, 1, 2), dbtcn=new(128),
                dWm=new(64, 192) if do_gcn else None, dbm=new(64) if do_gcn else None,
-               dA1=new(V, V) if do_gcn else None, dA2=new(V, V) if do_gcn else None,
+               dA1=(dA[0] if dA is not None else new(V, V)) if do_gcn else None,
+               dA2=(dA[1] if dA is not None else new(V, V)) if do_gcn else None,
                dgamma_prev=new(64) if gamma_prev is not None else None,
                dbeta_prev=new(64) if gamma_prev is not None else None,
                coef_prev=new(3, 64) if gamma_prev is not None else None)
@@ -455,13 +464,13 @@ def wn_layer_bwd(xin, scsh_in, fs, wtcn, prep, Wm, P0n, P1n, d_next, y, bn_coef,
     st = _stream()
     n_out = B * T_out * V
     _lib.check(_timed("wn_layer_bwd", 4 * (2 * B * T_in * V * 64 + n_out * 64 * 5 + n_out * 128), 0,
-                      lambda: L.hopmi_wn_layer_bwd(xin.data_ptr(), scsh_in.data_ptr(), fs.data_ptr(), wtcn.data_ptr(),
+                      lambda: L.hopmi_wn_layer_bwd(xin.data_ptr(), scsh_in.data_ptr(), fs.data_ptr(), _conv_w(wf), _conv_w(wg),
                                                    _ptr(prep), _ptr(Wm), _ptr(P0n), _ptr(P1n), int(d_next), _ptr(y),
                                                    _ptr(bn_coef), dutail.data_ptr(), dutail.stride(2), _ptr(gamma_prev),
                                                    _ptr(mean_rstd_prev), out["P0"].data_ptr(), out["P1"].data_ptr(),
-                                                   out["dwtcn"].data_ptr(), out["dbtcn"].data_ptr(), _ptr(out["dWm"]),
-                                                   _ptr(out["dbm"]), _ptr(out["dA1"]), _ptr(out["dA2"]),
-                                                   _ptr(out["dgamma_prev"]), _ptr(out["dbeta_prev"]), _ptr(out["coef_prev"]),
+                                                   out["dwf"].data_ptr(), out["dwg"].data_ptr(), out["dbtcn"].data_ptr(),
+                                                   _ptr(out["dWm"]), _ptr(out["dbm"]), _ptr(out["dA1"]), _ptr(out["dA2"]),
+                                                   1 if dA is not None else 0, _ptr(out["dgamma_prev"]), _ptr(out["dbeta_prev"]), _ptr(out["coef_prev"]),
                                                    ws.data_ptr(), B, T_in, V, dilation, 1 if do_gcn else 0, st)),
                "hopmi_wn_layer_bwd")
     return out

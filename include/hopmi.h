@@ -78,8 +78,8 @@ int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const floa
  *   xin      [B][T_in][V][64]  previous layer's PRE-BatchNorm output (or the start-conv output)
  *   scsh_in  [128]             scale[64], shift[64] applied to xin on load (previous layer's BatchNorm as
  *                              an affine map; ones / zeros for the first layer)
- *   wtcn     [4][64][64]       Wf tap0, Wg tap0, Wf tap1, Wg tap1, each [out][in]  (filter_convs / gate_convs
- *                              weight[:, :, 0, tap]);  btcn [128] = filter bias, gate bias
+ *   wf, wg   [64][64][1][2]    filter_convs[i].weight / gate_convs[i].weight exactly as nn.Conv2d holds them
+ *                              ([out][in][1][tap], tap 1 reads frame t + dilation);  bf, bg [64] their biases
  *   prep, Wm, bm               as hopmi_gcn_fwd (used when do_gcn)
  *   y        [B][T_out][V][64] gcn(u) + bm + r^[t+d], pre-BatchNorm (nullable; T_out = T_in - dilation)
  *   fs       [B][T_out][V][128] tanh and sigmoid gate values saved for the backward (nullable)
@@ -88,8 +88,8 @@ int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const floa
  *            (training-mode BatchNorm statistics, do_gcn only), to be finalised by hopmi_wn_bn_finalize.
  */
 size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation);
-int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wtcn, const float* btcn,
-                       const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
+int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wf, const float* wg, const float* bf,
+                       const float* bg, const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
                        int utail_ld, float* ws, int B, int T_in, int V, int dilation, int do_gcn, void* stream);
 
 /* BatchNorm2d training-mode finalisation (gwnet.py:237) from the partials of the layer call with the same
@@ -101,25 +101,27 @@ int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const float* beta,
                          int B, int T_in, int V, int dilation, void* stream);
 
 /* Backward of one fused WaveNet layer (autograd of gwnet.py:181-237), see csrc/wavenet_bwd.hip.
- *   xin, scsh_in, fs, wtcn, prep, Wm : as in / saved by the forward
+ *   xin, scsh_in, fs, wf, wg, prep, Wm : as in / saved by the forward
  *   P0n, P1n [B][T_out - d_next][V][64]: gradient w.r.t. this layer's BatchNorm output as written by the NEXT
  *            layer's backward (its tap-0 / tap-1 contributions), d_next = that layer's dilation   (do_gcn only)
  *   y, bn_coef [3][64]: this layer's pre-BN output and the dy = ca*dx^ + cb*y + ck coefficients that the next
  *            layer's backward call produced (coef_prev there)                                     (do_gcn only)
  *   dutail: gradient w.r.t. this layer's skip-tail block, rows of stride dutail_ld
  *   gamma_prev, mean_rstd_prev: BatchNorm_{i-1} (nullable for the first layer)
- * Outputs: P0, P1 [B][T_out][V][64] (for the previous layer / the start conv), dwtcn [4][64][64], dbtcn [128],
- *   dWm [64][192], dbm [64], dA1, dA2 [V][V] (do_gcn only), dgamma_prev, dbeta_prev [64], coef_prev [3][64].
+ * Outputs: P0, P1 [B][T_out][V][64] (for the previous layer / the start conv), dwf, dwg [64][64][1][2] (the conv
+ *   weights' own layout), dbtcn [128] = d(bf) | d(bg), dWm [64][192], dbm [64], dA1, dA2 [V][V] (do_gcn only;
+ *   accumulate_dA != 0 ADDS into them, so one pair of buffers collects all layers), dgamma_prev, dbeta_prev [64],
+ *   coef_prev [3][64].
  *   ws: hopmi_wn_layer_bwd_ws_floats(...) floats.  Two launches (layer kernel + fixed-order reduce).
  *   The kernel keeps five tile images and both mix images in LDS: V <= 42 (hopmi_wn_layer_bwd_ws_floats returns 0 and
  *   hopmi_wn_layer_bwd HOPMI_EINVAL for larger graphs; hopmi_gcn_bwd covers those). */
 size_t hopmi_wn_layer_bwd_ws_floats(int B, int T_in, int V, int dilation);
-int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wtcn,
+int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wf, const float* wg,
                        const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
                        const float* y, const float* bn_coef, const float* dutail, int dutail_ld,
                        const float* gamma_prev, const float* mean_rstd_prev,
-                       float* P0, float* P1, float* dwtcn, float* dbtcn, float* dWm, float* dbm, float* dA1,
-                       float* dA2, float* dgamma_prev, float* dbeta_prev, float* coef_prev, float* ws,
+                       float* P0, float* P1, float* dwf, float* dwg, float* dbtcn, float* dWm, float* dbm, float* dA1,
+                       float* dA2, int accumulate_dA, float* dgamma_prev, float* dbeta_prev, float* coef_prev, float* ws,
                        int B, int T_in, int V, int dilation, int do_gcn, void* stream);
 
 /* ---- reprogramming cross-attention: model/HOP.py:289-299 (ReprogrammingLayer.reprogramming)

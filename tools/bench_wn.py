@@ -35,8 +35,9 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(0)
     A = torch.softmax(torch.randn(a.V, a.V, generator=g), 1).to(dev)
     prep = ops.gcn_prepare(A, A @ A)
-    wtcn = (torch.randn(4, 64, 64, generator=g) / 11).to(dev)
-    btcn = torch.randn(128, generator=g).to(dev)
+    wf = (torch.randn(64, 64, 1, 2, generator=g) / 11).to(dev)
+    wg = (torch.randn(64, 64, 1, 2, generator=g) / 11).to(dev)
+    bf, bg = torch.randn(64, generator=g).to(dev), torch.randn(64, generator=g).to(dev)
     Wm = (torch.randn(64, 192, generator=g) / 14).to(dev)
     bm = torch.randn(64, generator=g).to(dev)
     scsh = torch.cat([torch.ones(64), torch.zeros(64)]).to(dev)
@@ -59,7 +60,7 @@ def main():
         tails = torch.empty(a.B, 4, a.V, 512, device=dev)
         ut = tails[..., 64 * li:64 * li + 64]
         ws = torch.empty(L.hopmi_wn_layer_ws_floats(a.B, T_in, a.V, d), device=dev)
-        fn = lambda: L.hopmi_wn_layer_fwd(x.data_ptr(), scsh.data_ptr(), wtcn.data_ptr(), btcn.data_ptr(), prep.data_ptr(),
+        fn = lambda: L.hopmi_wn_layer_fwd(x.data_ptr(), scsh.data_ptr(), wf.data_ptr(), wg.data_ptr(), bf.data_ptr(), bg.data_ptr(), prep.data_ptr(),
                                           Wm.data_ptr(), bm.data_ptr(), y.data_ptr(), fs.data_ptr() if a.saves else None,
                                           ut.data_ptr(), ut.stride(2), ws.data_ptr(), a.B, T_in, a.V, d, do_gcn, st)
         n_out = a.B * T_out * a.V

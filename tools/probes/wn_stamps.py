@@ -29,7 +29,7 @@ def main():
         x = torch.randn(B, T_in, V, 64, device=dev); y = torch.empty(B, T_out, V, 64, device=dev)
         fs = torch.empty(B, T_out, V, 128, device=dev); ut = torch.empty(B, 4, V, 64, device=dev)
         A = torch.softmax(torch.randn(V, V, device=dev), 1); A2 = A @ A
-        wt = torch.randn(4, 64, 64, device=dev) / 11; bt = torch.randn(128, device=dev)
+        wt = torch.randn(64, 64, 1, 2, device=dev) / 11; wt2 = torch.randn(64, 64, 1, 2, device=dev) / 11; bt = torch.randn(64, device=dev); bt2 = torch.randn(64, device=dev)
         W = torch.randn(64, 192, device=dev) / 14; b = torch.randn(64, device=dev)
         scsh = torch.cat([torch.ones(64), torch.zeros(64)]).to(dev)
         stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
@@ -37,7 +37,7 @@ def main():
         prep = torch.empty(L.hopmi_gcn_prep_floats(V), device=dev)
         assert L.hopmi_gcn_prepare(P(A), P(A2), P(prep), V, None) == 0
         ws = torch.empty(L.hopmi_wn_layer_ws_floats(B, T_in, V, d), device=dev)
-        args = [P(x), P(scsh), P(wt), P(bt), P(prep), P(W), P(b), P(y), P(fs), P(ut), 64, P(ws), B, T_in, V, d, 1, None]
+        args = [P(x), P(scsh), P(wt), P(wt2), P(bt), P(bt2), P(prep), P(W), P(b), P(y), P(fs), P(ut), 64, P(ws), B, T_in, V, d, 1, None]
         for _ in range(3):
             stamps.zero_(); assert L.hopmi_wn_layer_fwd(*args) == 0; torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
