@@ -278,7 +278,10 @@ def attn_keep_mask(seed: int, N: int, H: int, S: int, p_drop: float, device) -> 
     x = x ^ (x >> 13)
     x = (x * 0xC2B2AE35) & _M32
     x = x ^ (x >> 16)
-    return x >= int(p_drop * 4294967296.0)
+    # the kernels receive p_drop as a C float and form the threshold from that value: round the same way here (with
+    # the double 0.1 the thresholds differ by 7, i.e. one mask bit in ~6e8 elements)
+    p32 = float(torch.tensor(p_drop, dtype=torch.float32))
+    return x >= int(p32 * 4294967296.0)
 
 
 class _BertAttnFn(torch.autograd.Function):
