@@ -592,6 +592,67 @@ def test_train_llm_vs_reference_golden(golden, V, epoch, monkeypatch):
             assert checksum_close(checksum(sd[str(n)]), want, RTOL, atol), (n, checksum(sd[str(n)]), want)
 
 
+def test_train_llm_baseline_size_vs_oracle(monkeypatch):
+    """One full train_llm step at the BASELINE.json configs[1] size -- B = 128, TED, BERT-base geometry x 6 layers (so the
+    BERT attention kernel, the persistent GRU at 4 batch groups, 240-tile WaveNet launches and the split-K mapping
+    layer all run at the shapes bench.py times) -- against the oracle's step on the host: the returned loss dict, and
+    after the optimizer step the BatchNorm running statistics and the checksums of a few parameter tensors
+    (dropout off; the closed-form fills and the replayed CPU random stream make both sides see the same numbers)."""
+    import hopmi
+    from transformers import BertConfig, BertModel
+    from hopmi import steps
+    from oracle import fill, ref_cpu, spec
+    from oracle.golden_util import Accel, SynthTok, SynthVocab, checksum, checksum_close, hop_cfg, step_args
+    dev = _dev()
+    V, B, n_spk = 9, 128, 11
+    bcfg = BertConfig(num_hidden_layers=6, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=30522)
+    m = hopmi.Model(hop_cfg(V, bcfg.hidden_size), BertModel(bcfg), SynthTok(), SynthVocab(n_spk)).float()
+    m.reprogramming_layer.dropout.p = 0.0
+    fill.fill_state_(m)
+    d = hopmi.ConvDiscriminator(3 * V)
+    d.gru.dropout = 0.0
+    fill.fill_state_(d, salt=1)
+    m.to(dev).train(); d.to(dev).train()
+    m._randn_like = lambda t: torch.randn(t.shape).to(t.device)
+    monkeypatch.setattr(steps, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
+    monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    inp = fill.hot_path_inputs(B, V, bcfg.vocab_size, n_spk)
+    gin = {k: v.to(dev) for k, v in inp.items()}
+    torch.manual_seed(777)
+    ret = hopmi.train_llm(step_args(V), 0, gin["in_audio"], gin["log_melspec"], gin["text"], gin["target_dir_vec"],
+                          gin["vid_indices"], m, d, g_opt, d_opt, Accel())
+    # the oracle's step on the host
+    g_sd = spec.build_sd(spec.model_spec(V, bcfg, n_spk))
+    d_sd = spec.build_sd(spec.disc_spec(3 * V), salt=1)
+    for k, v in g_sd.items():
+        if v.is_floating_point() and not k.startswith("llm_model.") and k != "word_embeddings" and "running_" not in k:
+            v.requires_grad_(True)
+    for k, v in d_sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    og = torch.optim.Adam([v for v in g_sd.values() if v.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+    od = torch.optim.Adam([v for v in d_sd.values() if v.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+    torch.manual_seed(777)
+    rng = lambda kind, shape: torch.randperm(shape[0]) if kind == "perm" else torch.randn(shape)
+    want, *_ = ref_cpu.train_llm_step(step_args(V), hop_cfg(V, bcfg.hidden_size), 0, inp, g_sd, d_sd, og, od, rng,
+                                      bert_heads=bcfg.num_attention_heads)
+    assert sorted(ret.keys()) == sorted(want.keys())
+    for k in want:
+        tol = RTOL * max(abs(want[k]), 1e-6) if k != "DIV_REG" else 0.05 * abs(want[k]) + 1e-9     # ratio of two small L1 terms
+        assert abs(ret[k] - want[k]) <= tol, (k, ret[k], want[k])
+    sd = m.state_dict()
+    for i in range(8):                      # both forwards of the step advanced the statistics (one replayed, DESIGN.md 5)
+        assert_close(sd[f"gwnet.bn.{i}.running_mean"], g_sd[f"gwnet.bn.{i}.running_mean"], what=f"bn{i} rm")
+        assert_close(sd[f"gwnet.bn.{i}.running_var"], g_sd[f"gwnet.bn.{i}.running_var"], what=f"bn{i} rv")
+    # post-step parameters: Adam turns every gradient into a +-lr step, so near-zero gradients decide signs by rounding;
+    # a checksum over a big tensor tolerates that (1e-3 relative + a few sign flips of size 2 lr)
+    for n in ("mapping_layer.weight", "gru.weight_hh_l0", "beat.0.weight", "reprogramming_layer.out_projection.weight"):
+        a, b = checksum(sd[n]), checksum(g_sd[n].detach())
+        assert checksum_close(a, b, RTOL, 2e-3 * 64), (n, a, b)
+
+
 @pytest.mark.parametrize("V,epoch", [(9, 0), (42, 11)])
 def test_train_llm_bf16_mixed_precision_tracks_reference(golden, V, epoch, monkeypatch):
     """BASELINE.json configs 2 / 4 (bf16): library GEMMs under autocast, HIP kernels and losses in fp32.  The
