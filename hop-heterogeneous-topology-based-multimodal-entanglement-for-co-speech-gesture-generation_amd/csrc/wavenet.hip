@@ -279,15 +279,15 @@ __global__ __launch_bounds__(1024) void wn_bn_finalize_kernel(const float* __res
   __shared__ double red[8][2 * C];
   const int col = threadIdx.x & 127, chunk = threadIdx.x >> 7;
   double acc = 0.0;
-  for (int b0 = chunk; b0 < nblk; b0 += 64) {
-    float v[8];
+  for (int b0 = chunk; b0 < nblk; b0 += 256) {       // 32 loads in flight: one memory round trip for up to 256 partials
+    float v[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const int b = b0 + 8 * u;
-      v[u] = (b < nblk) ? part[(size_t)b * 2 * C + col] : 0.f;
+      v[u] = (b < nblk) ? part[(size_t)min(b, nblk - 1) * 2 * C + col] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    for (int u = 0; u < 32; ++u) acc += (double)v[u];
   }
   red[chunk][col] = acc;
   __syncthreads();
