@@ -714,6 +714,27 @@ def test_discriminator_vs_reference_golden(golden, P):
     assert_close(d.pre_conv[1].running_var, g["bn1_rv"], what="bn1 rv")
 
 
+def test_inference_prototype_cache_tracks_weights():
+    """No-grad forwards keep the weight-only prototype branch across calls; any in-place weight update must invalidate it."""
+    dev = _dev()
+    m, bcfg = _make_model(9, dev)
+    m.eval()
+    inp = _inputs(9, bcfg, dev)
+    args = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"][:, :16], inp["vid_indices"])
+    def fwd():                                       # (the speaker VAE samples in eval mode too: same draw every call)
+        torch.manual_seed(1)
+        return m(*args)[0]
+
+    with torch.no_grad():
+        a = fwd()
+        kv1 = m._kv_infer[1][0]
+        b = fwd()
+        assert m._kv_infer[1][0] is kv1 and torch.equal(a, b)            # reused
+        m.mapping_layer.weight.mul_(1.5)                                   # e.g. load_state_dict / an optimizer step
+        c = fwd()
+        assert m._kv_infer[1][0] is not kv1 and not torch.equal(a, c)     # recomputed
+
+
 def test_generate_long_matches_reference_loop():
     """test_checkpoint.py:395-472 restated on the host (per-window model call, numpy cross-fade of 4 frames, vstack)
     against hopmi.generate_long (device-side loop); the eval-mode forward itself is pinned by the *_eval goldens."""
