@@ -714,6 +714,30 @@ def test_discriminator_vs_reference_golden(golden, P):
     assert_close(d.pre_conv[1].running_var, g["bn1_rv"], what="bn1 rv")
 
 
+def test_generate_long_hipgraph_equals_eager():
+    """The captured hipGraph of the window forward replays the same kernels: bit-identical windows, and a weight update
+    re-captures (the prototype tensors are part of the capture)."""
+    import hopmi
+    dev = _dev()
+    m, bcfg = _make_model(9, dev)
+    m._randn_like = lambda t: torch.zeros_like(t)                 # capturable, deterministic speaker sample
+    W = 3
+    g = torch.Generator().manual_seed(4)
+    audio = torch.randn(W, 36267, generator=g).to(dev)
+    mel = torch.randn(W, 34, 128, generator=g).to(dev)
+    text = torch.randint(0, bcfg.vocab_size, (W, 34), generator=g).to(dev)
+    pre0 = (0.1 * torch.randn(1, 16, 27, generator=g)).to(dev)
+    vid = torch.tensor([3], device=dev)
+    eager = hopmi.generate_long(m, audio, mel, text, pre0, vid)
+    graphed = hopmi.generate_long(m, audio, mel, text, pre0, vid, use_graph=True)
+    assert torch.equal(eager, graphed)
+    with torch.no_grad():
+        m.mapping_layer.weight.mul_(1.25)
+    eager2 = hopmi.generate_long(m, audio, mel, text, pre0, vid)
+    graphed2 = hopmi.generate_long(m, audio, mel, text, pre0, vid, use_graph=True)
+    assert torch.equal(eager2, graphed2) and not torch.equal(eager, eager2)
+
+
 def test_inference_prototype_cache_tracks_weights():
     """No-grad forwards keep the weight-only prototype branch across calls; any in-place weight update must invalidate it."""
     dev = _dev()

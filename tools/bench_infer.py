@@ -35,3 +35,9 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 out = hopmi.generate_long(m, b["in_audio"], b["log_melspec"], b["text"], pre0, vid)
 torch.cuda.synchronize()
 print(f"generate_long {W} windows -> {tuple(out.shape)}: {(time.perf_counter() - t0) * 1e3:.1f} ms ({(time.perf_counter() - t0) / W * 1e3:.2f} ms per window)")
+
+hopmi.generate_long(m, b["in_audio"], b["log_melspec"], b["text"], pre0, vid, use_graph=True)      # capture
+torch.cuda.synchronize(); t0 = time.perf_counter()
+out = hopmi.generate_long(m, b["in_audio"], b["log_melspec"], b["text"], pre0, vid, use_graph=True)
+torch.cuda.synchronize()
+print(f"generate_long {W} windows, hipGraph window forward: {(time.perf_counter() - t0) * 1e3:.1f} ms ({(time.perf_counter() - t0) / W * 1e3:.2f} ms per window)")
