@@ -522,7 +522,7 @@ class _GruLayerFn(torch.autograd.Function):
                           lambda: L.hopmi_gru_fwd(gi.data_ptr(), whh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
                                                   gates.data_ptr(), ws.data_ptr(), B, T, H, st)), "hopmi_gru_fwd")
         _track_status(ws)
-        if GRU_CHECK_STATUS and int(ws[-16].item()) != 0:
+        if GRU_CHECK_STATUS and not torch.cuda.is_current_stream_capturing() and int(ws[-16].item()) != 0:
             raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out (status word set)")
         ctx.save_for_backward(y, gates, whh)
         return y
@@ -545,7 +545,7 @@ class _GruLayerFn(torch.autograd.Function):
                                                   dgi.data_ptr(), dgh.data_ptr(), ws.data_ptr(), ws2.data_ptr(), B, T, H, st)),
                    "hopmi_gru_bwd")
         _track_status(ws2)
-        if GRU_CHECK_STATUS and int(ws2[-16].item()) != 0:
+        if GRU_CHECK_STATUS and not torch.cuda.is_current_stream_capturing() and int(ws2[-16].item()) != 0:
             raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
         # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
         # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.

@@ -257,7 +257,7 @@ def test_gru_fwd_bwd_vs_oracle(B, T, I, H, L, persistent, monkeypatch):
     from hopmi import ops
     from oracle import fill, ref_cpu, spec
     dev = _dev()
-    ops.GRU_CHECK_STATUS = True          # raise if a persistent-kernel hand-off ever timed out
+    monkeypatch.setattr(ops, "GRU_CHECK_STATUS", True)     # raise if a persistent-kernel hand-off ever timed out
     sd = spec.build_sd(spec.gru_spec("", I, H, L), gains={"weight_hh": 2.0, "weight_ih": 2.0})
     x = fill.normal("gru.x", (B, T, I))
     gout = fill.uniform("gru.gout", (B, T, 2 * H))
