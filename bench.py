@@ -93,10 +93,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    dev = torch.device("cuda", local_rank)
+    # HOPMI_REHEARSE_ONE_GPU=1 (rehearsal on a single-GPU box only): every rank uses cuda:0 and the collectives go
+    # through gloo, so the multi-process plumbing (rendezvous, plan agreement, timing reduction) can be exercised
+    # without a second device; run it with HOPMI_GRU_PERSISTENT=0 (two persistent launches cannot share one GPU)
+    one_gpu = os.environ.get("HOPMI_REHEARSE_ONE_GPU") == "1"
+    dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)    # backend "nccl" is RCCL on ROCm
     elif args.rehearse_sync:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29534")
