@@ -17,6 +17,7 @@ _VP = ctypes.c_void_p
 SIGNATURES = {
     "hopmi_version": (ctypes.c_char_p, []),
     "hopmi_last_error": (ctypes.c_char_p, []),
+    "hopmi_reload_env": (None, []),
     "hopmi_gcn_prep_floats": (ctypes.c_size_t, [_I]),
     "hopmi_gcn_prepare": (_I, [_VP, _VP, _VP, _I, _VP]),
     "hopmi_gcn_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
@@ -27,16 +28,16 @@ SIGNATURES = {
     "hopmi_wn_bn_finalize": (_I, [_VP] * 5 + [ctypes.c_float, ctypes.c_float] + [_VP] * 2 + [_I] * 4 + [_VP]),
     "hopmi_wn_layer_bwd_ws_floats": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "hopmi_wn_layer_bwd": (_I, [_VP] * 9 + [_I] + [_VP] * 3 + [_I] + [_VP] * 11 + [_I] + [_VP] * 4 + [_I] * 5 + [_VP]),
-    "hopmi_reprog_attn_fwd": (_I, [_VP] * 5 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP]),
+    "hopmi_reprog_attn_fwd": (_I, [_VP] * 5 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_reprog_attn_bwd_splits": (_I, []),
-    "hopmi_reprog_attn_bwd": (_I, [_VP] * 9 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP]),
+    "hopmi_reprog_attn_bwd": (_I, [_VP] * 9 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_time_next_launch": (_I, [_VP, _VP]),
-    "hopmi_bert_attn_fwd": (_I, [_VP] * 2 + [_I] * 3 + [ctypes.c_float, ctypes.c_uint, _VP]),
-    "hopmi_bert_attn_bwd": (_I, [_VP] * 3 + [_I] * 3 + [ctypes.c_float, ctypes.c_uint, _VP]),
+    "hopmi_bert_attn_fwd": (_I, [_VP] * 2 + [_I] * 3 + [ctypes.c_float, ctypes.c_uint, _VP, _VP]),
+    "hopmi_bert_attn_bwd": (_I, [_VP] * 3 + [_I] * 3 + [ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_bias_gelu_fwd": (_I, [_VP] * 3 + [_I, _I, _VP]),
     "hopmi_bias_gelu_bwd": (_I, [_VP] * 4 + [_I, _I, _VP]),
-    "hopmi_bias_dropout_residual_layernorm_fwd": (_I, [_VP] * 3 + [_I] + [_VP] * 5 + [_I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP]),
-    "hopmi_bias_dropout_residual_layernorm_bwd": (_I, [_VP] * 6 + [_I, _I, ctypes.c_float, ctypes.c_uint, _VP]),
+    "hopmi_bias_dropout_residual_layernorm_fwd": (_I, [_VP] * 3 + [_I] + [_VP] * 5 + [_I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
+    "hopmi_bias_dropout_residual_layernorm_bwd": (_I, [_VP] * 6 + [_I, _I, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_gru_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_gru_fwd": (_I, [_VP] * 6 + [_I, _I, _I, _VP]),
     "hopmi_gru_bwd_ws_floats": (ctypes.c_size_t, [_I, _I]),

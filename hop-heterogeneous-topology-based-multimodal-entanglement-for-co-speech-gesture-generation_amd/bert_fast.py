@@ -55,7 +55,7 @@ class FrozenBertEncoder:
 
     def _seed(self):
         FrozenBertEncoder._calls += 1
-        return (torch.initial_seed() * 2246822519 + FrozenBertEncoder._calls * 3266489917) & 0xFFFFFFFF
+        return (ops.base_seed() * 2246822519 + FrozenBertEncoder._calls * 3266489917) & 0xFFFFFFFF
 
     def __call__(self, inputs_embeds):
         llm, cfg = self.llm, self.llm.config

@@ -1,6 +1,11 @@
 // libhopmi: version / error reporting shared by all entry points.
 #include "common.h"
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
 namespace hopmi {
 static thread_local char g_err[512] = "";
 
@@ -9,6 +14,32 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// Tuning knobs (HOPMI_WN_GRID, ...) are read from the environment ONCE per process and kept in a small table: a getenv
+// per launch showed up in host profiles of the training step.  hopmi_reload_env() forgets the table (probes that sweep
+// a knob inside one process call it after changing the variable).
+namespace {
+struct EnvSlot { const char* name; int value; };
+constexpr int kEnvSlots = 16;
+EnvSlot g_env[kEnvSlots];
+std::atomic<int> g_env_n{0};
+std::mutex g_env_mu;
+}  // namespace
+
+int env_int(const char* name, int dflt) {
+  const int n = g_env_n.load(std::memory_order_acquire);
+  for (int i = 0; i < n; ++i)
+    if (g_env[i].name == name || strcmp(g_env[i].name, name) == 0) return g_env[i].value < 0 ? dflt : g_env[i].value;
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  const char* e = getenv(name);
+  const int v = (e && *e) ? atoi(e) : -1;           // every knob is a non-negative integer; -1 = unset
+  const int m = g_env_n.load(std::memory_order_relaxed);
+  if (m < kEnvSlots) {
+    g_env[m] = EnvSlot{name, v};
+    g_env_n.store(m + 1, std::memory_order_release);
+  }
+  return v < 0 ? dflt : v;
 }
 
 int check_launch(const char* what) {
@@ -23,3 +54,7 @@ int check_launch(const char* what) {
 
 extern "C" const char* hopmi_version(void) { return "hopmi 0.1 (gfx950)"; }
 extern "C" const char* hopmi_last_error(void) { return hopmi::g_err; }
+extern "C" void hopmi_reload_env(void) {
+  std::lock_guard<std::mutex> lk(hopmi::g_env_mu);
+  hopmi::g_env_n.store(0, std::memory_order_release);
+}

@@ -31,7 +31,8 @@ constexpr int AKT = AKC / 16;      // key tiles per chunk
 __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                               const float* __restrict__ Vv, float* __restrict__ O,
                                                               float* __restrict__ lse, int N, int S, int H, float scale,
-                                                              unsigned drop_thresh, float drop_scale, unsigned seed) {
+                                                              unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;                                // [64][ALD]
   float* Vs = Ks + AKC * ALD;                      // [64][ALD]
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
                                                                  const float* __restrict__ Vv, const float* __restrict__ dO,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
                                                                  float* __restrict__ dQ, int N, int S, int H, float scale,
-                                                                 unsigned drop_thresh, float drop_scale, unsigned seed) {
+                                                                 unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
   float* Vs = Ks + AKC * ALD;
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* _
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   float* __restrict__ dKp, float* __restrict__ dVp, int N, int S,
                                                                   int H, int nsplit, float scale, unsigned drop_thresh,
-                                                                  float drop_scale, unsigned seed) {
+                                                                  float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   // workgroup = (key chunk of 64, head, row split): the query-row tiles t = split, split + nsplit, ... are
   // walked here and the partial dK / dV go to slab `split` of dKp / dVp ([nsplit][S][H][E]); the caller
   // adds the slabs in a fixed order.
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* _
 using namespace hopmi;
 
 extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
-                                     int N, int S, int H, int E, float scale, float p_drop, unsigned seed, void* stream) {
+                                     int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   if (!q || !k || !v || !o || !lse) { set_error("hopmi_reprog_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
   if (E != AE || N <= 0 || S <= 0 || H <= 0) {
     set_error("hopmi_reprog_attn_fwd: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", N, S, H, E);
@@ -440,7 +443,7 @@ extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float
   const int ntile = (N + ABM - 1) / ABM;
   const size_t lds = (size_t)(2 * AKC * ALD + 4 * 16 * APLD) * sizeof(float);
   hipLaunchKernelGGL(reprog_attn_fwd_kernel, dim3(ntile * H), dim3(256), lds, static_cast<hipStream_t>(stream), q, k, v, o,
-                     lse, N, S, H, scale, thresh, dscale, seed);
+                     lse, N, S, H, scale, thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_reprog_attn_fwd");
 }
 
@@ -450,7 +453,7 @@ extern "C" int hopmi_reprog_attn_bwd_splits(void) { return 8; }
 
 extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                                      const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
-                                     float scale, float p_drop, unsigned seed, void* stream) {
+                                     float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv) { set_error("hopmi_reprog_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
   if (E != AE || N <= 0 || S <= 0 || H <= 0) {
     set_error("hopmi_reprog_attn_bwd: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", N, S, H, E);
@@ -462,11 +465,11 @@ extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lds_q = (size_t)(2 * AKC * ALD + 4 * 16 * APLD) * sizeof(float);
   hipLaunchKernelGGL(reprog_attn_bwd_dq_kernel, dim3(((N + ABM - 1) / ABM) * H), dim3(256), lds_q, st, q, k, v, d_o, lse, delta,
-                     dq, N, S, H, scale, thresh, dscale, seed);
+                     dq, N, S, H, scale, thresh, dscale, seed, seed_dev);
   if (int e = check_launch("hopmi_reprog_attn_bwd(dq)")) return e;
   const int nsplit = hopmi_reprog_attn_bwd_splits();
   const size_t lds_kv = (size_t)(2 * KVR * ALD + 4 * 2 * 16 * KVPLD + 2 * KVR) * sizeof(float);
   hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel, dim3(((S + KVK - 1) / KVK) * H * nsplit), dim3(256), lds_kv, st, q, k, v, d_o,
-                     lse, delta, dk, dv, N, S, H, nsplit, scale, thresh, dscale, seed);
+                     lse, delta, dk, dv, N, S, H, nsplit, scale, thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_reprog_attn_bwd(dkv)");
 }

@@ -63,7 +63,8 @@ __device__ __forceinline__ void xt_product(f32x4 (&o)[4], const float* X, const 
 // dropped-out probabilities pass through a wave-private LDS tile to become an MFMA operand.  One barrier.
 template <int MT>
 __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int H,
-                                                                unsigned thresh, float dscale, unsigned seed) {
+                                                                unsigned thresh, float dscale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   constexpr int LP = 16 * MT, PLD = LP + 4, NT = 64 * MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const float* __r
 template <int MT>
 __global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 float* __restrict__ dqkv, int L, int H, unsigned thresh,
-                                                                float dscale, unsigned seed) {
+                                                                float dscale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   constexpr int LP = 16 * MT, PLD = LP + 4, NT = 64 * MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
@@ -287,7 +289,7 @@ static int bert_attn_validate(const char* what, int B, int L, int H, float p_dro
 
 using namespace hopmi;
 
-extern "C" int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, void* stream) {
+extern "C" int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   if (int e = bert_attn_validate("hopmi_bert_attn_fwd", B, L, H, p_drop)) return e;
   if (!qkv || !out) { set_error("hopmi_bert_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
   const int MT = (L + 15) / 16, LP = 16 * MT;
@@ -296,16 +298,16 @@ extern "C" int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, i
   const float dscale = 1.f / (1.f - p_drop);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (MT) {
-    case 1: hipLaunchKernelGGL(bert_attn_fwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
-    case 2: hipLaunchKernelGGL(bert_attn_fwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
-    case 3: hipLaunchKernelGGL(bert_attn_fwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
-    default: hipLaunchKernelGGL(bert_attn_fwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, out, L, H, thresh, dscale, seed); break;
+    case 1: hipLaunchKernelGGL(bert_attn_fwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
+    case 2: hipLaunchKernelGGL(bert_attn_fwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
+    case 3: hipLaunchKernelGGL(bert_attn_fwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
+    default: hipLaunchKernelGGL(bert_attn_fwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
   }
   return check_launch("hopmi_bert_attn_fwd");
 }
 
 extern "C" int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* dqkv, int B, int L, int H, float p_drop,
-                                   unsigned seed, void* stream) {
+                                   unsigned seed, const unsigned* seed_dev, void* stream) {
   if (int e = bert_attn_validate("hopmi_bert_attn_bwd", B, L, H, p_drop)) return e;
   if (!qkv || !d_out || !dqkv) { set_error("hopmi_bert_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
   const int MT = (L + 15) / 16, LP = 16 * MT;
@@ -314,10 +316,10 @@ extern "C" int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* 
   const float dscale = 1.f / (1.f - p_drop);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (MT) {
-    case 1: hipLaunchKernelGGL(bert_attn_bwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
-    case 2: hipLaunchKernelGGL(bert_attn_bwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
-    case 3: hipLaunchKernelGGL(bert_attn_bwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
-    default: hipLaunchKernelGGL(bert_attn_bwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed); break;
+    case 1: hipLaunchKernelGGL(bert_attn_bwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
+    case 2: hipLaunchKernelGGL(bert_attn_bwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
+    case 3: hipLaunchKernelGGL(bert_attn_bwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
+    default: hipLaunchKernelGGL(bert_attn_bwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
   }
   return check_launch("hopmi_bert_attn_bwd");
 }

@@ -25,6 +25,7 @@ constexpr int LDD = C + 4;        // same for a [rows][64] tile (68 = 4 mod 64)
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+int env_int(const char* name, int dflt);   // cached environment knob (api.hip)
 
 inline int ceil_to(int x, int m) { return (x + m - 1) / m * m; }
 

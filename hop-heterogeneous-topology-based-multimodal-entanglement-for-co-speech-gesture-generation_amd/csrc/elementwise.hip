@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const float* 
                                                                    const float* __restrict__ beta, float* __restrict__ out,
                                                                    float* __restrict__ xhat, float* __restrict__ rstd_out, int M,
                                                                    int D, int res_rows, float eps, unsigned drop_thresh,
-                                                                   float drop_scale, unsigned seed) {
+                                                                   float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const float* 
 __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
                                                                    const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                                    float* __restrict__ dx, float* __restrict__ dres, int M, int D,
-                                                                   unsigned drop_thresh, float drop_scale, unsigned seed) {
+                                                                   unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
@@ -185,8 +187,7 @@ extern "C" int hopmi_bias_gelu_bwd(const float* x, const float* bias, const floa
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const float* bias, const float* res, int res_rows,
                                                          const float* gamma, const float* beta, float* out, float* xhat,
-                                                         float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
-                                                         void* stream) {
+                                                         float* rstd, int M, int D, float eps, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_fwd")) return e;
   if (!x || !bias || !res || !gamma || !beta || !out) { set_error("hopmi_bias_dropout_residual_layernorm_fwd: null pointer argument"); return HOPMI_EINVAL; }
   if (D > 256 * LN_MAX4 || res_rows <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
@@ -196,19 +197,19 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const f
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, res,
-                     gamma, beta, out, xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed);
+                     gamma, beta, out, xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_bias_dropout_residual_layernorm_fwd");
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xhat, const float* rstd,
                                                          const float* gamma, float* dx, float* dres, int M, int D,
-                                                         float p_drop, unsigned seed, void* stream) {
+                                                         float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
   if (!dout || !xhat || !rstd || !gamma || !dx || !dres) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: null pointer argument"); return HOPMI_EINVAL; }
   if (D > 256 * LN_MAX4 || !(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: D=%d p_drop=%f", D, p_drop); return HOPMI_EINVAL; }
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dout, xhat, rstd,
-                     gamma, dx, dres, M, D, thresh, dscale, seed);
+                     gamma, dx, dres, M, D, thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_bias_dropout_residual_layernorm_bwd");
 }

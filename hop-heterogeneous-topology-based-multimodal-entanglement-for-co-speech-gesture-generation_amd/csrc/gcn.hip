@@ -331,10 +331,6 @@ __global__ __launch_bounds__(256) void gcn_bwd_reduce_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
 
 // Slabs per forward tile: trade MFMA-tile padding against having >= 2 workgroups per CU.
 static int pick_fwd_slabs(int n_slabs, int V) {

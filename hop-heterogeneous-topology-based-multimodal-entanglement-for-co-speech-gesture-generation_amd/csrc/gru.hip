@@ -614,17 +614,14 @@ static int gru_num_cus() {
   return cus;
 }
 
-static int gru_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
 
-// persistent path iff the caller gave a workspace, every workgroup can be resident at once (one per CU) and it is
-// not disabled (HOPMI_GRU_PERSISTENT=0)
+// persistent path iff the caller gave a workspace (the host side withholds it when it cannot promise that nothing else
+// competes for the CUs: HOPMI_GRU_PERSISTENT=0, an RCCL exchange in flight, a shared device) and every workgroup can be
+// resident at once (one per CU)
 static bool gru_persistent_ok(int B, int H, const void* ws) {
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const int nJp = (nJ + 7) / 8 * 8;
-  return ws != nullptr && gru_env_int("HOPMI_GRU_PERSISTENT", 1) != 0 && 2 * nbb * nJp <= gru_num_cus();
+  return ws != nullptr && 2 * nbb * nJp <= gru_num_cus();
 }
 
 extern "C" size_t hopmi_gru_ws_bytes(int B, int T, int H) {

@@ -27,10 +27,7 @@ static inline LayerGeom make_layer_geom(int B, int T_in, int V, int d, int grid_
   return L;
 }
 
-static inline int wn_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
+static inline int wn_env_int(const char* name, int dflt) { return env_int(name, dflt); }
 
 static inline int wn_validate(int B, int T_in, int V, int d) {
   if (B <= 0 || V < 1 || V > HOPMI_MAX_NODES || d < 1 || T_in - d < 4) {

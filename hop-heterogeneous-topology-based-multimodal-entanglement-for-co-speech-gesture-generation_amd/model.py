@@ -130,7 +130,7 @@ class ReprogrammingLayer(nn.Module):
         if q.shape[-1] != 128:
             raise NotImplementedError("hopmi reprogramming kernel: head dim d_keys must be 128 (HOP.py:119)")
         ReprogrammingLayer._calls += 1
-        seed = (torch.initial_seed() * 2654435761 + ReprogrammingLayer._calls * 40503) & 0xFFFFFFFF
+        seed = (ops.base_seed() * 2654435761 + ReprogrammingLayer._calls * 40503) & 0xFFFFFFFF
         return ops.reprog_attention(q, k, v, scale, p, seed)
 
 

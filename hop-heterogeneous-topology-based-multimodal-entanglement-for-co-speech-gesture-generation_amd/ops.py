@@ -227,15 +227,15 @@ class _BiasDropResLnFn(torch.autograd.Function):
         out = torch.empty_like(x)
         xhat = torch.empty_like(x) if need else None
         rstd = torch.empty(M, dtype=torch.float32, device=x.device) if need else None
-        L, st = _lib.lib(), _stream()
+        L, st, sp = _lib.lib(), _stream(), _seed_ptr()
         _lib.check(_timed("bias_drop_res_ln_fwd", 4 * x.numel() * (4 if need else 3), 0,
                           lambda: L.hopmi_bias_dropout_residual_layernorm_fwd(
                               x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
-                              out.data_ptr(), _ptr(xhat), _ptr(rstd), M, D, float(eps), float(p_drop), int(seed) & _M32, st)),
+                              out.data_ptr(), _ptr(xhat), _ptr(rstd), M, D, float(eps), float(p_drop), int(seed) & _M32, sp, st)),
                    "hopmi_bias_dropout_residual_layernorm_fwd")
         if need:
             ctx.save_for_backward(xhat, rstd, gamma)
-        ctx.p_drop, ctx.seed, ctx.res_shape, ctx.x_rows = float(p_drop), int(seed) & _M32, res.shape, M
+        ctx.p_drop, ctx.seed, ctx.res_shape, ctx.x_rows, ctx.sp = float(p_drop), int(seed) & _M32, res.shape, M, sp
         return out
 
     @staticmethod
@@ -250,7 +250,7 @@ class _BiasDropResLnFn(torch.autograd.Function):
         _lib.check(_timed("bias_drop_res_ln_bwd", 16 * xhat.numel(), 0,
                           lambda: L.hopmi_bias_dropout_residual_layernorm_bwd(
                               dout.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                              dres.data_ptr(), M, D, ctx.p_drop, ctx.seed, st)),
+                              dres.data_ptr(), M, D, ctx.p_drop, ctx.seed, ctx.sp, st)),
                    "hopmi_bias_dropout_residual_layernorm_bwd")
         if tuple(ctx.res_shape) != tuple(dres.shape):            # broadcast residual (e.g. position embeddings)
             dres = dres.view(-1, *ctx.res_shape).sum(0)
@@ -264,6 +264,25 @@ def bias_dropout_residual_layernorm(x, bias, res, gamma, beta, eps, p_drop=0.0, 
 
 # ------------------------------------------------------------------- reprogramming cross-attention
 _M32 = 0xFFFFFFFF
+
+# Dropout stream position in DEVICE memory (a 1-element int32 tensor) or None.  Every seeded kernel draws its mask
+# from hash(seed + *SEED_DEV, ...): the host-side `seed` distinguishes the call sites of a step, the device word
+# distinguishes the steps -- a captured hipGraph of the training step (graph.GraphedTrainStep) adds to it at the head
+# of every replay, so replays draw fresh masks although the kernel arguments are frozen in the graph.
+SEED_DEV = None
+
+
+def base_seed() -> int:
+    """torch's seed with the data-parallel rank folded in: replicas are seeded identically (same initial weights) but
+    must draw different dropout masks (the reference's per-process generators diverge the same way)."""
+    s = torch.initial_seed()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        s += 0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1)
+    return s & 0xFFFFFFFFFFFFFFFF
+
+
+def _seed_ptr():
+    return None if SEED_DEV is None else SEED_DEV.data_ptr()
 
 
 def attn_keep_mask(seed: int, N: int, H: int, S: int, p_drop: float, device) -> torch.Tensor:
@@ -296,12 +315,12 @@ class _BertAttnFn(torch.autograd.Function):
         if three != 3 or dh != 64 or L > 64:
             raise _lib.HopmiError(f"hopmi bert_attn: unsupported qkv shape {tuple(qkv.shape)} (need (B, L<=64, 3, H, 64))")
         out = torch.empty(B, L, H * dh, dtype=torch.float32, device=qkv.device)
-        Lb, st = _lib.lib(), _stream()
+        Lb, st, sp = _lib.lib(), _stream(), _seed_ptr()
         _lib.check(_timed("bert_attn_fwd", 4 * 4 * B * L * H * dh, 4 * B * H * L * L * dh,
-                          lambda: Lb.hopmi_bert_attn_fwd(qkv.data_ptr(), out.data_ptr(), B, L, H, float(p_drop), int(seed), st)),
+                          lambda: Lb.hopmi_bert_attn_fwd(qkv.data_ptr(), out.data_ptr(), B, L, H, float(p_drop), int(seed), sp, st)),
                    "hopmi_bert_attn_fwd")
         ctx.save_for_backward(qkv)
-        ctx.p_drop, ctx.seed = float(p_drop), int(seed)
+        ctx.p_drop, ctx.seed, ctx.sp = float(p_drop), int(seed), sp
         return out
 
     @staticmethod
@@ -314,7 +333,7 @@ class _BertAttnFn(torch.autograd.Function):
         Lb, st = _lib.lib(), _stream()
         _lib.check(_timed("bert_attn_bwd", 4 * 7 * B * L * H * dh, 10 * B * H * L * L * dh,
                           lambda: Lb.hopmi_bert_attn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, L, H,
-                                                         ctx.p_drop, ctx.seed, st)), "hopmi_bert_attn_bwd")
+                                                         ctx.p_drop, ctx.seed, ctx.sp, st)), "hopmi_bert_attn_bwd")
         return dqkv, None, None
 
 
@@ -337,14 +356,14 @@ class _ReprogAttnFn(torch.autograd.Function):
             raise _lib.HopmiError(f"hopmi reprog_attn: bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
         o = torch.empty_like(q)
         lse = torch.empty(B, Lq, H, dtype=torch.float32, device=q.device)
-        Lb, st = _lib.lib(), _stream()
+        Lb, st, sp = _lib.lib(), _stream(), _seed_ptr()
         N = B * Lq
         _lib.check(_timed("reprog_attn_fwd", 4 * (2 * N * H * E + 2 * S * H * E), 4 * N * H * S * E,
                           lambda: Lb.hopmi_reprog_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
                                                            lse.data_ptr(), N, S, H, E, float(scale), float(p_drop),
-                                                           int(seed) & _M32, st)), "hopmi_reprog_attn_fwd")
+                                                           int(seed) & _M32, sp, st)), "hopmi_reprog_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale, ctx.p_drop, ctx.seed = float(scale), float(p_drop), int(seed) & _M32
+        ctx.scale, ctx.p_drop, ctx.seed, ctx.sp = float(scale), float(p_drop), int(seed) & _M32, sp
         return o
 
     @staticmethod
@@ -364,7 +383,7 @@ class _ReprogAttnFn(torch.autograd.Function):
         _lib.check(_timed("reprog_attn_bwd", 4 * (4 * N * H * E + 4 * S * H * E), 14 * N * H * S * E,
                           lambda: Lb.hopmi_reprog_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(),
                                                            lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                                           dv.data_ptr(), N, S, H, E, ctx.scale, ctx.p_drop, ctx.seed, st)),
+                                                           dv.data_ptr(), N, S, H, E, ctx.scale, ctx.p_drop, ctx.seed, ctx.sp, st)),
                    "hopmi_reprog_attn_bwd")
         return dq, dk.sum(0), dv.sum(0), None, None, None
 
@@ -482,6 +501,28 @@ def wn_layer_bwd(xin, scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next, y, bn_coe
 # ------------------------------------------------------------------------------------------- GRU
 GRU_CHECK_STATUS = False      # tests set this: reads the persistent kernel's status word back (a host sync)
 _PENDING_STATUS = []          # status words of persistent launches not yet checked (see deferred_status)
+_PERSISTENT_HOLD = 0          # > 0: persistent GRU launches are withheld (see no_persistent_gru)
+
+
+class no_persistent_gru:
+    """Within the block the GRU recurrences run as per-time-step launches.  The persistent kernels need every one of their
+    workgroups resident at once (they hand h_t over through counters); that only holds while nothing else competes for
+    the CUs.  GradSync wraps a backward during which RCCL kernels run beside the compute stream in this; a shared
+    device (HOPMI_REHEARSE_ONE_GPU) or HOPMI_GRU_PERSISTENT=0 withhold them for the whole process."""
+
+    def __enter__(self):
+        global _PERSISTENT_HOLD
+        _PERSISTENT_HOLD += 1
+
+    def __exit__(self, *exc):
+        global _PERSISTENT_HOLD
+        _PERSISTENT_HOLD -= 1
+
+
+def gru_persistent_allowed() -> bool:
+    import os
+    return (_PERSISTENT_HOLD == 0 and os.environ.get("HOPMI_GRU_PERSISTENT", "1") != "0"
+            and os.environ.get("HOPMI_REHEARSE_ONE_GPU") != "1")
 
 
 def deferred_status():
@@ -496,9 +537,31 @@ def deferred_status():
     return st
 
 
+def check_status_now():
+    """Inference entry points (no training step drains the list for them): read the pending status words back and
+    raise if a persistent hand-off timed out.  One small device->host copy."""
+    st = deferred_status()
+    if st is not None and float(st.item()) != 0.0:
+        raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out (status word set); "
+                              "set HOPMI_GRU_PERSISTENT=0 to use per-time-step launches")
+
+
+STATUS_SINK = None            # a list while a training-step graph is being captured: receives the status words
+
+
 def _track_status(ws):
-    if len(_PENDING_STATUS) < 4096:
-        _PENDING_STATUS.append(ws[-16])
+    if ws is None:
+        return
+    if STATUS_SINK is not None:                 # captured launches: whoever replays the graph reads these words
+        STATUS_SINK.append(ws[-16])
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    if len(_PENDING_STATUS) >= 1024:            # nobody drains (e.g. a long eval loop): fold what is there
+        folded = torch.stack(_PENDING_STATUS).sum()
+        _PENDING_STATUS.clear()
+        _PENDING_STATUS.append(folded)
+    _PENDING_STATUS.append(ws[-16])
 
 
 class _GruLayerFn(torch.autograd.Function):
@@ -517,12 +580,13 @@ class _GruLayerFn(torch.autograd.Function):
         y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=gi.device)
         gates = torch.empty(B, T, 2, 4 * H, dtype=torch.float32, device=gi.device)
         L, st = _lib.lib(), _stream()
-        ws = torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=gi.device)
+        ws = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=gi.device)
+              if gru_persistent_allowed() else None)
         _lib.check(_timed("gru_fwd", 0, 2 * T * B * 2 * 3 * H * H,
                           lambda: L.hopmi_gru_fwd(gi.data_ptr(), whh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
-                                                  gates.data_ptr(), ws.data_ptr(), B, T, H, st)), "hopmi_gru_fwd")
+                                                  gates.data_ptr(), _ptr(ws), B, T, H, st)), "hopmi_gru_fwd")
         _track_status(ws)
-        if GRU_CHECK_STATUS and not torch.cuda.is_current_stream_capturing() and int(ws[-16].item()) != 0:
+        if GRU_CHECK_STATUS and ws is not None and not torch.cuda.is_current_stream_capturing() and int(ws[-16].item()) != 0:
             raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out (status word set)")
         ctx.save_for_backward(y, gates, whh)
         return y
@@ -539,13 +603,14 @@ class _GruLayerFn(torch.autograd.Function):
         dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
         dgh = torch.empty_like(dgi)
         ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
-        ws2 = torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=y.device)
+        ws2 = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=y.device)
+               if gru_persistent_allowed() else None)
         _lib.check(_timed("gru_bwd", 0, 2 * T * B * 2 * 3 * H * H,
                           lambda: L.hopmi_gru_bwd(dy.data_ptr(), y.data_ptr(), gates.data_ptr(), whhT.data_ptr(),
-                                                  dgi.data_ptr(), dgh.data_ptr(), ws.data_ptr(), ws2.data_ptr(), B, T, H, st)),
+                                                  dgi.data_ptr(), dgh.data_ptr(), ws.data_ptr(), _ptr(ws2), B, T, H, st)),
                    "hopmi_gru_bwd")
         _track_status(ws2)
-        if GRU_CHECK_STATUS and not torch.cuda.is_current_stream_capturing() and int(ws2[-16].item()) != 0:
+        if GRU_CHECK_STATUS and ws2 is not None and not torch.cuda.is_current_stream_capturing() and int(ws2[-16].item()) != 0:
             raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
         # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
         # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.

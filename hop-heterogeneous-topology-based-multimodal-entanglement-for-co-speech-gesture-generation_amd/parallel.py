@@ -20,6 +20,8 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import ops as _ops
+
 
 class _Bucket:
     """One flat all-reduce buffer and its per-parameter views.  After the exchange the parameters' `.grad` ARE these
@@ -35,14 +37,16 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.handle = None
+        self.had_grad = [True] * len(params)     # which parameters had a gradient when the bucket was launched
 
 
 class _Group:
     """The trainable parameters of one module (generator / discriminator); buckets never span
     groups, so a backward that only reaches the discriminator only exchanges its 1 MB."""
 
-    def __init__(self, params):
+    def __init__(self, params, module=None):
         self.params = params
+        self.module = module
         self.buckets: Optional[List[_Bucket]] = None
         self.order: List[torch.nn.Parameter] = []     # gradient production order seen in the planning backward
 
@@ -53,6 +57,8 @@ class GradSync:
     Usage:  sync = GradSync([model, discriminator]);  train_llm(..., accelerator=sync)
     With world_size == 1 (or torch.distributed not initialised) it is a plain backward.
     """
+
+    takes_only = True            # backward(loss, only=...) is understood (steps._backward)
 
     def __init__(self, modules, bucket_mb: float = 64.0, grad_dtype: Optional[torch.dtype] = None, group=None,
                  force: bool = False):
@@ -74,10 +80,11 @@ class GradSync:
                     seen.add(id(p))
                     ps.append(p)
             if ps:
-                self.groups.append(_Group(ps))
+                self.groups.append(_Group(ps, m))
         self._bucket_of = {}
         self._group_of = {}
         self._in_backward = False
+        self._skip = set()
         self.bytes_reduced = 0                       # for tests / reporting
         if self.active:
             for g in self.groups:
@@ -117,9 +124,10 @@ class GradSync:
 
     def _launch(self, b: _Bucket):
         dst, src = [], []
-        for p, v in zip(b.params, b.views):
-            if p.grad is None:
-                v.zero_()
+        for i, (p, v) in enumerate(zip(b.params, b.views)):
+            b.had_grad[i] = p.grad is not None
+            if p.grad is None:                               # same on every rank (same graph): exchanged as zeros,
+                v.zero_()                                    # left None afterwards (_collect)
             elif p.grad.data_ptr() != v.data_ptr():          # (already the view: accumulated in place by autograd)
                 dst.append(v)
                 src.append(p.grad)
@@ -132,9 +140,11 @@ class GradSync:
     def _on_grad(self, p):
         if not self._in_backward:
             return
+        g = self._group_of[id(p)]
+        if id(g) in self._skip:
+            return
         b = self._bucket_of.get(id(p))
         if b is None:                            # group not planned yet: just record the production order
-            g = self._group_of[id(p)]
             if g.buckets is None:
                 g.order.append(p)
             return
@@ -146,21 +156,27 @@ class GradSync:
         b.handle.wait()
         if not self._avg:
             b.flat.mul_(1.0 / self.world)
+        # a parameter without a gradient in this backward keeps `.grad is None`, so the optimizer skips it exactly as a
+        # single-GPU run does (a zero gradient would still move it through Adam's momentum)
         if b.flat.dtype == b.params[0].dtype:
-            for p, v in zip(b.params, b.views):
-                p.grad = v                                   # gradient lives in the bucket until the next zero_grad
+            for p, v, had in zip(b.params, b.views, b.had_grad):
+                if had:
+                    p.grad = v                               # gradient lives in the bucket until the next zero_grad
         else:                                                # compressed exchange: widen back into fp32 gradients
-            for p in b.params:
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-            torch._foreach_copy_([p.grad for p in b.params], b.views)
+            live = [(p, v) for p, v, had in zip(b.params, b.views, b.had_grad) if had]
+            torch._foreach_copy_([p.grad for p, _ in live], [v for _, v in live])
         b.handle = None
 
     # -- accelerator.backward shape (train_llm.py:34,85) -----------------------------------------------
-    def backward(self, loss):
+    def backward(self, loss, only=None):
+        """`only`: modules whose gradients this backward is FOR (train_llm passes the generator for the generator loss:
+        in the GAN phase that backward also reaches the discriminator's parameters, whose gradients nobody uses --
+        the next discriminator step zeroes them -- so their buckets are not exchanged)."""
         if not self.active:
             loss.backward()
             return
+        wanted = None if only is None else {id(m) for m in only}
+        self._skip = set() if wanted is None else {id(g) for g in self.groups if id(g.module) not in wanted}
         for g in self.groups:
             for b in g.buckets or ():
                 b.pending = len(b.params)
@@ -168,10 +184,15 @@ class GradSync:
                 g.order = []
         self._in_backward = True
         try:
-            loss.backward()
+            # RCCL kernels run beside the compute stream from here on: the persistent GRU kernels' co-residency
+            # assumption does not hold, use the per-time-step launches for this backward
+            with _ops.no_persistent_gru():
+                loss.backward()
         finally:
             self._in_backward = False
         for g in self.groups:
+            if id(g) in self._skip:
+                continue
             if g.buckets is None:                # not planned yet: did this backward reach the group?
                 if any(p.grad is not None for p in g.params):
                     self._plan(g)

@@ -68,6 +68,14 @@ def _step_cache(model):
     return m.step_cache() if hasattr(m, "step_cache") else contextlib.nullcontext()
 
 
+def _backward(accelerator, loss, module):
+    """accelerator.backward(loss) (train_llm.py:34,85); a GradSync is also told which module the loss trains."""
+    if getattr(accelerator, "takes_only", False):
+        accelerator.backward(loss, only=(_unwrap(module),))
+    else:
+        accelerator.backward(loss)
+
+
 def _regularisers(args, outputs, z_context, z_mu, z_logvar, out_rand, z_rand):
     """train_llm.py:59-73 / train_gan.py:68-81."""
     beta = 0.05
@@ -144,7 +152,7 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
                 dis_real = discriminator(add_noise(target_dir_vec), text_token_padded)
                 dis_fake = discriminator(add_noise(outputs.detach().float()), text_token_padded)
                 dis_error = torch.sum(-torch.mean(torch.log(dis_real.float() + 1e-8) + torch.log(1 - dis_fake.float() + 1e-8)))
-            accelerator.backward(dis_error)
+            _backward(accelerator, dis_error, discriminator)
             dis_optimizer.step()
 
         model_optim.zero_grad()
@@ -171,7 +179,7 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
             if epoch > 10:                                                     # literal gate, train_llm.py:81
                 loss = loss + gen_error * args.loss_gan_weight
         fetch = _LossFetch(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)
-        accelerator.backward(loss)
+        _backward(accelerator, loss, model)
         model_optim.step()
     return fetch.result()
 

@@ -36,6 +36,9 @@ extern "C" {
 
 const char* hopmi_version(void);
 const char* hopmi_last_error(void);
+/* Tuning knobs (HOPMI_WN_GRID, HOPMI_WN_MAXMT, HOPMI_WN_BWD_GRID, HOPMI_GCN_*) are read from the environment once per
+ * process; this forgets the cached values so that the next call reads them again (used by the sweep probes). */
+void hopmi_reload_env(void);
 
 /* Measurement hook: the next hopmi_wn_layer_fwd call of this host thread records the two hipEvent_t EXACTLY around its
  * layer kernel (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps, what a profiler's
@@ -128,11 +131,14 @@ int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, 
  *   o[n][h][:] = sum_s dropout(softmax_s(scale * q[n][h][:] . k[s][h][:])) v[s][h][:]
  *   q, o [N][H][E] with N = B*L flat query rows; k, v [S][H][E] shared by the batch; E must be 128;
  *   lse [N][H] = log-sum-exp of the scaled scores (saved for the backward).
- *   Dropout keeps probability (n, h, s) iff hash(seed, n, h, s) >= p_drop * 2^32 (stateless, so the
- *   backward regenerates the same mask); p_drop = 0 disables it.
+ *   Dropout keeps probability (n, h, s) iff hash(seed', n, h, s) >= p_drop * 2^32 (stateless, so the
+ *   backward regenerates the same mask); p_drop = 0 disables it.  seed' = seed + *seed_dev when seed_dev (a device
+ *   pointer, nullable) is given: the stream position then lives in device memory, so a captured hipGraph of the
+ *   training step draws fresh masks on every replay (the host adds to *seed_dev inside the graph).  Every seeded
+ *   entry point below takes the same (seed, seed_dev) pair.
  */
 int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
-                          int N, int S, int H, int E, float scale, float p_drop, unsigned seed, void* stream);
+                          int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* Backward of the above: d_o [N][H][E] -> dq [N][H][E] and PARTIAL dk, dv [R][S][H][E] with
  * R = hopmi_reprog_attn_bwd_splits() (the query rows are split R ways over workgroups; the caller adds the
@@ -141,7 +147,7 @@ int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float*
 int hopmi_reprog_attn_bwd_splits(void);
 int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                           const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
-                          float scale, float p_drop, unsigned seed, void* stream);
+                          float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* ---- self-attention of the frozen BERT encoder (HOP.py:204 -> transformers BertSelfAttention.forward; replaces
  *      the transpose_for_scores copies + the library scaled-dot-product attention + the output re-layout) ----
@@ -150,9 +156,9 @@ int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const 
  *   backward: d_out [B][L][H*64] -> dqkv [B][L][3][H][64] (gradient of the projection output); probabilities are
  *   recomputed, nothing is saved.  Dropout keeps (b*L + l, h, key) iff hash(seed, b*L + l, h, key) >= p_drop * 2^32
  *   (same stateless hash as hopmi_reprog_attn_fwd).  One workgroup per (b, h): no atomics, reproducible. */
-int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, void* stream);
+int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* dqkv, int B, int L, int H, float p_drop,
-                        unsigned seed, void* stream);
+                        unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* ---- fused element-wise epilogues of the frozen BERT block (HOP.py:204 -> transformers BertIntermediate /
  *      BertSelfOutput / BertOutput), forward and backward w.r.t. activations (the LLM is frozen, HOP.py:90-91).
@@ -165,11 +171,11 @@ int hopmi_bias_gelu_fwd(const float* x, const float* bias, float* out, int M, in
 int hopmi_bias_gelu_bwd(const float* x, const float* bias, const float* dy, float* dx, int M, int N, void* stream);
 int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const float* bias, const float* res, int res_rows,
                                               const float* gamma, const float* beta, float* out, float* xhat,
-                                              float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
+                                              float* rstd, int M, int D, float eps, float p_drop, unsigned seed, const unsigned* seed_dev,
                                               void* stream);
 int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xhat, const float* rstd,
                                               const float* gamma, float* dx, float* dres, int M, int D,
-                                              float p_drop, unsigned seed, void* stream);
+                                              float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* ---- bidirectional GRU layer recurrence: model/HOP.py:166-167,248 (decoder nn.GRU, hidden 350) and
  *      model/multimodal_context_net.py:236-237,257 (discriminator nn.GRU, hidden 64); torch.nn.GRU
