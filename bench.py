@@ -3,13 +3,19 @@
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A "step" is one `train_llm` call (train_eval/train_llm.py:9-98 semantics, epoch <= 10: two
-generator forwards, one backward, Adam on 65.7 M parameters, plus the RCCL gradient all-reduce
-when N > 1) on one batch of synthetic 34-frame clips already resident in HBM.  Workload at every
-N: BASELINE.json configs[1] per GPU (TED 10-joint = 9 graph nodes, batch 128 per GPU, fp32), so
-scaling is weak.  Prints ONE JSON line on rank 0 carrying the `roofline` of the gwnet graph-conv
-kernel (algorithmic bytes / HIP-event time, measured live in the timed region) and, at N = 1, the
-`cpu_baseline` (the parity-pinned CPU oracle timed on this box's host cores).
+A "step" is one `train_llm` call (train_eval/train_llm.py:9-98 semantics, epoch <= 10: two generator forwards, one
+backward, Adam on 65.7 M parameters, plus the RCCL gradient exchange when N > 1) on one batch of synthetic 34-frame
+clips already resident in HBM.  Workload at every N: BASELINE.json configs[1] per GPU (TED 10-joint = 9 graph nodes,
+batch 128 per GPU, fp32), so scaling is weak.
+
+Three separate regions, in this order:
+  1. kernel region (`--kernel-steps`, untimed for `value`): eager `train_llm` steps with HIP events on every hand-written
+     kernel launch -> the `roofline` object (algorithmic bytes / event time of the fused WaveNet-layer kernel);
+  2. W warm-up steps, then EXACTLY K timed steps between two barrier + synchronize fences with NO instrumentation:
+     `value` = world * B * K / elapsed (max over ranks).  The steps are hopmi.GraphedTrainStep calls (the recorded
+     hipGraphs of the same train_llm; `--eager` times train_llm itself);
+  3. rank 0, N = 1 only: `cpu_baseline`, the parity-pinned CPU oracle on this box's host cores.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -23,63 +29,112 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3   # exact-f32 MFMA == vector peak
+PROFILE_ROUND = "r02"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="clips per GPU (configs[1]: 128)")
     ap.add_argument("--dataset", default="TED", choices=["TED", "TED_expressive"])
     ap.add_argument("--epoch", type=int, default=0, help="> 10 adds the GAN discriminator step")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = the headline configuration (configs[1]); bf16 = library GEMMs under autocast (configs 2/4)")
+                    help="fp32 = the headline configuration (configs[1]); bf16 = configs 2/4 (bf16 GEMMs + bf16 gradient exchange)")
+    ap.add_argument("--eager", action="store_true", help="time steps.train_llm itself instead of its recorded hipGraphs")
+    ap.add_argument("--kernel-steps", type=int, default=6, help="instrumented eager steps for the roofline object (0 = none)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
     ap.add_argument("--rehearse-sync", action="store_true",
-                    help="N=1 only: run GradSync's bucketed RCCL path on a 1-rank group (overhead rehearsal of the N>1 path)")
+                    help="N=1 only: run the N>1 exchange path on a 1-rank RCCL group (overhead rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-b128", action="store_true", help="skip the one CPU step at the GPU's batch size")
     return ap.parse_args()
 
 
 def cpu_baseline(args, V):
-    """The CPU oracle (oracle/ref_cpu.py, pinned to the reference by tests/golden) running the same
-    train_llm step on this box's host cores: BASELINE.json configs[0] (batch 4, fp32, full step)."""
+    """The CPU oracle (oracle/ref_cpu.py, pinned to the reference by tests/golden) running the same train_llm step on
+    this box's host cores: BASELINE.json configs[0] (batch 4, fp32, full step) and, once, the GPU's batch size
+    (the batch-independent mapping layer is half of the CPU step at batch 4)."""
     import torch
     from transformers import BertConfig
     from hopmi import synth
     from oracle import ref_cpu, spec
-    B = args.cpu_batch
-    # the box's CPU share for one GPU is 16 cores; torch's default (all 128 hardware threads)
-    # oversubscribes it 8x
+    # the box's CPU share for one GPU is 16 cores; torch's default (all hardware threads) oversubscribes it
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     bcfg = BertConfig(num_hidden_layers=6)
-    g_sd = spec.build_sd(spec.model_spec(V, bcfg, 1370))
-    d_sd = spec.build_sd(spec.disc_spec(3 * V), salt=1)
-    for k, v in g_sd.items():
-        if v.is_floating_point() and not k.startswith("llm_model.") and k != "word_embeddings" and "running_" not in k:
-            v.requires_grad_(True)
-    for k, v in d_sd.items():
-        if v.is_floating_point() and "running_" not in k:
-            v.requires_grad_(True)
-    g_opt = torch.optim.Adam([v for v in g_sd.values() if v.requires_grad], lr=1e-2, betas=(0.5, 0.999))
-    d_opt = torch.optim.Adam([v for v in d_sd.values() if v.requires_grad], lr=1e-3, betas=(0.5, 0.999))
-    batch = synth.synthetic_batch(B, V, 1234, "cpu")
-    batch["text"] = batch["text"]
-    rng = lambda kind, shape: torch.randperm(shape[0]) if kind == "perm" else torch.randn(shape)
     cfg, sargs = synth.model_configs(args.dataset), synth.step_args(args.dataset)
-    times = []
-    for i in range(1 + args.cpu_steps):
-        t0 = time.perf_counter()
-        ref_cpu.train_llm_step(sargs, cfg, args.epoch, batch, g_sd, d_sd, g_opt, d_opt, rng, bert_heads=12)
-        times.append(time.perf_counter() - t0)
-    times = sorted(times[1:])
-    med = times[len(times) // 2]
-    return {"value": B / med, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{args.cpu_steps} train_llm steps (median, after 1 warm-up) at batch {B}, {args.dataset}, "
-                      f"fp32, 6-layer BERT-base geometry; {med:.3f} s/step"}
+    rng = lambda kind, shape: torch.randperm(shape[0]) if kind == "perm" else torch.randn(shape)
+
+    def run(B, n_steps):
+        g_sd = spec.build_sd(spec.model_spec(V, bcfg, 1370))
+        d_sd = spec.build_sd(spec.disc_spec(3 * V), salt=1)
+        for k, v in g_sd.items():
+            if v.is_floating_point() and not k.startswith("llm_model.") and k != "word_embeddings" and "running_" not in k:
+                v.requires_grad_(True)
+        for k, v in d_sd.items():
+            if v.is_floating_point() and "running_" not in k:
+                v.requires_grad_(True)
+        g_opt = torch.optim.Adam([v for v in g_sd.values() if v.requires_grad], lr=1e-2, betas=(0.5, 0.999))
+        d_opt = torch.optim.Adam([v for v in d_sd.values() if v.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+        batch = synth.synthetic_batch(B, V, 1234, "cpu")
+        times = []
+        for _ in range(1 + n_steps):
+            t0 = time.perf_counter()
+            ref_cpu.train_llm_step(sargs, cfg, args.epoch, batch, g_sd, d_sd, g_opt, d_opt, rng, bert_heads=12)
+            times.append(time.perf_counter() - t0)
+        times = sorted(times[1:])
+        return times[len(times) // 2]
+
+    B = args.cpu_batch
+    med = run(B, args.cpu_steps)
+    out = {"value": B / med, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{args.cpu_steps} train_llm steps (median, after 1 warm-up) at batch {B}, {args.dataset}, "
+                     f"fp32, 6-layer BERT-base geometry; {med:.3f} s/step"}
+    if not args.no_cpu_b128 and args.batch != B:
+        t = run(args.batch, 1)
+        out["at_gpu_batch"] = {"value": args.batch / t, "unit": "clips/s", "batch": args.batch,
+                               "sample": f"1 step after 1 warm-up at batch {args.batch}; {t:.2f} s/step"}
+    return out
+
+
+def roofline(ks, V, B, n_kernel_steps):
+    """The roofline object from the kernel region's event timings."""
+    gf = ks["wn_layer_fwd"]
+    sec = gf["kernel_ms"] * 1e-3
+    gbs = gf["bytes"] / sec / 1e9
+    moved = (gf["bytes"] + gf["extra_bytes"]) / sec / 1e9
+    tfl = gf["flops"] / sec / 1e12
+    traffic = None        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run in here)
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_traffic.json")) as f:
+            t = json.load(f)
+        if t.get("V") == V and t.get("B") == B:
+            traffic = t["kernels"]["wn_layer_fwd"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+    r = {"kernel": "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv: BN-on-load, gated TCN, skip tail, "
+                   "node mix, graph conv, residual, BN statistics); the 8 layer launches of every training forward",
+         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "traffic": traffic, "launches": gf["launches"], "avg_us": 1e3 * gf["kernel_ms"] / gf["launches"],
+         "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
+         "bytes_definition": "SURVEY.md 8(d), fused layer: 4 B x 64 ch x V x (B*T_in read + B*T_out written + 4*B skip-tail frames)",
+         "moved_bytes_per_launch": (gf["bytes"] + gf["extra_bytes"]) / gf["launches"],
+         "moved_gbs": moved, "moved_frac": moved / HBM_PEAK_GBS,
+         "f32_mfma_equiv_tflops": tfl, "f32_mfma_equiv_frac": tfl / F32_MFMA_PEAK_TFLOPS,
+         "timing": f"start/stop HIP events attached to each wn_layer_fwd dispatch (hipExtLaunchKernelGGL) on the launch stream, "
+                   f"over {n_kernel_steps} instrumented eager train_llm steps run before the timed region (the timed region "
+                   "itself carries no instrumentation); the other kernels' *_avg_us are event pairs minus the smallest "
+                   "empty-pair interval"}
+    for name in ("wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "bert_attn_fwd", "bert_attn_bwd", "gru_fwd", "gru_bwd"):
+        if name in ks and ks[name]["launches"]:
+            k = ks[name]
+            r[name + "_avg_us"] = 1e3 * k["kernel_ms"] / k["launches"]
+            if k["flops"]:
+                r[name + "_tflops"] = k["flops"] / (k["kernel_ms"] * 1e-3) / 1e12
+    return r
 
 
 def main():
@@ -94,8 +149,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     # HOPMI_REHEARSE_ONE_GPU=1 (rehearsal on a single-GPU box only): every rank uses cuda:0 and the collectives go
-    # through gloo, so the multi-process plumbing (rendezvous, plan agreement, timing reduction) can be exercised
-    # without a second device; run it with HOPMI_GRU_PERSISTENT=0 (two persistent launches cannot share one GPU)
+    # through gloo, so the multi-process plumbing (rendezvous, exchange, timing reduction) can be exercised without a
+    # second device (the persistent GRU kernels are withheld: two such launches cannot share one GPU)
     one_gpu = os.environ.get("HOPMI_REHEARSE_ONE_GPU") == "1"
     dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
@@ -116,7 +171,6 @@ def main():
     V = 9 if args.dataset == "TED" else 42
     B = args.batch
     hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
-    # (the bf16 mode is host-bound at these sizes: the per-call table lookup costs more than the selection gains)
     tuned = (not args.no_tuned_gemms) and args.dtype == "fp32" and hopmi.use_tuned_gemms()
     torch.manual_seed(0)                                       # identical replicas
     model = hopmi.Model(synth.model_configs(args.dataset), synth.build_bert(6), synth.SyntheticTokenizer(),
@@ -124,16 +178,25 @@ def main():
     disc = hopmi.ConvDiscriminator(3 * V).to(dev)
     model.train()
     disc.train()
+    torch.manual_seed(1000 + rank)                             # ... that draw different noise / dropout masks
     lr = 0.01 if args.dataset == "TED" else 0.005              # run_ted.py:103 / run_expressive.py:100
     g_opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr, betas=(0.5, 0.999), fused=True)
     d_opt = torch.optim.Adam(disc.parameters(), lr=lr * 0.1, betas=(0.5, 0.999), fused=True)
-    sync = GradSync([model, disc], force=args.rehearse_sync)
+    grad_dtype = torch.bfloat16 if args.dtype == "bf16" else None      # configs[2]/[4]: bf16 RCCL exchange
+    sync = GradSync([model, disc], force=args.rehearse_sync, grad_dtype=grad_dtype)
     sargs = synth.step_args(args.dataset)
     batch = synth.synthetic_batch(B, V, 1234 + rank, dev)
+    inputs = (batch["in_audio"], batch["log_melspec"], batch["text"], batch["target_dir_vec"], batch["vid_indices"])
+
+    def eager_step():
+        return hopmi.train_llm(sargs, args.epoch, *inputs, model, disc, g_opt, d_opt, sync)
+
+    graphed = hopmi.GraphedTrainStep(sargs, model, disc, g_opt, d_opt, accelerator=sync, eager_calls=1,
+                                     grad_dtype=grad_dtype, enabled=not args.eager, force_exchange=args.rehearse_sync,
+                                     group=dist.group.WORLD if dist.is_initialized() else None)
 
     def step():
-        return hopmi.train_llm(sargs, args.epoch, batch["in_audio"], batch["log_melspec"], batch["text"],
-                               batch["target_dir_vec"], batch["vid_indices"], model, disc, g_opt, d_opt, sync)
+        return graphed(args.epoch, *inputs)
 
     def fence():
         torch.cuda.synchronize()
@@ -141,67 +204,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- 1. kernel region: instrumented eager steps (these also bring up handles / workspaces / autograd threads) ----
+    ks = None
+    if args.kernel_steps > 0:
+        eager_step()                                           # first call: lazy initialisation, GradSync's plan
+        ops.TIMER = ops.KernelTimer()
+        for _ in range(args.kernel_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        timer, ops.TIMER = ops.TIMER, None
+        ks = timer.summary()
+
+    # ---- 2. warm-up (includes the recording of the step's graphs), then the timed region --------------------------------
     for _ in range(args.warmup):
         step()
-    ops.TIMER = ops.KernelTimer()
     fence()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(args.steps):
         last = step()
+        stamps.append(time.perf_counter())
     fence()
     elapsed = time.perf_counter() - t0
-    timer, ops.TIMER = ops.TIMER, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
     if rank == 0:
-        ks = timer.summary()
-        gf = ks["wn_layer_fwd"]
-        # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
-        # inside this process): (2*FETCH_SIZE + WRITE_SIZE) KB per launch, gfx950 correction applied there
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f)["kernels"]["wn_layer_fwd"]["hbm_bytes_per_launch"] if (V == 9 and B == 128) else None
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        gbs = gf["bytes"] / (gf["kernel_ms"] * 1e-3) / 1e9
-        tfl = gf["flops"] / (gf["kernel_ms"] * 1e-3) / 1e12
+        per_step = sorted(b - a for a, b in zip(stamps, stamps[1:]))
+        median_ms = 1e3 * per_step[len(per_step) // 2]
+        gan = args.epoch > 10
         out = {
             "metric": "training clips/sec (34-frame, 10-joint TED)" if V == 9 else "training clips/sec (34-frame, 43-joint TED-Expressive)",
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 GEMMs (autocast) + f32 HIP kernels, f32 master weights", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "median_ms_per_step": median_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 library GEMMs (autocast) + bf16 gradient exchange; f32 HIP kernels, master weights and optimizer",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{1 if V == 9 else 3}] per GPU: {args.dataset} {V + 1}-joint ({V} graph nodes), "
-                                   f"34-frame clips, batch {B}/GPU, {args.dtype}, full train_llm step "
-                                   f"({'GAN phase' if args.epoch > 10 else 'epoch<=10: 2 generator forwards + backward + Adam'})",
+                                   f"34-frame clips, batch {B}/GPU, {args.dtype}, one full train_llm step = "
+                                   + ("GAN phase (epoch > 10): discriminator step (1 no-grad generator forward, 2 discriminator forwards, "
+                                      "backward, Adam) + generator step (2 generator forwards, 1 discriminator forward, backward, Adam)"
+                                      if gan else
+                                      "2 generator forwards (the graded one + the no-grad forward of the diversity regulariser, "
+                                      "train_llm.py:58) + 1 backward + Adam on 65.7 M parameters")
+                                   + "; inside one step the batch-independent prototype branch (mapping layer, K/V projections) and the "
+                                     "dropout-free audio branch (beat MLP, gwnet: 8 fused-layer launches) are computed ONCE and reused by the "
+                                     "step's other forwards, whose BatchNorm running-statistics update is replayed on the same partial "
+                                     "sums (bit-identical to recomputing, tests/test_gpu_parity.py::test_step_cache_audio_branch_equals_recompute)",
+                       "execution": "steps.train_llm issued from Python every step (--eager)" if args.eager else
+                                    "hopmi.GraphedTrainStep: the launches of one steps.train_llm call recorded once as hipGraphs "
+                                    "(cut behind the loss copy and around every collective) and replayed; dropout advances through a "
+                                    "device-side seed word",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "exchange": None if world == 1 and not args.rehearse_sync else
+                                   "prototype rows of the mapping layer sharded over ranks (all-gather S, all-reduce dS), "
+                                   "one flat all-reduce of the other gradients per module, eager RCCL calls between graph launches",
                        "llm": "BERT-base geometry, 6 layers, random init, frozen",
                        "library_gemm_selection": "shipped TunableOp table (replay only)" if tuned else "library default",
                        "losses": last},
-            # the gwnet graph conv runs inside the fused WaveNet-layer kernel (BN-on-load, gated TCN, skip tail,
-            # node mix, graph conv, residual, BN statistics): algorithmic bytes = xin read + y / saved gates /
-            # skip tail written, per launch
-            "roofline": {"kernel": "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv; 8 layers of the training forward, gates saved)",
-                         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "launches": gf["launches"], "avg_us": 1e3 * gf["kernel_ms"] / gf["launches"],
-                         "avg_us_with_event_pair": 1e3 * gf["total_ms"] / gf["launches"],
-                         "event_pair_overhead_us": 1e3 * gf["event_overhead_ms"],
-                         "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
-                         "f32_mfma_tflops": tfl, "f32_mfma_frac": tfl / F32_MFMA_PEAK_TFLOPS,
-                         "timing": "start/stop HIP events attached to each wn_layer_fwd dispatch (hipExtLaunchKernelGGL) on the launch "
-                                   "stream, inside the timed region; the other kernels' *_avg_us are event pairs minus the "
-                                   "smallest empty-pair interval"},
         }
-        for name in ("wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "bert_attn_fwd", "bert_attn_bwd", "gru_fwd", "gru_bwd"):
-            if name in ks and ks[name]["launches"]:
-                k = ks[name]
-                out["roofline"][name + "_avg_us"] = 1e3 * k["kernel_ms"] / k["launches"]
-                if k["flops"]:
-                    out["roofline"][name + "_tflops"] = k["flops"] / (k["kernel_ms"] * 1e-3) / 1e12
+        if ks is not None:
+            out["roofline"] = roofline(ks, V, B, args.kernel_steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V)
         print(json.dumps(out), flush=True)

@@ -577,6 +577,20 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
   }
 }
 
+// Arrival counters and status word are cleared by a kernel, not by hipMemsetAsync: inside a replayed hipGraph a memset
+// node was observed to land AFTER the dependent persistent kernel had started (the counters still held the previous
+// replay's arrivals, then were zeroed under the running kernel, whose hand-offs then timed out); kernel -> kernel
+// ordering holds in graphs and eagerly alike.
+__global__ void gru_clear_ws_kernel(int* __restrict__ ws, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ws[i] = 0;
+}
+
+static void gru_clear_ws(void* ws, size_t bytes, hipStream_t st) {
+  const int n = (int)(bytes / sizeof(int));
+  hipLaunchKernelGGL(gru_clear_ws_kernel, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<int*>(ws), n);
+}
+
 static int gru_validate(const void* const* ptrs, int n, int B, int T, int H) {
   for (int i = 0; i < n; ++i)
     if (!ptrs[i]) { set_error("hopmi_gru: null pointer argument #%d", i); return HOPMI_EINVAL; }
@@ -649,7 +663,7 @@ extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh
     hipStream_t st = static_cast<hipStream_t>(stream);
     int* cnt = static_cast<int*>(ws);
     int* status = cnt + (size_t)2 * nbb * T;
-    if (hipMemsetAsync(ws, 0, hopmi_gru_ws_bytes(B, T, H), st) != hipSuccess) return check_launch("hopmi_gru_fwd(memset)");
+    gru_clear_ws(ws, hopmi_gru_ws_bytes(B, T, H), st);
     const int grid = 2 * nbb * nJp;
     switch ((KP + 127) / 128) {
       case 1: launch_gru_fwd_persistent<1>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
@@ -659,7 +673,7 @@ extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh
     }
     return check_launch("hopmi_gru_fwd(persistent)");
   }
-  if (ws != nullptr) (void)hipMemsetAsync(ws, 0, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));   // status = 0
+  if (ws != nullptr) gru_clear_ws(ws, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));   // status = 0
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);
@@ -697,7 +711,7 @@ extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates
     hipStream_t st = static_cast<hipStream_t>(stream);
     int* cnt = static_cast<int*>(ws2);
     int* status = cnt + (size_t)2 * nbb * T;
-    if (hipMemsetAsync(ws2, 0, hopmi_gru_ws_bytes(B, T, H), st) != hipSuccess) return check_launch("hopmi_gru_bwd(memset)");
+    gru_clear_ws(ws2, hopmi_gru_ws_bytes(B, T, H), st);
     const int grid = 2 * nbb * nJp;
     switch ((KP + 127) / 128) {
       case 1: launch_gru_bwd_persistent<1>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
@@ -707,7 +721,7 @@ extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates
     }
     return check_launch("hopmi_gru_bwd(persistent)");
   }
-  if (ws2 != nullptr) (void)hipMemsetAsync(ws2, 0, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));  // status = 0
+  if (ws2 != nullptr) gru_clear_ws(ws2, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));  // status = 0
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);

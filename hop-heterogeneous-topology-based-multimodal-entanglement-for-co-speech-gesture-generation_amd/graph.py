@@ -1,0 +1,323 @@
+"""The training step of the reference (`train_eval/train_llm.py:9-98`) as replayed hipGraphs.
+
+`steps.train_llm` issues ~1 500 kernel launches per step; on a slow or instrumented host the step is bound by the time
+the host needs to issue them, not by the device.  `GraphedTrainStep` records the launches of one `train_llm` call once
+(the very same Python code: `steps.train_llm` runs under stream capture with this object standing in for the
+`accelerator`) and replays them:
+
+    step = hopmi.GraphedTrainStep(args, model, discriminator, model_optim, dis_optimizer)      # Adam optimizers
+    losses = step(epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices)   # = train_llm(...)
+
+* The first `eager_calls` calls run `steps.train_llm` itself (library handles, workspaces and autograd threads come up
+  outside a capture); the next call captures and replays; later calls copy the batch into the graph's static inputs
+  and replay.  Every call is exactly one training step.  One recording per phase (`epoch <= 10` / GAN phase) and batch
+  shape; a batch of another shape (the last, short one of an epoch) runs the eager step.
+* The recording is cut into segments where the step talks to the outside: behind the loss copy (the replay waits for
+  that event only and returns while backward + optimizer still run), and -- with more than one rank -- around every
+  collective, which are ordinary eager RCCL calls between two graph launches (nothing of RCCL is captured).
+* Dropout: the seeded kernels add a device-side stream position to their (frozen) seed argument
+  (`ops.SEED_DEV`, bumped at the head of every replay); torch's own generators are graph-safe.
+* Data parallelism: the batch-independent prototype matrix S = W_map E + b
+  (HOP.py:116,200; 70 GFLOP forward + 70 GFLOP weight gradient, constant in the batch) is ROW-SHARDED over the ranks:
+  each rank computes its ceil(1500 / N) rows, S is all-gathered (4.6 MB), the backward all-reduces dS (4.6 MB) instead
+  of the 183 MB weight gradient, and each rank forms dW for and updates only its own rows.  The other gradients
+  (~80 MB fp32) are exchanged as one flat all-reduce per module.  `unshard()` brings every rank's copy of the mapping
+  layer (and its Adam moments) up to date, e.g. before `state_dict()`.
+"""
+import contextlib
+import gc
+
+import torch
+import torch.distributed as dist
+
+from . import ops as _ops
+from . import steps as _steps
+
+_STEP_INC = 0x9E3779B1            # added to ops.SEED_DEV at the head of every replay
+
+
+def shard_rows(n_rows: int, rank: int, world: int):
+    """Row range [r0, r1) of a matrix of n_rows rows owned by `rank`, and the padded per-rank row count (equal shards
+    for the all-gather; the last ranks' shards are short or empty)."""
+    per = -(-n_rows // world)
+    r0 = min(rank * per, n_rows)
+    return r0, min(r0 + per, n_rows), per
+
+
+def mapping_grad_rows(dS, E, r0, r1, out_w, out_b, bf16=False):
+    """Rows [r0, r1) of the mapping layer's gradients from dS (1500 x d_llm): dW = dS E^T, db = sum_j dS (the backward
+    of S = W E + b[:, None]); written into the same rows of the full-size gradient buffers."""
+    if r1 <= r0:
+        return
+    g = dS[r0:r1]
+    if bf16:
+        out_w[r0:r1].copy_(g.to(torch.bfloat16) @ E.to(torch.bfloat16).t())
+    else:
+        torch.mm(g, E.t(), out=out_w[r0:r1])
+    torch.sum(g, dim=1, out=out_b[r0:r1])
+
+
+def all_gather_rows(buf, per, group=None):
+    """In-place all-gather of equal row shards: rank r contributes buf[r*per:(r+1)*per]."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = buf[rank * per:(rank + 1) * per]
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(buf, mine, group=group)
+    else:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine.contiguous(), group=group)
+        for r, p in enumerate(parts):
+            buf[r * per:(r + 1) * per].copy_(p)
+
+
+def all_reduce_mean(flat, group=None):
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, group=group)
+        flat.div_(dist.get_world_size(group))
+
+
+class _Capture:
+    """Stands in for the `accelerator` of `train_llm` while its launches are being recorded, and owns the recording:
+    a list of ("graph", CUDAGraph) / ("eager", callable) entries that a replay walks in order."""
+    takes_only = True
+
+    def __init__(self, owner, gan):
+        self.owner, self.gan = owner, gan
+        self.plan = []
+        self.status = []            # ops.STATUS_SINK: status words of the persistent GRU launches recorded so far
+        self.graph = None
+        self.fetch = None
+        self.keep = []              # tensors the recording owns (flat exchange buffers, ...)
+
+    def begin(self):
+        self.graph = torch.cuda.CUDAGraph()
+        self.graph.capture_begin(pool=self.owner._pool)
+
+    def end(self):
+        self.graph.capture_end()
+        self.plan.append(("graph", self.graph))
+        self.graph = None
+
+    def cut(self, eager_fn=None):
+        self.end()
+        if eager_fn is not None:
+            self.plan.append(("eager", eager_fn))
+        self.begin()
+
+    # -- hooks called from steps.train_llm / steps._LossFetch ------------------------------------------------------
+    def take_status(self):
+        parts = [w.float().reshape(()) for w in self.status]
+        self.status.clear()
+        parts.append(self.owner._bwd_status)          # the previous replay's backward launches
+        return torch.stack(parts).sum()
+
+    def fetch_into(self, fetch, dev):
+        o = self.owner
+        host = o._host[:dev.numel()]
+        host.copy_(dev, non_blocking=True)
+        self.fetch = fetch
+        ev = o._event
+        self.cut(ev.record)                            # the replay's host side waits for this event only
+        return host
+
+    def backward(self, loss, only=None):
+        loss.backward()
+        is_disc = only is not None and len(only) == 1 and only[0] is self.owner.disc
+        self.owner._after_backward(self, is_disc)
+
+
+class GraphedTrainStep:
+    def __init__(self, args, model, discriminator, model_optim, dis_optimizer, accelerator=None, group=None,
+                 eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False):
+        """`accelerator`: what the eager calls hand to train_llm (a GradSync when more than one rank trains; default a
+        plain backward).  `grad_dtype=torch.bfloat16` halves the bytes of the flat gradient exchanges (the sums still
+        land in fp32 gradients).  `enabled=False` makes every call the eager step (for A/B runs).  `force_exchange` runs
+        the collectives of the N > 1 recording on a 1-rank group too (rehearsal on a single-GPU box)."""
+        self.args, self.model, self.disc = args, _steps._unwrap(model), _steps._unwrap(discriminator)
+        self.g_opt, self.d_opt = model_optim, dis_optimizer
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
+        self.accel = accelerator if accelerator is not None else _PlainBackward()
+        self.eager_left = eager_calls
+        self.grad_dtype = grad_dtype
+        self.enabled = enabled
+        self.records = {}
+        self.sharded = False
+        self._pool = None
+        self._built = False
+
+    # -- one-time device state -------------------------------------------------------------------------------------
+    def _build(self, dev):
+        m = self.model
+        self._pool = torch.cuda.graph_pool_handle()
+        self._stream = torch.cuda.Stream(device=dev)
+        self._event = torch.cuda.Event()
+        self._host = torch.zeros(16, dtype=torch.float32).pin_memory()
+        self._bwd_status = torch.zeros((), dtype=torch.float32, device=dev)
+        self._seed_word = torch.zeros(1, dtype=torch.int64, device=dev)    # ops.SEED_DEV while recording
+        self._has_proto = bool(getattr(m, "use_reprograme", False))
+        if self._has_proto:
+            n, d = m.mapping_layer.weight.shape[0], m.word_embeddings.shape[1]
+            self.r0, self.r1, self.per = shard_rows(n, self.rank, self.world)
+            self._S_pad = torch.zeros(self.per * self.world, d, dtype=torch.float32, device=dev)
+            self._S = self._S_pad[:n].requires_grad_()                    # the leaf the graded forward reads
+            self._Wg = torch.zeros_like(m.mapping_layer.weight)            # rows outside [r0, r1) stay zero
+            self._bg = torch.zeros_like(m.mapping_layer.bias)
+        for opt in (self.g_opt, self.d_opt):
+            _make_capturable(opt)
+        self._built = True
+
+    # -- the three places where a recording differs from the eager step -------------------------------------------
+    def _prototype_segment(self, cap, amp):
+        """Head of every replay: advance the dropout stream, compute this rank's rows of S, all-gather."""
+        self._seed_word.add_(_STEP_INC)
+        if not self._has_proto:
+            return
+        with torch.no_grad(), amp:
+            if self.r1 > self.r0:
+                self._S_pad[self.r0:self.r1].copy_(self.model.prototype_rows(self.r0, self.r1))
+        if self.exchange:
+            buf, per, grp = self._S_pad, self.per, self.group
+            cap.cut(lambda: all_gather_rows(buf, per, grp))
+
+    def _after_backward(self, cap, is_disc):
+        """Called with the gradients of one module freshly produced: exchange them (world > 1), then -- for the
+        generator -- turn dS into this rank's rows of the mapping layer's gradients."""
+        module = self.disc if is_disc else self.model
+        if self.exchange:
+            grads = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None]
+            if not is_disc and self._has_proto and self._S.grad is not None:
+                grads.append(self._S.grad)
+            flat = torch.empty(sum(g.numel() for g in grads), dtype=self.grad_dtype or torch.float32, device=grads[0].device)
+            views, off = [], 0
+            for g in grads:
+                views.append(flat[off:off + g.numel()].view(g.shape))
+                off += g.numel()
+            torch._foreach_copy_(views, grads)
+            cap.keep.append(flat)
+            grp = self.group
+            cap.cut(lambda: all_reduce_mean(flat, grp))
+            torch._foreach_copy_(grads, views)
+        if not is_disc and self._has_proto:
+            m = self.model
+            dS = self._S.grad
+            with torch.no_grad():
+                if dS is not None:
+                    mapping_grad_rows(dS, m.word_embeddings, self.r0, self.r1, self._Wg, self._bg,
+                                      bf16=torch.is_autocast_enabled())
+            m.mapping_layer.weight.grad, m.mapping_layer.bias.grad = self._Wg, self._bg
+
+    # -- capture -----------------------------------------------------------------------------------------------------
+    def _capture(self, epoch, batch):
+        dev = batch[0].device
+        gan = epoch > 10 and self.args.loss_gan_weight > 0.0
+        static = [t.clone() for t in batch]
+        cap = _Capture(self, gan)
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        amp_factory = lambda: _steps._amp(self.args, static[3])
+        m = self.model
+        prev_sink, prev_cap, prev_seed = _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV
+        _ops.deferred_status()                                   # pending eager launches are not this recording's
+        gc.collect()
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(self._stream), _ops.no_timer():
+            _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV = cap.status, cap, self._seed_word
+            if self._has_proto:
+                m._proto_S = self._S
+                self._S.grad = None
+            try:
+                cap.begin()
+                try:
+                    self._prototype_segment(cap, amp_factory())
+                    _steps.train_llm(self.args, epoch, *static, m, self.disc, self.g_opt, self.d_opt, cap)
+                    # tail of the last segment: the backward launches' status words, read by the NEXT replay's fetch
+                    if cap.status:
+                        self._bwd_status.copy_(torch.stack([w.float().reshape(()) for w in cap.status]).sum())
+                        cap.status.clear()
+                finally:
+                    cap.end()
+            finally:
+                _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV = prev_sink, prev_cap, prev_seed
+                m._proto_S = None
+        cur.wait_stream(self._stream)
+        if cap.fetch is None:
+            raise RuntimeError("hopmi GraphedTrainStep: the recorded step never fetched its losses")
+        self.sharded = self.sharded or (self.world > 1 and self._has_proto)
+        return dict(cap=cap, static=static, terms=cap.fetch.terms, n_vals=len(cap.fetch.terms) + 1)
+
+    # -- call --------------------------------------------------------------------------------------------------------
+    def __call__(self, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices):
+        batch = (in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices)
+        if not (self.enabled and in_audio.is_cuda):
+            return self._eager(epoch, batch)
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            return self._eager(epoch, batch)
+        gan = epoch > 10 and self.args.loss_gan_weight > 0.0
+        key = (gan, torch.is_autocast_enabled(), _steps._MIXED, getattr(self.args, "mixed_precision", None)) + tuple(
+            (tuple(t.shape), t.dtype) for t in batch)
+        rec = self.records.get(key)
+        if rec is None:
+            if any(k[0] == gan for k in self.records):           # another batch shape of a recorded phase: eager
+                return self._eager(epoch, batch)
+            if not self._built:
+                self._build(in_audio.device)
+            rec = self.records[key] = self._capture(epoch, batch)
+        for dst, src in zip(rec["static"], batch):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        for kind, x in rec["cap"].plan:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()
+        self._event.synchronize()
+        return _steps._LossFetch.decode(rec["terms"], self._host[:rec["n_vals"]].tolist(), True)
+
+    def _eager(self, epoch, batch):
+        if self.sharded:
+            self.unshard()
+        return _steps.train_llm(self.args, epoch, *batch, self.model, self.disc, self.g_opt, self.d_opt, self.accel)
+
+    # -- prototype shards -> full copies ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def unshard(self):
+        """All-gather the mapping layer's rows (and their Adam moments) from their owners, so that every rank holds the
+        current full tensors (call before state_dict() / evaluation when training with more than one rank)."""
+        if not (self.sharded and self.world > 1):
+            return
+        m = self.model
+        n = m.mapping_layer.weight.shape[0]
+        tensors = [m.mapping_layer.weight, m.mapping_layer.bias]
+        for p in (m.mapping_layer.weight, m.mapping_layer.bias):
+            st = self.g_opt.state.get(p, {})
+            tensors += [st[k] for k in ("exp_avg", "exp_avg_sq") if k in st]
+        for t in tensors:
+            pad = torch.zeros((self.per * self.world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[:n].copy_(t)
+            all_gather_rows(pad, self.per, self.group)
+            t.copy_(pad[:n])
+        self.sharded = False
+
+
+class _PlainBackward:
+    def backward(self, loss):
+        loss.backward()
+
+
+def _make_capturable(opt):
+    """A captured optimizer step needs its step counters on the device (torch.optim `capturable=True`)."""
+    if not isinstance(opt, (torch.optim.Adam, torch.optim.AdamW)):
+        raise TypeError("hopmi GraphedTrainStep: only torch.optim.Adam / AdamW steps are recorded "
+                        f"(got {type(opt).__name__}); use train_llm for other optimizers")
+    for g in opt.param_groups:
+        g["capturable"] = True
+    for p, st in opt.state.items():
+        if "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
+            st["step"] = st["step"].to(p.device)

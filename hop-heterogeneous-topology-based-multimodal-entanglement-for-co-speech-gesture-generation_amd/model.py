@@ -186,6 +186,7 @@ class Model(nn.Module):
         self._randn_like = torch.randn_like      # tests inject CPU-drawn noise here
         self._cache = None
         self._kv_infer = None                        # (weights key, K/V prototypes) of the last no-grad call
+        self._proto_S = None                         # set by graph.GraphedTrainStep: S as a leaf it owns
         self._bert_fast = None
 
     # -- per-step cache of the batch-independent prototype branch -------------------------------
@@ -206,26 +207,37 @@ class Model(nn.Module):
               self.reprogramming_layer.value_projection.weight, self.reprogramming_layer.value_projection.bias)
         return tuple((p._version, p.data_ptr()) for p in ps) + (torch.is_autocast_enabled(),)
 
+    def prototype_rows(self, r0=0, r1=None):
+        """Rows [r0, r1) of S = mapping_layer(E^T)^T = W_map @ E + b[:, None] (HOP.py:200; 1500 x d_llm).  K = vocab
+        (30522) is huge and M x N tiny (72 GEMM tiles on 256 CUs): K is split into equal chunks as one strided batched
+        GEMM on views (no copies) and the partial products are added in a fixed order.  A row range is what one rank
+        of a prototype-sharded data-parallel run owns (graph.GraphedTrainStep)."""
+        W, E, b = self.mapping_layer.weight, self.word_embeddings, self.mapping_layer.bias
+        if r0 != 0 or r1 is not None:
+            W, b = W[r0:r1], b[r0:r1]
+        ks = next((c for c in (6, 8, 4, 3, 2) if self.vocab_size % c == 0 and self.vocab_size // c >= 1024), 1)
+        # (fp32 only: the bf16 strided-batched GEMM backward of these views faults inside the BLAS library, and a
+        # bf16 GEMM of this size does not need the split)
+        if ks > 1 and W.is_cuda and not torch.is_autocast_enabled():
+            return _SplitKAffine.apply(W, E, b, ks)
+        return torch.addmm(b.unsqueeze(1), W, E)
+
     def _prototypes(self):
         if self._cache is not None and "kv" in self._cache:
             return self._cache["kv"]
+        if self._proto_S is not None:               # a graphed step owns S (computed by row shards, gradient taken there)
+            with torch.enable_grad():               # (the first forward of a GAN step runs under no_grad, the K/V it
+                kv = self.reprogramming_layer.project_source(self._proto_S, self._proto_S)   # caches feed the graded one)
+            if self._cache is not None:
+                self._cache["kv"] = kv
+            return kv
         infer = not torch.is_grad_enabled()
         if infer:                                   # inference: the branch only depends on the weights, keep it
             key = self._prototype_key()             # across calls until one of them changes (test_checkpoint.py:459 loop)
             if self._kv_infer is not None and self._kv_infer[0] == key:
                 return self._kv_infer[1]
         with torch.enable_grad():
-            # HOP.py:200: mapping_layer(E^T)^T == W_map @ E + b[:, None]   (1500 x d_llm).  K = vocab (30522)
-            # is huge and M x N tiny (72 GEMM tiles on 256 CUs): split K into equal chunks as one strided
-            # batched GEMM (no copies) and add the partial products in a fixed order.
-            W, E = self.mapping_layer.weight, self.word_embeddings
-            ks = next((c for c in (6, 8, 4, 3, 2) if self.vocab_size % c == 0 and self.vocab_size // c >= 1024), 1)
-            # (fp32 only: the bf16 strided-batched GEMM backward of these views faults inside the BLAS library, and a
-            # bf16 GEMM of this size does not need the split)
-            if ks > 1 and W.is_cuda and not torch.is_autocast_enabled():
-                S = _SplitKAffine.apply(W, E, self.mapping_layer.bias, ks)
-            else:
-                S = torch.addmm(self.mapping_layer.bias.unsqueeze(1), W, E)
+            S = self.prototype_rows()
             kv = self.reprogramming_layer.project_source(S, S)
         if self._cache is not None:
             self._cache["kv"] = kv
@@ -240,8 +252,10 @@ class Model(nn.Module):
         and only repeats that forward's BatchNorm running-statistics update (train_llm.py:58 runs such a forward
         for the diversity regulariser)."""
         c = self._cache
-        key = (id(in_audio), in_audio._version, id(pre_seq), pre_seq._version, self.training)
-        if c is not None and not torch.is_grad_enabled() and c.get("audio_key") == key:
+        key = None
+        if c is not None and not (in_audio.is_inference() or pre_seq.is_inference()):   # (inference tensors have no version)
+            key = (id(in_audio), in_audio._version, id(pre_seq), pre_seq._version, self.training)
+        if key is not None and not torch.is_grad_enabled() and c.get("audio_key") == key:
             if self.training:
                 self.gwnet.replay_bn_update()
             return c["audio"]
@@ -256,7 +270,7 @@ class Model(nn.Module):
         pre = g_seq.new_zeros((B, 34, 3 * V + 1))
         pre[:, 0:4, :-1] = g_seq
         pre[:, 0:4, -1] = 1
-        if c is not None and self.gwnet.dropout == 0:
+        if key is not None and self.gwnet.dropout == 0:
             c["audio_key"], c["audio"] = key, (pre.detach(), beat.detach())
             c["audio_refs"] = (in_audio, pre_seq)                               # keeps the ids in the key alive
         return pre, beat

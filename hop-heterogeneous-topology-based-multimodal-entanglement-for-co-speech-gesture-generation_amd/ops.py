@@ -29,23 +29,23 @@ class KernelTimer:
         self.exact = set()
         self._n = 0
 
-    def launch_exact(self, name, nbytes, flops, fn):
+    def launch_exact(self, name, nbytes, flops, fn, extra=0):
         """For entry points that support hopmi_time_next_launch: the events are recorded by the dispatch itself
         (kernel begin / end), so there is no pair overhead to take off."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); e1.record()                     # materialise the hipEvent_t handles
         _lib.check(_lib.lib().hopmi_time_next_launch(e0.cuda_event, e1.cuda_event), "hopmi_time_next_launch")
         rc = fn()
-        self.spans.setdefault(name, []).append((e0, e1, nbytes, flops))
+        self.spans.setdefault(name, []).append((e0, e1, nbytes, flops, extra))
         self.exact.add(name)
         return rc
 
-    def launch(self, name, nbytes, flops, fn):
+    def launch(self, name, nbytes, flops, fn, extra=0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn()
         e1.record()
-        self.spans.setdefault(name, []).append((e0, e1, nbytes, flops))
+        self.spans.setdefault(name, []).append((e0, e1, nbytes, flops, extra))
         self._n += 1
         if self._n % 8 == 0:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,20 +59,35 @@ class KernelTimer:
         over = gaps[0] if gaps else 0.0
         out = {}
         for name, spans in self.spans.items():
-            ms = sum(a.elapsed_time(b) for a, b, _, _ in spans)
+            ms = sum(s[0].elapsed_time(s[1]) for s in spans)
             o = 0.0 if name in self.exact else over
             out[name] = dict(launches=len(spans), total_ms=ms, kernel_ms=max(ms - len(spans) * o, 0.0),
-                             event_overhead_ms=o, bytes=sum(s[2] for s in spans), flops=sum(s[3] for s in spans))
+                             event_overhead_ms=o, bytes=sum(s[2] for s in spans), flops=sum(s[3] for s in spans),
+                             extra_bytes=sum(s[4] for s in spans))
         return out
 
 
 TIMER = None
 
 
-def _timed(name, nbytes, flops, fn, exact=False):
+class no_timer:
+    """Within the block no launch is timed (event records do not belong inside a stream capture)."""
+
+    def __enter__(self):
+        global TIMER
+        self.prev, TIMER = TIMER, None
+
+    def __exit__(self, *exc):
+        global TIMER
+        TIMER = self.prev
+
+
+def _timed(name, nbytes, flops, fn, exact=False, extra=0):
+    """`nbytes` = algorithmic bytes of the launch; `extra` = bytes it moves on top of those by the
+    build's own choice (tensors saved for the backward), reported separately."""
     if TIMER is None:
         return fn()
-    return TIMER.launch_exact(name, nbytes, flops, fn) if exact else TIMER.launch(name, nbytes, flops, fn)
+    return TIMER.launch_exact(name, nbytes, flops, fn, extra) if exact else TIMER.launch(name, nbytes, flops, fn, extra)
 
 
 def gcn_algorithmic_bytes(n_slabs: int, V: int) -> int:
@@ -430,13 +445,15 @@ def wn_layer_fwd(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, utail, dilation, *,
         raise _lib.HopmiError(f"hopmi wn_layer: bad utail view {tuple(utail.shape)} strides {utail.stride()}")
     st = _stream()
     n_out = B * T_out * V
-    nbytes = 4 * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + n_out * 128 * (1 if want_fs else 0) + B * 4 * V * 64)
+    # SURVEY.md 8(d), fused layer: x in + x out + the last-4-frames skip tail; the saved gates are not algorithmic
+    nbytes = 4 * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + B * 4 * V * 64)
+    extra = 4 * n_out * 128 * (1 if want_fs else 0)
     flops = n_out * (2 * 2 * 2 * 64 * 64 + (2 * 192 * 64 + 4 * 64 * V if do_gcn else 0))
     _lib.check(_timed("wn_layer_fwd", nbytes, flops,
                       lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), _conv_w(wf), _conv_w(wg), bf.data_ptr(), bg.data_ptr(),
                                                    _ptr(prep), _ptr(Wm), _ptr(bm), _ptr(y), _ptr(fs), utail.data_ptr(),
                                                    utail.stride(2), _ptr(ws), B, T_in, V, dilation,
-                                                   1 if do_gcn else 0, st), exact=True), "hopmi_wn_layer_fwd")
+                                                   1 if do_gcn else 0, st), exact=True, extra=extra), "hopmi_wn_layer_fwd")
     if bn is not None:
         _lib.check(L.hopmi_wn_bn_finalize(ws.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
                                           float(momentum), float(eps), scsh_out.data_ptr(), mean_rstd.data_ptr(),

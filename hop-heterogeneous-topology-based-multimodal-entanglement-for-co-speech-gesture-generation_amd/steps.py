@@ -91,13 +91,20 @@ def _regularisers(args, outputs, z_context, z_mu, z_logvar, out_rand, z_rand):
     return div_reg, kld
 
 
+_CAPTURE = None     # a graph._Capture while a training-step graph is being recorded (see graph.GraphedTrainStep)
+
+
 class _LossFetch:
     """The step's single device->host transfer, started as soon as every loss term exists (i.e. BEFORE the generator
     backward and the optimizer step are enqueued) into pinned memory, and waited for at the end of the step.  The
     values are the same floats; the host just no longer waits for the backward / optimizer kernels before it returns,
     so it issues the next step while the device finishes this one (the reference's `.item()` calls drain the device
     up to five times per step, train_llm.py:88-96).  The status words of persistent GRU launches ride along: those of
-    this step's forwards and of the PREVIOUS step's backward, so a hand-off time-out surfaces at most one step late."""
+    this step's forwards and of the PREVIOUS step's backward, so a hand-off time-out surfaces at most one step late.
+
+    While a step graph is being captured (`_CAPTURE`), the copy goes into the capture's pinned buffer and the graph is
+    cut right behind it: a replay waits for that cut's event only, decodes with `decode()`, and returns while the
+    backward / optimizer segment still runs."""
 
     def __init__(self, args, gan, huber, kld, div_reg, gen_error, dis_error):
         terms = [("loss", args.loss_regression_weight, huber)]
@@ -107,35 +114,48 @@ class _LossFetch:
             terms.append(("DIV_REG", args.loss_reg_weight, div_reg))
         if gan:
             terms += [("gen", args.loss_gan_weight, gen_error), ("dis", 1.0, dis_error)]
-        self.terms = terms
+        self.terms = [(k, w) for k, w, _ in terms]
         stacked = [t.detach().float().reshape(()) for _, _, t in terms]
-        self.status = _ops.deferred_status() if stacked[0].is_cuda else None    # persistent-kernel hand-off status words
+        cap = _CAPTURE
+        if cap is not None:
+            self.status = cap.take_status()
+        else:
+            self.status = _ops.deferred_status() if stacked[0].is_cuda else None    # persistent-kernel hand-off status words
         if self.status is not None:
-            stacked.append(self.status.to(stacked[0].device))
+            stacked.append(self.status.to(stacked[0].device).float().reshape(()))
         dev = torch.stack(stacked)
-        if dev.is_cuda:
+        if cap is not None:
+            self.host, self.event = cap.fetch_into(self, dev), None
+        elif dev.is_cuda:
             self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
             self.host.copy_(dev, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record()
         else:
             self.host, self.event = dev, None
+        self.captured = cap is not None
 
-    def result(self):
+    @staticmethod
+    def decode(terms, vals, has_status):
         """train_llm.py:88-98.  `if kld:` / `if div_reg:` in the reference are truthiness tests on the tensors: a term
         that is exactly 0.0 is left out."""
-        if self.event is not None:
-            self.event.synchronize()
-        vals = self.host.tolist()
-        if self.status is not None and vals.pop() != 0.0:
+        vals = list(vals)
+        if has_status and vals.pop() != 0.0:
             raise RuntimeError("hopmi: a persistent GRU kernel timed out waiting for a hand-off; "
                                "set HOPMI_GRU_PERSISTENT=0 to use per-time-step launches")
         ret = {}
-        for (k, wgt, _), v in zip(self.terms, vals):
+        for (k, wgt), v in zip(terms, vals):
             if k in ("KLD", "DIV_REG") and v == 0.0:
                 continue
             ret[k] = wgt * v
         return ret
+
+    def result(self):
+        if self.captured:                      # nothing has run yet: the replay decodes (graph.GraphedTrainStep)
+            return {}
+        if self.event is not None:
+            self.event.synchronize()
+        return self.decode(self.terms, self.host.tolist(), self.status is not None)
 
 
 def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,

@@ -394,4 +394,4 @@ def train_llm_step(args, cfg, epoch, batch, g_sd: SD, d_sd: SD, g_optim, d_optim
     if gan:
         ret["gen"] = args.loss_gan_weight * gen_error.item()
         ret["dis"] = dis_error.item()
-    return ret, outputs.detach(), z_mu.detach(), z_logvar.detach()
+    return ret, outputs.detach(), z_mu.detach(), z_logvar.detach(), out_rand.detach()

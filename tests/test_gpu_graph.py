@@ -1,0 +1,180 @@
+"""hopmi.GraphedTrainStep (the recorded hipGraphs of train_llm) against steps.train_llm itself, on the device."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _pair(V, dev):
+    import hopmi
+    from transformers import BertModel
+    from oracle import fill
+    from oracle.golden_util import SynthTok, SynthVocab, hop_cfg, tiny_bert_config
+    bcfg = tiny_bert_config()
+    m = hopmi.Model(hop_cfg(V, bcfg.hidden_size), BertModel(bcfg), SynthTok(), SynthVocab(11)).float()
+    m.reprogramming_layer.dropout.p = 0.0
+    fill.fill_state_(m)
+    m._randn_like = lambda t: torch.full_like(t, 0.25)               # capturable, deterministic speaker sample
+    d = hopmi.ConvDiscriminator(3 * V)
+    d.gru.dropout = 0.0
+    fill.fill_state_(d, salt=1)
+    inp = fill.hot_path_inputs(2, V, bcfg.vocab_size, 11)
+    return m.to(dev).train(), d.to(dev).train(), {k: v.to(dev) for k, v in inp.items()}
+
+
+def _deterministic_draws(monkeypatch):
+    from hopmi import steps
+    monkeypatch.setattr(steps, "_randn_like", lambda t: torch.full_like(t, 0.5))
+    monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.arange(n - 1, -1, -1, device=device))
+
+
+@pytest.mark.parametrize("V,epoch", [(9, 0), (9, 11), (42, 11)])
+def test_graphed_step_equals_eager(V, epoch, monkeypatch):
+    """Five steps: train_llm itself on one copy, GraphedTrainStep (2 eager calls, 1 capture + replay, 2 replays) on the
+    other, dropout off and the random draws replaced by constants: same loss dicts and same parameters after every step
+    (the recorded step differs only in who forms the mapping layer's weight gradient and in Adam's capturable form)."""
+    import hopmi
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m1, d1, inp = _pair(V, dev)
+    m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
+    m2._randn_like = m1._randn_like
+    mk = lambda m, d: (torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999)),
+                       torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999)))
+    g1, o1 = mk(m1, d1)
+    g2, o2 = mk(m2, d2)
+    args = step_args(V)
+    batch = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"], inp["vid_indices"])
+    graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, eager_calls=2)
+    for it in range(5):
+        want = hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, Accel())
+        got = graphed(epoch, *batch)
+        assert sorted(got) == sorted(want), (it, got, want)
+        for k in want:
+            assert abs(got[k] - want[k]) <= 2e-4 * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])   # (Adam noise, see below)
+    assert len(graphed.records) == 1
+    for (n, a), (_, b) in zip(list(m1.named_parameters()) + list(d1.named_parameters()),
+                              list(m2.named_parameters()) + list(d2.named_parameters())):
+        # Adam turns rounding-level gradient differences of analytically-zero gradients into +-lr steps: 5 steps of 1e-3
+        assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1.0) + (1.1e-2 if "bias" in n else 0.0), n
+    for (n, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
+        if a.is_floating_point():
+            # (a bias in front of a training-mode BatchNorm has an analytically zero gradient: Adam moves it by +-lr per
+            # step on rounding noise, DESIGN.md 2, and it shifts that BatchNorm's batch mean by as much)
+            slack = 6e-3 if n.endswith("running_mean") else 0.0
+            assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1.0) + slack, n
+        else:
+            assert torch.equal(a, b), n
+
+
+def test_graphed_step_new_batches_and_other_shapes(monkeypatch):
+    """Replays read the batch from static buffers (a new batch of the recorded shape is copied in), another batch size
+    falls back to the eager step, and both keep training the same model."""
+    import hopmi
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m1, d1, inp = _pair(9, dev)
+    m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
+    m2._randn_like = m1._randn_like
+    mk = lambda m, d: (torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999)),
+                       torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999)))
+    g1, o1 = mk(m1, d1)
+    g2, o2 = mk(m2, d2)
+    args = step_args(9)
+    graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, eager_calls=1)
+    names = ("in_audio", "log_melspec", "text", "target_dir_vec", "vid_indices")
+    gen = torch.Generator().manual_seed(5)
+    for it in range(5):
+        if it == 3:                                   # a short batch
+            b = tuple(inp[k][:1].clone() for k in names)
+        else:                                         # fresh tensors of the recorded shape
+            b = tuple((inp[k] + 0.01 * it * torch.randn(inp[k].shape, generator=gen).to(dev)) if inp[k].is_floating_point()
+                      else inp[k].roll(it, 0) for k in names)
+        want = hopmi.train_llm(args, 0, *b, m1, d1, g1, o1, Accel())
+        got = graphed(0, *b)
+        for k in want:
+            assert abs(got[k] - want[k]) <= 2e-4 * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])   # (Adam noise, see below)
+    assert len(graphed.records) == 1
+
+
+def test_seed_word_advances_dropout_masks():
+    """The seeded kernels add *ops.SEED_DEV to their seed: same word -> same mask, another word -> another mask, and the
+    backward regenerates the forward's mask (gradient of sum(o) w.r.t. v counts the kept keys)."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(2, 34, 8, 128, generator=g).to(dev)
+    k = torch.randn(96, 8, 128, generator=g).to(dev)
+    v = torch.randn(96, 8, 128, generator=g).to(dev)
+    prev = ops.SEED_DEV
+    try:
+        ops.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+        a = ops.reprog_attention(q, k, v, 0.1, 0.3, 1234)
+        ops.SEED_DEV = None
+        a0 = ops.reprog_attention(q, k, v, 0.1, 0.3, 1234)
+        assert torch.equal(a, a0)                                      # word 0 == no word
+        ops.SEED_DEV = torch.full((1,), 77, dtype=torch.int64, device=dev)
+        b = ops.reprog_attention(q, k, v, 0.1, 0.3, 1234)
+        b2 = ops.reprog_attention(q, k, v, 0.1, 0.3, 1234)
+        c = ops.reprog_attention(q, k, v, 0.1, 0.3, 1234 + 77)
+        assert torch.equal(b, b2) and not torch.equal(a, b)
+        ops.SEED_DEV = None
+        c0 = ops.reprog_attention(q, k, v, 0.1, 0.3, 1234 + 77)
+        assert torch.equal(b, c0)                                      # seed + word is what is hashed
+        # BERT epilogue + attention honour the word as well
+        x = torch.randn(40, 768, generator=g).to(dev)
+        res = torch.randn(40, 768, generator=g).to(dev)
+        one, zero = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+        e0 = ops.bias_dropout_residual_layernorm(x, zero, res, one, zero, 1e-12, 0.2, 9)
+        ops.SEED_DEV = torch.full((1,), 5, dtype=torch.int64, device=dev)
+        e1 = ops.bias_dropout_residual_layernorm(x, zero, res, one, zero, 1e-12, 0.2, 9)
+        ops.SEED_DEV = None
+        e2 = ops.bias_dropout_residual_layernorm(x, zero, res, one, zero, 1e-12, 0.2, 14)
+        assert not torch.equal(e0, e1) and torch.equal(e1, e2)
+        qkv = torch.randn(2, 34, 3, 12, 64, generator=g).to(dev)
+        f0 = ops.bert_attention(qkv, 0.2, 3)
+        ops.SEED_DEV = torch.full((1,), 8, dtype=torch.int64, device=dev)
+        f1 = ops.bert_attention(qkv, 0.2, 3)
+        ops.SEED_DEV = None
+        f2 = ops.bert_attention(qkv, 0.2, 11)
+        assert not torch.equal(f0, f1) and torch.equal(f1, f2)
+        # backward regenerates the forward's mask under a non-zero word
+        ops.SEED_DEV = torch.full((1,), 31, dtype=torch.int64, device=dev)
+        qq, vv = q.clone().requires_grad_(), v.clone().requires_grad_()
+        o = ops.reprog_attention(qq, k, vv, 0.1, 0.3, 99)
+        o.sum().backward()
+        ops.SEED_DEV = None
+        qq2, vv2 = q.clone().requires_grad_(), v.clone().requires_grad_()
+        o2 = ops.reprog_attention(qq2, k, vv2, 0.1, 0.3, 99 + 31)
+        o2.sum().backward()
+        assert torch.equal(o, o2) and torch.equal(vv.grad, vv2.grad) and torch.equal(qq.grad, qq2.grad)
+    finally:
+        ops.SEED_DEV = prev
+
+
+def test_graphed_step_dropout_advances(monkeypatch):
+    """With dropout on, consecutive replays of the recorded step draw different masks: at learning rate 0 (weights and
+    batch fixed) the loss still changes from replay to replay, and stays finite."""
+    import hopmi
+    from oracle.golden_util import step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m, d, inp = _pair(9, dev)
+    m.reprogramming_layer.dropout.p = 0.3
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=0.0, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(d.parameters(), lr=0.0, betas=(0.5, 0.999))
+    graphed = hopmi.GraphedTrainStep(step_args(9), m, d, g_opt, d_opt, eager_calls=1)
+    batch = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"], inp["vid_indices"])
+    # BatchNorm running statistics move, but training-mode forwards do not read them: only the masks change the loss
+    losses = [graphed(0, *batch)["loss"] for _ in range(6)]
+    assert all(l == l and abs(l) < 1e9 for l in losses)
+    assert len(set(losses[1:])) >= 4, losses
