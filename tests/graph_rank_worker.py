@@ -1,0 +1,78 @@
+"""Worker of tests/test_gpu_graph.py::test_graphed_exchange_two_ranks_one_gpu (launched by torch.distributed.run, every
+rank on cuda:0, gloo collectives): per rank, 4 training steps through hopmi.GraphedTrainStep with the N > 1 recording
+(prototype rows sharded, flat gradient all-reduces between graph launches) and, on a second copy of the models, the
+same steps through steps.train_llm + GradSync (the hook-driven bucketed exchange); prints one JSON line per rank."""
+import copy
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    os.environ["HOPMI_REHEARSE_ONE_GPU"] = "1"          # shared device: no persistent GRU launches
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    import hopmi
+    from hopmi import steps
+    from hopmi.parallel import GradSync
+    from oracle.golden_util import step_args
+    from test_gpu_graph import _pair
+    epoch = int(sys.argv[1])
+    steps._randn_like = lambda t: torch.full_like(t, 0.5)
+    steps._randperm = lambda n, device: torch.arange(n - 1, -1, -1, device=device)
+    m1, d1, inp = _pair(9, dev)
+    # a different batch per rank (same replicas)
+    names = ("in_audio", "log_melspec", "text", "target_dir_vec", "vid_indices")
+    batch = tuple((inp[k] * (1.0 + 0.25 * rank)) if inp[k].is_floating_point() else inp[k].roll(rank, 0) for k in names)
+    m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
+    m2._randn_like = m1._randn_like
+    mk = lambda m, d: (torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999)),
+                       torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999)))
+    g1, o1 = mk(m1, d1)
+    g2, o2 = mk(m2, d2)
+    args = step_args(9)
+    sync1 = GradSync([m1, d1], bucket_mb=0.25)
+    sync2 = GradSync([m2, d2], bucket_mb=0.25)
+    graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, accelerator=sync2, eager_calls=1, group=dist.group.WORLD)
+    losses1, losses2 = [], []
+    for it in range(4):
+        losses1.append(hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, sync1))
+        losses2.append(graphed(epoch, *batch))
+    sharded_before = bool(graphed.sharded)
+    own = (graphed.r0, graphed.r1)
+    # rows this rank does not own have not moved since the recording began; unshard() fetches them from their owners
+    stale = (m2.mapping_layer.weight - m1.mapping_layer.weight).abs().max().item()
+    graphed.unshard()
+    worst = {}
+    # biases in front of a training-mode BatchNorm / the key-projection bias have analytically zero gradients: Adam moves
+    # them by +-lr per step on rounding noise, on every element -- only their max is bounded
+    noise = lambda n: n.endswith("mlp.mlp.bias") or n in ("pre_conv.0.bias", "pre_conv.3.bias") or n.endswith("key_projection.bias")
+    for (n, a), (_, b) in zip(list(m1.named_parameters()) + list(d1.named_parameters()),
+                              list(m2.named_parameters()) + list(d2.named_parameters())):
+        diff = (a - b).abs()
+        worst[n] = (diff.max().item(), diff.mean().item())
+    # replicas must agree across ranks after the exchange: checksum of every parameter, all-gathered
+    cs = torch.tensor([p.double().sum().item() for p in list(m2.parameters()) + list(d2.parameters())], dtype=torch.float64)
+    allcs = [torch.empty_like(cs) for _ in range(world)]
+    dist.all_gather(allcs, cs)
+    spread = max((c - allcs[0]).abs().max().item() for c in allcs)
+    print("RANKJSON " + json.dumps(dict(rank=rank, losses_eager=losses1, losses_graph=losses2, sharded=sharded_before, own=own,
+                                        stale_before_unshard=stale, n_plan=[k for k, _ in next(iter(graphed.records.values()))["cap"].plan],
+                                        worst_max=max(v[0] for v in worst.values()), worst_mean=max(v[1] for k, v in worst.items() if not noise(k)),
+                                        worst_mean_name=max((k for k in worst if not noise(k)), key=lambda k: worst[k][1]),
+                                        worst_name=max(worst, key=lambda k: worst[k][0]), replica_spread=spread)), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

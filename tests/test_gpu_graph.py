@@ -178,3 +178,34 @@ def test_graphed_step_dropout_advances(monkeypatch):
     losses = [graphed(0, *batch)["loss"] for _ in range(6)]
     assert all(l == l and abs(l) < 1e9 for l in losses)
     assert len(set(losses[1:])) >= 4, losses
+
+
+@pytest.mark.parametrize("epoch", [0, 11])
+def test_graphed_exchange_two_ranks_one_gpu(epoch):
+    """The N > 1 recording (prototype rows sharded over ranks, S all-gathered, dS + the other gradients all-reduced by
+    eager collectives between graph launches) with two ranks sharing cuda:0 over gloo, against the hook-driven GradSync
+    exchange under steps.train_llm on copies of the same models: same losses every step, same parameters after
+    unshard(), and identical replicas across the ranks (tests/graph_rank_worker.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + epoch), os.path.join(root, "tests", "graph_rank_worker.py"), str(epoch)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rows = [json.loads(l.split("RANKJSON ", 1)[1]) for l in r.stdout.splitlines() if "RANKJSON " in l]
+    assert len(rows) == 2, r.stdout[-2000:]
+    for row in rows:
+        assert row["sharded"] and row["own"] in ([0, 750], [750, 1500]), row
+        assert "eager" in row["n_plan"] and row["n_plan"].count("graph") >= 4, row["n_plan"]
+        assert row["stale_before_unshard"] > 1e-4                       # the other rank's rows really were not updated here
+        for a, b in zip(row["losses_eager"], row["losses_graph"]):
+            assert sorted(a) == sorted(b)
+            for k in a:
+                assert abs(a[k] - b[k]) <= 2e-4 * max(abs(a[k]), 1e-6), (k, a[k], b[k])
+        # elements whose gradient is at rounding level may take a +-lr Adam step the other way (4 steps of 1e-3)
+        assert row["worst_max"] <= 8.5e-3 and row["worst_mean"] <= 5e-5, row
+        assert row["replica_spread"] <= 1e-6, row
