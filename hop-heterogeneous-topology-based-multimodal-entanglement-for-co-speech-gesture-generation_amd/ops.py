@@ -90,6 +90,13 @@ def _timed(name, nbytes, flops, fn, exact=False, extra=0):
     return TIMER.launch_exact(name, nbytes, flops, fn, extra) if exact else TIMER.launch(name, nbytes, flops, fn, extra)
 
 
+def time_noop_launch():
+    """Launch an empty kernel through the timer's exact path (when a KernelTimer is active): its reported duration is
+    the floor of the dispatch-event timing method, recorded next to the kernels it is compared with."""
+    L, st = _lib.lib(), _stream()
+    _lib.check(_timed("noop", 0, 0, lambda: L.hopmi_noop_launch(st), exact=True), "hopmi_noop_launch")
+
+
 def gcn_algorithmic_bytes(n_slabs: int, V: int) -> int:
     """read x' + write h = 2*64*V*4 B per slab, plus the per-launch constants
     (A: V*V*4 B twice, Wm+bm: 49 408 B)."""
@@ -419,14 +426,43 @@ def _conv_w(w):
     return w.data_ptr()
 
 
-def wn_layer_fwd(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, utail, dilation, *, want_y=True, want_fs=False,
-                 do_gcn=True, bn=None, stats_keep=None):
+def wn_prepare_weights(layers):
+    """Split-bf16 MFMA weight images of the fused WaveNet layers (hopmi_wn_prepare_weights): `layers` = a sequence of
+    (filter_conv.weight, gate_conv.weight, gconv.mlp.mlp.weight) per layer; one launch for all of them, once per forward
+    pass.  Returns a (n_layers, bytes) uint8 tensor; row l is layer l's image (`wimg` of wn_layer_fwd / wn_layer_bwd)."""
+    import ctypes
+    n = len(layers)
+    L = _lib.lib()
+    per = L.hopmi_wn_weight_image_bytes(1)
+    if n < 1 or L.hopmi_wn_weight_image_bytes(n) == 0:
+        raise _lib.HopmiError(f"hopmi wn_prepare_weights: {n} layers unsupported")
+    dev = layers[0][0].device
+    img = torch.empty(n, per, dtype=torch.uint8, device=dev)
+    tabs = []
+    for k in range(3):
+        ptrs = []
+        for l in range(n):
+            t = layers[l][k]
+            if k < 2:
+                ptrs.append(_conv_w(t))
+            else:
+                if t.numel() != 64 * 192 or not t.is_contiguous() or t.dtype != torch.float32:
+                    raise _lib.HopmiError(f"hopmi wn_prepare_weights: Wm must be a contiguous float32 (64,192[,1,1]) tensor, got {tuple(t.shape)}")
+                ptrs.append(t.data_ptr())
+        tabs.append((ctypes.c_void_p * n)(*ptrs))
+    _lib.check(L.hopmi_wn_prepare_weights(tabs[0], tabs[1], tabs[2], n, img.data_ptr(), _stream()), "hopmi_wn_prepare_weights")
+    return img
+
+
+def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_y=True, want_fs=False,
+                 do_gcn=True, bn=None, stats_keep=None, timer_name="wn_layer_fwd"):
     """One fused WaveNet layer (hopmi_wn_layer_fwd).  No autograd here: the differentiable wrapper is the
-    stack-level Function.  xin (B,T_in,V,64) contiguous; utail: a (B,4,V,64) view whose last-dim stride
-    is 1 (a channel slice of the (B,4,V,512) skip-tail buffer).  bn = (gamma, beta, running_mean,
-    running_var, momentum, eps) for training-mode batch statistics -> returns scale/shift for the next
+    stack-level Function.  xin (B,T_in,V,64) contiguous; wimg: this layer's row of wn_prepare_weights(); utail: a
+    (B,4,V,64) view whose last-dim stride is 1 (a channel slice of the (B,4,V,512) skip-tail buffer).  bn = (gamma, beta,
+    running_mean, running_var, momentum, eps) for training-mode batch statistics -> returns scale/shift for the next
     layer and (mean, rstd).  `stats_keep`: a list that receives (partial-sum workspace, B, T_in, V, dilation) so
-    that the same running-statistics update can be applied again (wn_bn_replay).  Returns (y, fs, scsh_out, mean_rstd)."""
+    that the same running-statistics update can be applied again (wn_bn_replay).  `want_fs` (diagnostic): also return the
+    tanh / sigmoid gate values.  Returns (y, fs, scsh_out, mean_rstd)."""
     B, T_in, V, _ = xin.shape
     T_out = T_in - dilation
     dev = xin.device
@@ -441,18 +477,20 @@ def wn_layer_fwd(xin, scsh_in, wf, wg, bf, bg, prep, Wm, bm, utail, dilation, *,
         scsh_out = torch.empty(128, dtype=torch.float32, device=dev)
         mean_rstd = torch.empty(128, dtype=torch.float32, device=dev)
         ws = torch.empty(L.hopmi_wn_layer_ws_floats(B, T_in, V, dilation), dtype=torch.float32, device=dev)
-    if utail.stride(-1) != 1 or utail.stride(2) % 4 or utail.shape != (B, 4, V, 64):
+    if utail is not None and (utail.stride(-1) != 1 or utail.stride(2) % 4 or utail.shape != (B, 4, V, 64)):
         raise _lib.HopmiError(f"hopmi wn_layer: bad utail view {tuple(utail.shape)} strides {utail.stride()}")
+    if wimg.dtype != torch.uint8 or wimg.numel() != L.hopmi_wn_weight_image_bytes(1) or not wimg.is_contiguous():
+        raise _lib.HopmiError("hopmi wn_layer: `wimg` is not one layer's row of wn_prepare_weights()")
     st = _stream()
     n_out = B * T_out * V
-    # SURVEY.md 8(d), fused layer: x in + x out + the last-4-frames skip tail; the saved gates are not algorithmic
-    nbytes = 4 * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + B * 4 * V * 64)
+    # SURVEY.md 8(d), fused layer: x in + x out + the last-4-frames skip tail (+ the per-launch weight image)
+    nbytes = 4 * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + (B * 4 * V * 64 if utail is not None else 0))
     extra = 4 * n_out * 128 * (1 if want_fs else 0)
     flops = n_out * (2 * 2 * 2 * 64 * 64 + (2 * 192 * 64 + 4 * 64 * V if do_gcn else 0))
-    _lib.check(_timed("wn_layer_fwd", nbytes, flops,
-                      lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), _conv_w(wf), _conv_w(wg), bf.data_ptr(), bg.data_ptr(),
-                                                   _ptr(prep), _ptr(Wm), _ptr(bm), _ptr(y), _ptr(fs), utail.data_ptr(),
-                                                   utail.stride(2), _ptr(ws), B, T_in, V, dilation,
+    _lib.check(_timed(timer_name, nbytes, flops,
+                      lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), wimg.data_ptr(), bf.data_ptr(), bg.data_ptr(),
+                                                   _ptr(prep), _ptr(bm), _ptr(y), _ptr(fs), _ptr(utail),
+                                                   utail.stride(2) if utail is not None else 64, _ptr(ws), B, T_in, V, dilation,
                                                    1 if do_gcn else 0, st), exact=True, extra=extra), "hopmi_wn_layer_fwd")
     if bn is not None:
         _lib.check(L.hopmi_wn_bn_finalize(ws.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),

@@ -44,6 +44,9 @@ void hopmi_reload_env(void);
  * layer kernel (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps, what a profiler's
  * kernel trace reports), then the hook clears itself.  Pass NULLs to clear.  bench.py uses it for the live roofline. */
 int hopmi_time_next_launch(void* start_event, void* stop_event);
+/* An empty kernel launched with a WaveNet-layer kernel's shape; honours hopmi_time_next_launch.  Its measured duration is
+ * the floor of the dispatch-event timing method (~3.9 us on MI355X / ROCm 7.2; tools/probes/launch_floor.hip). */
+int hopmi_noop_launch(void* stream);
 
 /* ---- graph convolution: model/gwnet.py:24-46 (gcn.forward) + :8-14 (nconv) + :16-22 (linear)
  *
@@ -74,6 +77,22 @@ int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const floa
                   float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
                   int n_slabs, int V, void* stream);
 
+/* ---- weight images of the fused WaveNet layers (once per forward pass, all layers in one launch)
+ *
+ * The two channel contractions of a layer (gated TCN, gwnet.py:186-200; graph-conv mlp, gwnet.py:44-46) run as
+ * three-term split-bf16 products on v_mfma_f32_16x16x32_bf16: a = a_hi + a_lo (two bf16 numbers, 2^-17 relative),
+ * a b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo, fp32 accumulation -- fp32-class accuracy (~1.5e-5 per product, inside the
+ * 1e-3 bar with two orders of margin) at 5.3x the rate of the exact-fp32 MFMA.  hopmi_wn_prepare_weights splits the
+ * layers' weights into the MFMA A-operand fragments a wave loads:
+ *   wf[l], wg[l]  [64][64][1][2]  filter_convs[l].weight / gate_convs[l].weight exactly as nn.Conv2d holds them
+ *   Wm[l]         [64][192]       gconv[l].mlp.mlp.weight
+ *   image         hopmi_wn_weight_image_bytes(n_layers) bytes (112 KiB per layer); layer l's image starts at
+ *                 l * hopmi_wn_weight_image_bytes(1).
+ * wf / wg / Wm are HOST arrays of n_layers device pointers (n_layers <= 8). */
+size_t hopmi_wn_weight_image_bytes(int n_layers);
+int hopmi_wn_prepare_weights(const float* const* wf, const float* const* wg, const float* const* Wm, int n_layers,
+                             void* image, void* stream);
+
 /* ---- one fused WaveNet layer, forward: model/gwnet.py:181-237 (gated dilated TCN :186-200, the part of
  *      the skip path that reaches the output :209-220, graph conv :224-231, residual :233, BatchNorm2d
  *      batch statistics :237).  Activations channels-last [B][T][V][64].
@@ -81,18 +100,18 @@ int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const floa
  *   xin      [B][T_in][V][64]  previous layer's PRE-BatchNorm output (or the start-conv output)
  *   scsh_in  [128]             scale[64], shift[64] applied to xin on load (previous layer's BatchNorm as
  *                              an affine map; ones / zeros for the first layer)
- *   wf, wg   [64][64][1][2]    filter_convs[i].weight / gate_convs[i].weight exactly as nn.Conv2d holds them
- *                              ([out][in][1][tap], tap 1 reads frame t + dilation);  bf, bg [64] their biases
- *   prep, Wm, bm               as hopmi_gcn_fwd (used when do_gcn)
+ *   wimg                       this layer's weight image (hopmi_wn_prepare_weights);  bf, bg [64] the TCN biases
+ *   prep, bm                   as hopmi_gcn_fwd (used when do_gcn)
  *   y        [B][T_out][V][64] gcn(u) + bm + r^[t+d], pre-BatchNorm (nullable; T_out = T_in - dilation)
- *   fs       [B][T_out][V][128] tanh and sigmoid gate values saved for the backward (nullable)
- *   utail    u of the last 4 frames, row (b, f, v) at utail[((b*4 + f)*V + v)*utail_ld .. +64]
+ *   fs       [B][T_out][V][128] tanh and sigmoid gate values (nullable).  The training forward does not store them: the
+ *            backward regenerates them per layer with a gate-only call (do_gcn = 0, y = utail = NULL, fs given)
+ *   utail    u of the last 4 frames, row (b, f, v) at utail[((b*4 + f)*V + v)*utail_ld .. +64] (nullable: not stored)
  *   ws       nullable; hopmi_wn_layer_ws_floats(...) floats receiving per-workgroup sum / sum-of-squares of y
  *            (training-mode BatchNorm statistics, do_gcn only), to be finalised by hopmi_wn_bn_finalize.
  */
 size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation);
-int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const float* wf, const float* wg, const float* bf,
-                       const float* bg, const float* prep, const float* Wm, const float* bm, float* y, float* fs, float* utail,
+int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const void* wimg, const float* bf, const float* bg,
+                       const float* prep, const float* bm, float* y, float* fs, float* utail,
                        int utail_ld, float* ws, int B, int T_in, int V, int dilation, int do_gcn, void* stream);
 
 /* BatchNorm2d training-mode finalisation (gwnet.py:237) from the partials of the layer call with the same

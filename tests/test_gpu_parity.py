@@ -937,8 +937,10 @@ def test_gradsync_on_rccl_single_rank_group(monkeypatch):
         for (n, a), (_, b) in zip(list(m1.named_parameters()) + list(d1.named_parameters()),
                                   list(m2.named_parameters()) + list(d2.named_parameters())):
             # an element whose gradient is at rounding level may step the other way: <= 2 lr per step for few elements
+            # (for every element of the analytically-zero-gradient biases)
             diff = (a - b).abs()
-            assert diff.max().item() <= 6.5e-3 and diff.mean().item() <= 5e-5, (n, diff.max().item(), diff.mean().item())
+            assert diff.max().item() <= 6.5e-3, (n, diff.max().item())
+            assert _zero_grad_param(n) or diff.mean().item() <= 5e-5, (n, diff.mean().item())
     finally:
         dist.destroy_process_group()
 

@@ -3,8 +3,10 @@
 
     python tools/bench_wn.py [--V 9 --B 128] [--iters 200] [--saves]
 
-Per layer i (T_in = 16,15,13,12,10,9,7,6; dilation 1,2,...): back-to-back launches between two HIP events on
-the launch stream; reports algorithmic GB/s and fp32 TFLOP/s.  HOPMI_WN_GRID / HOPMI_WN_MAXMT
+Per layer i (T_in = 16,15,13,12,10,9,7,6; dilation 1,2,...): (a) the dispatch's own begin/end timestamps
+(hopmi_time_next_launch, median over --iters launches: what rocprofv3's kernel trace reports and bench.py's roofline
+uses) and (b) back-to-back launches between two HIP events (includes the ~1.5 us dependent-launch boundary); reports
+algorithmic GB/s (x in + y out + skip tail) and fp32-equivalent TFLOP/s.  HOPMI_WN_GRID / HOPMI_WN_MAXMT
 select the tile geometry for experiments."""
 import argparse
 import os
@@ -25,7 +27,7 @@ def main():
     ap.add_argument("--V", type=int, default=9)
     ap.add_argument("--B", type=int, default=128)
     ap.add_argument("--iters", type=int, default=200)
-    ap.add_argument("--saves", action="store_true", help="also write the saved gates (training forward)")
+    ap.add_argument("--saves", action="store_true", help="also write the gate values (diagnostic output)")
     ap.add_argument("--warm", type=float, default=2.0)
     ap.add_argument("--lib", default=None, help="alternative libhopmi.so (A/B runs)")
     a = ap.parse_args()
@@ -49,7 +51,8 @@ def main():
         torch.cuda.synchronize()
     L = hopmi._lib.lib()
     st = torch.cuda.current_stream().cuda_stream
-    tot_t = tot_b = tot_f = 0.0
+    wimg = ops.wn_prepare_weights([(wf, wg, Wm)])[0]
+    tot_t = tot_b = tot_f = tot_k = 0.0
     T_in = 16
     for li, d in enumerate(DIL):
         T_out = T_in - d
@@ -60,11 +63,11 @@ def main():
         tails = torch.empty(a.B, 4, a.V, 512, device=dev)
         ut = tails[..., 64 * li:64 * li + 64]
         ws = torch.empty(L.hopmi_wn_layer_ws_floats(a.B, T_in, a.V, d), device=dev)
-        fn = lambda: L.hopmi_wn_layer_fwd(x.data_ptr(), scsh.data_ptr(), wf.data_ptr(), wg.data_ptr(), bf.data_ptr(), bg.data_ptr(), prep.data_ptr(),
-                                          Wm.data_ptr(), bm.data_ptr(), y.data_ptr(), fs.data_ptr() if a.saves else None,
+        fn = lambda: L.hopmi_wn_layer_fwd(x.data_ptr(), scsh.data_ptr(), wimg.data_ptr(), bf.data_ptr(), bg.data_ptr(), prep.data_ptr(),
+                                          bm.data_ptr(), y.data_ptr(), fs.data_ptr() if a.saves else None,
                                           ut.data_ptr(), ut.stride(2), ws.data_ptr(), a.B, T_in, a.V, d, do_gcn, st)
         n_out = a.B * T_out * a.V
-        nbytes = 4 * 64 * (a.B * T_in * a.V + n_out * (3 if a.saves else 1) + 4 * a.B * a.V)
+        nbytes = 4 * 64 * (a.B * T_in * a.V + n_out + 4 * a.B * a.V)
         flops = n_out * (2 * 2 * 2 * 64 * 64 + 2 * 192 * 64 + 4 * 64 * a.V)
         for _ in range(10):
             hopmi._lib.check(fn(), "wn_layer_fwd")
@@ -75,11 +78,22 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.iters
-        print(f"layer {li} T_in={T_in:2d} d={d}: {us:7.2f} us  {nbytes / us / 1e3:7.1f} GB/s  {flops / us / 1e6:6.1f} TF", flush=True)
-        tot_t += us; tot_b += nbytes; tot_f += flops
+        durs = []
+        for _ in range(min(a.iters, 50)):
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k0.record(); k1.record()
+            L.hopmi_time_next_launch(k0.cuda_event, k1.cuda_event)
+            fn()
+            durs.append((k0, k1))
+        torch.cuda.synchronize()
+        ds = sorted(k0.elapsed_time(k1) * 1e3 for k0, k1 in durs)
+        kus = ds[len(ds) // 2]
+        print(f"layer {li} T_in={T_in:2d} d={d}: kernel {kus:6.2f} us ({nbytes / kus / 1e3:7.1f} GB/s, {flops / kus / 1e6:6.1f} TF)   "
+              f"back-to-back {us:6.2f} us", flush=True)
+        tot_t += us; tot_b += nbytes; tot_f += flops; tot_k += kus
         T_in = T_out
-    print(f"stack: {tot_t:.1f} us  {tot_b / tot_t / 1e3:.1f} GB/s algorithmic ({tot_b / tot_t / 8e6 * 100:.1f} % of 8 TB/s)  "
-          f"{tot_f / tot_t / 1e6:.1f} TF ({tot_f / tot_t / 157.3e6 * 100:.1f} % of the fp32 MFMA peak)")
+    print(f"stack: kernels {tot_k:.1f} us = {tot_b / tot_k / 1e3:.1f} GB/s algorithmic ({tot_b / tot_k / 8e6 * 100:.1f} % of 8 TB/s), "
+          f"{tot_f / tot_k / 1e6:.1f} TF fp32-equivalent; back-to-back {tot_t:.1f} us")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: where does a wn_layer_fwd workgroup spend its time?  Builds libhopmi_stamps.so (-DHOPMI_STAMPS)
-and prints median per-phase s_memtime deltas (100 MHz reference ticks -> ns) of wave 0 of every block."""
+and prints median per-phase s_memtime deltas (shader cycles) of wave 0 of every block."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -19,12 +19,14 @@ def main():
     L = ctypes.CDLL(SO)
     L.hopmi_gcn_prep_floats.restype = ctypes.c_size_t
     L.hopmi_wn_layer_ws_floats.restype = ctypes.c_size_t
+    L.hopmi_wn_weight_image_bytes.restype = ctypes.c_size_t
     dev = torch.device("cuda:0")
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    phases = ["issue x + wt loads", "wait, normalise, LDS, sync", "TCN mfma", "gate, fs stores, Wm issue, sync",
+    phases = ["prologue (weights, mix image, biases)", "x loads, normalise, split, LDS, sync", "TCN mfma", "gate, u stores, sync",
               "tail store, node mix, sync", "contraction mfma", "epilogue stores"]
-    for V, B, T_in, d, grid, mt in ((9, 128, 16, 1, 256, 5), (9, 128, 16, 1, 512, 3), (9, 128, 10, 1, 256, 5), (42, 64, 16, 1, 256, 3)):
+    for V, B, T_in, d, grid, mt in ((9, 128, 16, 1, 256, 5), (9, 128, 6, 2, 256, 5), (9, 128, 16, 1, 512, 3), (42, 64, 16, 1, 256, 3)):
         os.environ["HOPMI_WN_GRID"] = str(grid); os.environ["HOPMI_WN_MAXMT"] = str(mt)
+        L.hopmi_reload_env()
         T_out = T_in - d
         x = torch.randn(B, T_in, V, 64, device=dev); y = torch.empty(B, T_out, V, 64, device=dev)
         fs = torch.empty(B, T_out, V, 128, device=dev); ut = torch.empty(B, 4, V, 64, device=dev)
@@ -37,7 +39,10 @@ def main():
         prep = torch.empty(L.hopmi_gcn_prep_floats(V), device=dev)
         assert L.hopmi_gcn_prepare(P(A), P(A2), P(prep), V, None) == 0
         ws = torch.empty(L.hopmi_wn_layer_ws_floats(B, T_in, V, d), device=dev)
-        args = [P(x), P(scsh), P(wt), P(wt2), P(bt), P(bt2), P(prep), P(W), P(b), P(y), P(fs), P(ut), 64, P(ws), B, T_in, V, d, 1, None]
+        img = torch.empty(L.hopmi_wn_weight_image_bytes(1), dtype=torch.uint8, device=dev)
+        tab = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+        assert L.hopmi_wn_prepare_weights(tab(wt), tab(wt2), tab(W), 1, P(img), None) == 0
+        args = [P(x), P(scsh), P(img), P(bt), P(bt2), P(prep), P(b), P(y), None, P(ut), 64, P(ws), B, T_in, V, d, 1, None]
         for _ in range(3):
             stamps.zero_(); assert L.hopmi_wn_layer_fwd(*args) == 0; torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,13 +51,13 @@ def main():
         e1.record(); torch.cuda.synchronize()
         st = stamps.view(-1, 8).cpu()
         st = st[st[:, 0] > 0]
-        dd = (st[:, 1:8] - st[:, 0:7]).double() * 10.0          # ns
-        span = (st[:, 7].max() - st[:, 0].min()).item() * 10
-        print(f"V={V} B={B} T_in={T_in} grid={grid} maxmt={mt}: {st.shape[0]} blocks; first-start..last-end {span} ns; "
-              f"per-block median {((st[:,7]-st[:,0]).double()*10).median().item():.0f} ns; back-to-back {e0.elapsed_time(e1)*20:.1f} us/launch")
+        dd = (st[:, 1:8] - st[:, 0:7]).double()                 # shader cycles
+        span = (st[:, 7].max() - st[:, 0].min()).item()
+        print(f"V={V} B={B} T_in={T_in} grid={grid} maxmt={mt}: {st.shape[0]} blocks; first-start..last-end {span} cycles; "
+              f"per-block median {((st[:,7]-st[:,0]).double()).median().item():.0f} cycles; back-to-back {e0.elapsed_time(e1)*20:.1f} us/launch")
         for i, p in enumerate(phases):
-            print(f"    {p:34s} median {dd[:, i].median().item():7.0f} ns  max {dd[:, i].max().item():7.0f}")
-        print(f"    block start skew: {(st[:,0].max()-st[:,0].min()).item()*10} ns")
+            print(f"    {p:40s} median {dd[:, i].median().item():7.0f} cycles  max {dd[:, i].max().item():7.0f}")
+        print(f"    block start skew: {(st[:,0].max()-st[:,0].min()).item()} cycles")
 
 if __name__ == "__main__":
     main()
