@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
   float* AT = Gs + g.rows_lds * LDH;               // [KP][ldA]
   float* AB = AT + g.KP * g.ldA;                   // [K2P][ldB]
   float* DG = Hc;                                  // [rows_lds][LDG]  da | dg
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
-  const int V = g.V, c4 = tid & 15;
+  int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: per-wave bases stay in scalar registers
+  int lane = tid & 63, q = lane >> 4, j = lane & 15, c4 = tid & 15;
+  const int V = g.V;
   const int shift4 = L.d * V * 16;
 
   if (do_gcn) {
@@ -99,6 +101,10 @@ __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
   const int ntiles_dA = (g.VP >> 4) * nt_dA;
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    // every address below derives from the lane index: hiding it from the optimiser per iteration keeps the dozens of
+    // loop-invariant address registers from being hoisted out of the loop and held across all phases (they spilled)
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63; q = lane >> 4; j = lane & 15; c4 = tid & 15;
     const int slab0 = tile * g.S;
     const int nsl = min(g.S, L.n_slabs - slab0);
     const int R = nsl * V;
@@ -143,16 +149,18 @@ __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
         tr.v[it] = (rm.tail[it] >= 0 && rm.ok[it]) ? tv : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       __syncthreads();                             // previous tile's LDS fully consumed
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int row = (tid >> 4) + 16 * it;
         if (row < g.rows_lds) {
-          const bool ok = rm.ok[it];
-          *reinterpret_cast<float4*>(R0 + row * LDD + 4 * c4) = ok ? x0r.v[it] : z4;
-          *reinterpret_cast<float4*>(R1 + row * LDD + 4 * c4) = ok ? x1r.v[it] : z4;
-          *reinterpret_cast<float4*>(DY + row * LDD + 4 * c4) = ok ? dyr.v[it] : z4;
-          *reinterpret_cast<float4*>(Hc + row * LDH + 4 * c4) = ok ? ur.v[it] : z4;
+          // (value selects on the components: a select between an array element and a constant aggregate makes hipcc
+          // keep the whole register arrays in scratch and index them through memory)
+          const float m = rm.ok[it] ? 1.f : 0.f;
+          const float4 a0 = x0r.v[it], a1 = x1r.v[it], a2 = dyr.v[it], a3 = ur.v[it];
+          *reinterpret_cast<float4*>(R0 + row * LDD + 4 * c4) = make_float4(m * a0.x, m * a0.y, m * a0.z, m * a0.w);
+          *reinterpret_cast<float4*>(R1 + row * LDD + 4 * c4) = make_float4(m * a1.x, m * a1.y, m * a1.z, m * a1.w);
+          *reinterpret_cast<float4*>(DY + row * LDD + 4 * c4) = make_float4(m * a2.x, m * a2.y, m * a2.z, m * a2.w);
+          *reinterpret_cast<float4*>(Hc + row * LDH + 4 * c4) = make_float4(m * a3.x, m * a3.y, m * a3.z, m * a3.w);
           if (!do_gcn) *reinterpret_cast<float4*>(Gs + row * LDH + 4 * c4) = tr.v[it];      // dU = dutail
         }
       }
