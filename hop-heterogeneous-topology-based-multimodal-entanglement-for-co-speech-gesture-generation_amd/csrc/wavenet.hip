@@ -180,14 +180,16 @@ __device__ __forceinline__ void node_mix2_generic(const float* U, __bf16* Hh, __
 // graph-conv set behind the TCN phase -- so that neither is loop-carried (112-163 VGPRs, no spills).  MULTI = the
 // workgroup walks several tiles (plain loop, loads at the top of every iteration); !MULTI = the grid covers the launch,
 // one tile per workgroup: straight-line code whose first loads are issued before anything else.
-template <int MT, bool MULTI>
+// GCN = false: the gate-only form (TCN + gate, no graph conv: what the backward uses to regenerate the gate values).
+template <int MT, bool MULTI, bool GCN>
 __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
                                                                   const u32x4* __restrict__ wimg,
                                                                   const float* __restrict__ bfp, const float* __restrict__ bgp,
                                                                   const float* __restrict__ prep,
                                                                   const float* __restrict__ bm, float* __restrict__ y,
                                                                   float* __restrict__ fs, float* __restrict__ utail,
-                                                                  float* __restrict__ stats_part, LayerGeom L, int do_gcn, int utail_ld4) {
+                                                                  float* __restrict__ stats_part, LayerGeom L, int utail_ld4) {
+  constexpr int do_gcn = GCN ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HOPMI_STAMP(0);
   const GcnGeom& g = L.g;
@@ -235,16 +237,6 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
       x1r[it] = src4[rm.in0[it] + shift4];
     }
   };
-  // (the tiny mix image goes first: its wait then covers nothing else, and it is in LDS long before the node mix)
-  constexpr int AT_NIT = 3;                        // V <= 48: 48 * 112 / 4 = 1344 float4 <= 3 * 512
-  float4 atr[AT_NIT];
-  const int at_n4 = do_gcn ? (g.KP * g.ldA) >> 2 : 0;
-  {
-    // unconditional (clamped) loads: a conditionally written register array ends up in scratch
-    const float4* ap = reinterpret_cast<const float4*>(do_gcn ? prep : scsh);
-#pragma unroll
-    for (int it = 0; it < AT_NIT; ++it) atr[it] = ap[min(tid + WN_THREADS * it, max(at_n4, 1) - 1)];
-  }
   if (!MULTI) issue_tile(blockIdx.x);
 
   // ---- weights: the wave's split A-operand fragments, straight from the prepared image (L2-resident) ---------------
@@ -278,12 +270,12 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
   f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};   // BatchNorm partial sums of channels 16w + 4q + r
   // the 4 padding rows behind the tile are read by the node mix's K padding (times zero): keep them finite
   for (int idx = tid; idx < 4 * C; idx += WN_THREADS) U[(16 * MT + idx / C) * LDD + idx % C] = 0.f;
-  auto commit_mix_image = [&]() {
-#pragma unroll
-    for (int it = 0; it < AT_NIT; ++it)
-      if (tid + WN_THREADS * it < at_n4) reinterpret_cast<float4*>(AT)[tid + WN_THREADS * it] = atr[it];
-  };
-  commit_mix_image();
+  if (GCN) {
+    // the mix image -> LDS (plain copy loop: a register array staged across the loads ended up in scratch).  Its loads are
+    // the youngest in flight, so the wait also covers the tile's activation loads -- which the commit below needs anyway.
+    const int at_n4 = (g.KP * g.ldA) >> 2;
+    for (int idx = tid; idx < at_n4; idx += WN_THREADS) reinterpret_cast<float4*>(AT)[idx] = reinterpret_cast<const float4*>(prep)[idx];
+  }
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
     HOPMI_STAMP(1);
@@ -516,22 +508,23 @@ static int launch_wn_fwd(const float* xin, const float* scsh, const u32x4* wimg,
   const size_t lds = wn_fwd_lds_bytes(L.g);
   static bool attr_done = false;                         // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      (void)hipGetLastError();
-    }
+    const void* fns[] = {reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, true, true>),
+                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, false, true>),
+                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, true, false>),
+                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, false, false>)};
+    for (const void* fn : fns)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
     attr_done = true;
   }
   const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;      // null unless a measurement asked for this launch
   t_ev_start = t_ev_stop = nullptr;
-  if (L.g.ntiles > grid)
-    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, true>), dim3(grid), dim3(WN_THREADS), lds, st, e0, e1, 0, xin, scsh, wimg, bf, bg,
-                          prep, bm, y, fs, utail, part, L, do_gcn, utail_ld / 4);
-  else
-    hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, false>), dim3(grid), dim3(WN_THREADS), lds, st, e0, e1, 0, xin, scsh, wimg, bf, bg,
-                          prep, bm, y, fs, utail, part, L, do_gcn, utail_ld / 4);
+  const bool multi = L.g.ntiles > grid;
+#define HOPMI_WN_LAUNCH(MULTI_, GCN_)                                                                                          \
+  hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, MULTI_, GCN_>), dim3(grid), dim3(WN_THREADS), lds, st, e0, e1, 0, xin, scsh, wimg, bf, \
+                        bg, prep, bm, y, fs, utail, part, L, utail_ld / 4)
+  if (do_gcn) { if (multi) HOPMI_WN_LAUNCH(true, true); else HOPMI_WN_LAUNCH(false, true); }
+  else { if (multi) HOPMI_WN_LAUNCH(true, false); else HOPMI_WN_LAUNCH(false, false); }
+#undef HOPMI_WN_LAUNCH
   return HOPMI_OK;
 }
 

@@ -1,22 +1,23 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repository root):
-#   1. kernel-trace + stats of the default bench workload
-#   2./3. PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes, no other trace domains) for HBM traffic per launch
+#   1. kernel-trace + stats of the default bench workload (kernel region: 7 eager steps; warm-up + timed region: graph replays)
+#   2./3. PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes, no other trace domains) for HBM traffic per launch,
+#         on eager steps (--eager --kernel-steps 0: every dispatch is an ordinary launch)
 #   4. PMC pass SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE for the matrix-pipe utilisation of every kernel family
 # Raw output goes to gpurun_out/prof_*; tools/summarize_profiles.py turns it into profiles/<tag>_*.{csv,json}.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 REPO=$(pwd)
 mkdir -p gpurun_out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats -o stats -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/prof_stats.log 2>&1
 echo "stats pass done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/prof_fetch -o fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/prof_fetch -o fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager --kernel-steps 0 > $REPO/gpurun_out/prof_fetch.log 2>&1
 echo "fetch pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/prof_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/prof_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager --kernel-steps 0 > $REPO/gpurun_out/prof_write.log 2>&1
 echo "write pass done"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/prof_mfma -o mfma -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/prof_mfma -o mfma -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager --kernel-steps 0 > $REPO/gpurun_out/prof_mfma.log 2>&1
 echo "mfma pass done"
 cd $REPO
 python3 tools/summarize_profiles.py $TAG gpurun_out
