@@ -280,11 +280,11 @@ class Model(nn.Module):
         return self.forecast(in_audio, x_enc, text, pre_seq, vid_indices)
 
     def _llm(self, inputs_embeds):
-        """HOP.py:204.  A frozen HF BERT on a ROCm device runs through the fused fast path (same arithmetic,
-        fused QKV GEMM + HIP epilogues); anything else (LLaMA/GPT-2 options of run_ted.py:133-175) is called as is."""
-        if inputs_embeds.is_cuda and self._bert_fast is None:
+        """HOP.py:204.  A frozen HF BERT runs through the fused fast path (same arithmetic, fused QKV GEMM + HIP
+        epilogues); a module of another architecture (LLaMA/GPT-2 options of run_ted.py:133-175) is called as is."""
+        if self._bert_fast is None:
             self._bert_fast = bert_fast.FrozenBertEncoder(self.llm_model) if bert_fast.supports(self.llm_model) else False
-        if inputs_embeds.is_cuda and self._bert_fast:
+        if self._bert_fast:
             return self._bert_fast(inputs_embeds)
         return self.llm_model(inputs_embeds=inputs_embeds).last_hidden_state
 

@@ -199,12 +199,10 @@ class ConvDiscriminator(nn.Module):
         return self._conv3_cl(x, self.pre_conv[6])
 
     def forward(self, poses, in_text=None):
-        if poses.is_cuda:       # GEMM-shaped convs + the hand-written GRU recurrence (same cell as the decoder)
-            feat = self._pre_conv_cl(poses)
-            output = ops.gru_bidirectional(feat, self.gru, self.gru.dropout, self.training)
-        else:                   # host-side use (CPU unit test of the stock-op part); never on the GPU path
-            feat = self.pre_conv(poses.transpose(1, 2)).transpose(1, 2)
-            output, _ = self.gru(feat, None)
+        # GEMM-shaped convs + the hand-written GRU recurrence (same cell as the decoder); like the generator this only
+        # runs on a ROCm device (ops.gru_bidirectional raises for host tensors: no second, stock-torch path)
+        feat = self._pre_conv_cl(poses)
+        output = ops.gru_bidirectional(feat, self.gru, self.gru.dropout, self.training)
         output = output[:, :, :self.hidden_size] + output[:, :, self.hidden_size:]
         output = self.out(output.contiguous().view(-1, output.shape[2])).view(poses.shape[0], -1)
         return torch.sigmoid(self.out2(output))

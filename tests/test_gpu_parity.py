@@ -803,6 +803,57 @@ def test_discriminator_vs_reference_golden(golden, P):
     assert_close(d.pre_conv[1].running_var, g["bn1_rv"], what="bn1 rv")
 
 
+def test_trimodal_api_matches_reference_golden(golden, monkeypatch):
+    """Secondary boundary: PoseGenerator.forward(pre_seq, in_text, in_audio, vid) and
+    train_iter_gan(...) keep the reference's signatures and arithmetic (the generator on stock torch ops, the
+    discriminator on the HIP GRU recurrence)."""
+    import types
+    import hopmi
+    from hopmi import steps
+    dev = _dev()
+    monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))      # the reference's CPU draws
+    from oracle import fill
+    from oracle.golden_util import SynthVocab, checksum, checksum_close
+    g = golden("trimodal")
+    args = types.SimpleNamespace(n_pre_poses=4, n_poses=34, input_context="both", hidden_size=24, n_layers=2, dropout_prob=0.0,
+                                 freeze_wordembed=False, loss_warmup=-1, loss_gan_weight=5.0, loss_regression_weight=600.0,
+                                 loss_kld_weight=0.6, loss_reg_weight=0.4, z_type="speaker")
+    B, P, n_words, n_spk = 2, 27, 40, 7
+    gen = hopmi.PoseGenerator(args, P, n_words, 16, None, SynthVocab(n_spk))
+    for mod in gen.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    assert list(gen.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    fill.fill_state_(gen)
+    d = hopmi.ConvDiscriminator(P)
+    d.gru.dropout = 0.0
+    fill.fill_state_(d, salt=1)
+    gen.to(dev).train(); d.to(dev).train()
+    text = fill.integers("gan.text", (B, 34), n_words).to(dev)
+    audio = fill.normal("gan.audio", (B, 36267)).to(dev)
+    poses = fill.normal("gan.poses", (B, 34, P), 0.1).to(dev)
+    vid = fill.integers("gan.vid", (B,), n_spk).to(dev)
+    pre = poses.new_zeros(B, 34, P + 1)
+    pre[:, :4, :-1] = poses[:, :4]
+    pre[:, :4, -1] = 1
+    gen._randn_like = lambda t: torch.randn(t.shape).to(t.device)      # the reference's CPU draw
+    torch.manual_seed(99)
+    out, _, mu, _ = gen(pre, text, audio, vid)
+    assert torch.allclose(out.cpu(), torch.from_numpy(g["out"]), rtol=1e-3, atol=1e-5)
+    assert torch.allclose(mu.cpu(), torch.from_numpy(g["z_mu"]), rtol=1e-3, atol=1e-5)
+    g_opt = torch.optim.Adam(gen.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    torch.manual_seed(99)
+    ret = hopmi.train_iter_gan(args, 0, text, audio, poses, vid, gen, d, g_opt, d_opt)
+    assert sorted(ret.keys()) == [str(k) for k in g["ret_keys"]]
+    for k, want in zip(g["ret_keys"], g["ret_vals"]):
+        assert abs(ret[str(k)] - want) <= RTOL * max(abs(want), 1e-6), (k, ret[str(k)], want)
+    sd = gen.state_dict()
+    for n, want in zip(g["g_names"], g["g_cs"]):
+        assert checksum_close(checksum(sd[str(n)]), want, RTOL, 2.5e-3 * sd[str(n)].numel() if "bias" in str(n) else 1e-4), n
+
+
+
 def test_generate_long_hipgraph_equals_eager():
     """The captured hipGraph of the window forward replays the same kernels: bit-identical windows, and a weight update
     re-captures (the prototype tensors are part of the capture)."""
@@ -848,41 +899,49 @@ def test_inference_prototype_cache_tracks_weights():
         assert m._kv_infer[1][0] is not kv1 and not torch.equal(a, c)     # recomputed
 
 
-def test_generate_long_matches_reference_loop():
-    """test_checkpoint.py:395-472 restated on the host (per-window model call, numpy cross-fade of 4 frames, vstack)
-    against hopmi.generate_long (device-side loop); the eval-mode forward itself is pinned by the *_eval goldens."""
-    import numpy as np
+def test_checkpoint_load_and_generate_long_vs_reference(golden, tmp_path):
+    """A generator checkpoint in the reference's on-disk form -- torch.save({'generator': state_dict, ...}),
+    run_ted.py:454-461, with the reference's own key list / shapes / dtypes from the fixture and the closed-form values --
+    is loaded the way test_checkpoint.py:312-315 does (load_state_dict(checkpoint['generator']), strict) and driven through
+    hopmi.generate_long; the result must match what the REFERENCE produced from the same file with its own windowed
+    loop (test_checkpoint.py:395-472; fixture made by tools/make_golden.py::golden_checkpoint), eager and hipGraph."""
+    import ast
     import hopmi
+    from transformers import BertModel
+    from oracle import fill
+    from oracle.golden_util import SynthTok, SynthVocab, hop_cfg, tiny_bert_config
     dev = _dev()
-    m, bcfg = _make_model(9, dev)
-    m.eval()
+    g = golden("checkpoint_V9")
+    sd = {}
+    for i, (k, shp, dt) in enumerate(zip(g["state_keys"], g["state_shapes"], g["state_dtypes"])):
+        dtype = getattr(torch, str(dt).split(".")[1])
+        if dtype.is_floating_point:
+            sd[str(k)] = fill.fill_value(str(k), ast.literal_eval(str(shp))).to(dtype)
+        else:
+            sd[str(k)] = torch.from_numpy(g[f"nonfloat_{i}"]).to(dtype)
+    # HOP.py:111 registers the LLM's embedding matrix a second time as `word_embeddings`: both keys are one tensor in the
+    # reference's file (closed-form filled under the alias' name, which sorts last)
+    sd["llm_model.embeddings.word_embeddings.weight"] = sd["word_embeddings"]
+    path = tmp_path / "hop_checkpoint.bin"
+    torch.save({"args": None, "epoch": 3, "pose_dim": 27, "generator": sd}, path)
+    assert sorted(torch.load(path).keys()) == [str(k) for k in g["top_keys"]]
+    bcfg = tiny_bert_config()
+    m = hopmi.Model(hop_cfg(9, bcfg.hidden_size), BertModel(bcfg), SynthTok(), SynthVocab(11)).float()
+    missing = m.load_state_dict(torch.load(path, map_location="cpu")["generator"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m.to(dev).train(False)
+    m._randn_like = lambda t: torch.randn(t.shape).to(t.device)      # the reference's CPU draws of the speaker sample
     W = 3
-    g = torch.Generator().manual_seed(3)
-    audio = torch.randn(W, 36267, generator=g).to(dev)
-    mel = torch.randn(W, 34, 128, generator=g).to(dev)
-    text = torch.randint(0, bcfg.vocab_size, (W, 34), generator=g).to(dev)
-    pre0 = (0.1 * torch.randn(1, 16, 27, generator=g)).to(dev)
+    audio = fill.normal("ckpt.audio", (W, 36267)).to(dev)
+    mel = fill.normal("ckpt.mel", (W, 34, 128)).to(dev)
+    text = fill.integers("ckpt.text", (W, 34), bcfg.vocab_size).to(dev)
+    pre0 = fill.normal("ckpt.pre", (1, 16, 27), 0.1).to(dev)
     vid = torch.tensor([3], device=dev)
     torch.manual_seed(99)
     got = hopmi.generate_long(m, audio, mel, text, pre0, vid)
-    # the reference's loop
-    torch.manual_seed(99)
-    out_list, pre = [], pre0
-    with torch.no_grad():
-        for a in range(W):
-            if a > 0:
-                pre = outputs[:, -16:]
-            outputs, *_ = m(audio[a:a + 1], mel[a:a + 1], text[a:a + 1], pre.float(), vid)
-            out_seq = outputs[0].cpu().numpy()
-            if out_list:
-                last = out_list[-1][-4:]
-                out_list[-1] = out_list[-1][:-4]
-                for j in range(4):
-                    out_seq[j] = last[j] * (4 - j) / 5 + out_seq[j] * (j + 1) / 5
-            out_list.append(out_seq)
-    want = torch.from_numpy(np.vstack(out_list))
-    assert got.shape == (W * 30 + 4, 27)
-    assert_close(got, want, 1e-5, "generate_long")
+    want = torch.from_numpy(g["out_dir_vec"])
+    assert got.shape == want.shape == (W * 30 + 4, 27)
+    assert_close(got, want, what="generate_long vs the reference's loop")
     assert not m.training
 
 
