@@ -17,4 +17,5 @@ from .nets import ConvDiscriminator, PoseGenerator    # noqa: F401
 from .steps import train_llm, train_iter_gan, mixed_precision   # noqa: F401
 from .infer import generate_long                      # noqa: F401
 from .graph import GraphedTrainStep                   # noqa: F401
+from .feeder import HostFeeder, log_melspec           # noqa: F401
 from .tuning import use_tuned_gemms                   # noqa: F401

@@ -147,6 +147,7 @@ class GraphedTrainStep:
         self.grad_dtype = grad_dtype
         self.enabled = enabled
         self.records = {}
+        self.n_eager = self.n_replay = 0            # calls served by steps.train_llm itself / by a replay
         self.sharded = False
         self._pool = None
         self._built = False
@@ -272,6 +273,7 @@ class GraphedTrainStep:
         for dst, src in zip(rec["static"], batch):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        self.n_replay += 1
         for kind, x in rec["cap"].plan:
             if kind == "graph":
                 x.replay()
@@ -281,6 +283,7 @@ class GraphedTrainStep:
         return _steps._LossFetch.decode(rec["terms"], self._host[:rec["n_vals"]].tolist(), True)
 
     def _eager(self, epoch, batch):
+        self.n_eager += 1
         if self.sharded:
             self.unshard()
         return _steps.train_llm(self.args, epoch, *batch, self.model, self.disc, self.g_opt, self.d_opt, self.accel)

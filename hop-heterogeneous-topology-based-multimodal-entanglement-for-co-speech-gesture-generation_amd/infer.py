@@ -13,6 +13,8 @@ puts gwnet on the fused no-autograd kernels with folded BatchNorm.  Audio / mel 
 """
 import torch
 
+from . import ops as _ops
+
 
 class _WindowGraph:
     """hipGraph of one batch-1 eval forward (static shapes, no dropout in eval mode): the ~250 launches of a window
@@ -29,8 +31,14 @@ class _WindowGraph:
                 model(*self.inputs)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = model(*self.inputs)[0]
+        sink, prev = [], _ops.STATUS_SINK
+        _ops.STATUS_SINK = sink                     # status words of the recorded persistent GRU launches
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = model(*self.inputs)[0]
+                self.status = torch.stack([w.float().reshape(()) for w in sink]).sum() if sink else None
+        finally:
+            _ops.STATUS_SINK = prev
 
     def __call__(self, audio, mel, text, pre, vid):
         for dst, src in zip(self.inputs, (audio, mel, text, pre, vid)):
@@ -64,10 +72,13 @@ def generate_long(model, in_audio, log_melspec, text_tokens, pre_seq, vid_indice
         W = in_audio.shape[0]
         pre = pre_seq.float()
         chunks = []
+        status = []                                 # hand-off status of the recorded window graphs (checked once, at the end)
         for a in range(W):
             if use_graph and in_audio.is_cuda:
-                out = _window_graph(model, in_audio[a:a + 1], log_melspec[a:a + 1], text_tokens[a:a + 1], pre, vid_indices)(
-                    in_audio[a:a + 1], log_melspec[a:a + 1], text_tokens[a:a + 1], pre, vid_indices)
+                wg = _window_graph(model, in_audio[a:a + 1], log_melspec[a:a + 1], text_tokens[a:a + 1], pre, vid_indices)
+                out = wg(in_audio[a:a + 1], log_melspec[a:a + 1], text_tokens[a:a + 1], pre, vid_indices)
+                if wg.status is not None:
+                    status.append(wg.status.clone())
             else:
                 out, *_ = model(in_audio[a:a + 1], log_melspec[a:a + 1], text_tokens[a:a + 1], pre, vid_indices)
             seq = out[0]
@@ -79,6 +90,14 @@ def generate_long(model, in_audio, log_melspec, text_tokens, pre_seq, vid_indice
                 head = last * (n_blend - jn) / (n_blend + 1) + seq[:n_blend] * (jn + 1) / (n_blend + 1)   # :466-470
                 seq = torch.cat([head, seq[n_blend:]], 0)
             chunks.append(seq)
-        return torch.cat(chunks, 0)
+        result = torch.cat(chunks, 0)
+        if in_audio.is_cuda:
+            # no training step drains the persistent GRU kernels' status words here: read them back once (one tiny
+            # device->host copy for the whole sequence) so that a hand-off time-out cannot return garbage poses silently
+            _ops.check_status_now()
+            if status and float(torch.stack(status).sum().item()) != 0.0:
+                raise RuntimeError("hopmi generate_long: a persistent GRU kernel timed out waiting for a hand-off; "
+                                   "set HOPMI_GRU_PERSISTENT=0 to use per-time-step launches")
+        return result
     finally:
         model.train(was_training)

@@ -223,6 +223,15 @@ size_t hopmi_gru_bwd_ws_floats(int B, int H);
 int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
                   float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);
 
+/* ---- log-mel spectrogram of the audio clips: data_loader/lmdb_data_loader.py:216-218
+ *      melspec = librosa.feature.melspectrogram(y, sr=16000, n_fft=1024, hop_length=hop, power=2)   (librosa 0.8.1:
+ *      periodic Hann window, center=True with reflect padding, Slaney mel filters);  out = power_to_db(melspec, ref=np.max).T
+ *   audio [B][n_samples] -> out [B][1 + n_samples/hop][128]  (amin 1e-10, top_db 80).
+ *   The 128 triangular filters come as compact runs: band m covers FFT bins band_start[m] .. +band_len[m], weights at
+ *   band_w[band_off[m] ..] (host side: hopmi/feeder.py::mel_filter_runs).  mel_power_ws: B * frames * 128 floats. */
+int hopmi_logmel(const float* audio, int B, int n_samples, int hop, const int* band_start, const int* band_len,
+                 const int* band_off, const float* band_w, float* mel_power_ws, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE ONLY -- float64 restatement of the reference's log-mel feature
+(data_loader/lmdb_data_loader.py:216-218):
+
+    melspec     = librosa.feature.melspectrogram(y=audio_padded, sr=16000, n_fft=1024, hop_length=1096, power=2)
+    log_melspec = librosa.power_to_db(melspec, ref=np.max).T
+
+PARITY UNPINNED: librosa (pinned at 0.8.1 by the reference, requirements_HOP:35) is a third-party dependency that is neither
+under /root/reference nor importable in the build container, and the reference holds no fixture of this feature.  This file
+restates the published librosa 0.8.1 definitions -- stft(center=True, pad_mode='reflect', window='hann' = scipy
+get_window('hann', 1024, fftbins=True), win_length = n_fft), filters.mel(htk=False, norm='slaney', fmin=0, fmax=sr/2),
+power_to_db(amin=1e-10, top_db=80.0) -- in float64 numpy (an O(N^2) DFT-free path: numpy.fft.rfft); only tests import it.
+"""
+import numpy as np
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+    out = f / f_sp
+    big = f >= min_log_hz
+    out = np.where(big, min_log_mel + np.log(np.where(big, f, min_log_hz) / min_log_hz) / logstep, out)
+    return out
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_basis(sr=16000, n_fft=1024, n_mels=128):
+    freqs = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(0.0), _hz_to_mel(sr / 2.0), n_mels + 2))
+    w = np.zeros((n_mels, freqs.size))
+    for i in range(n_mels):
+        lower = (freqs - mel_f[i]) / (mel_f[i + 1] - mel_f[i])
+        upper = (mel_f[i + 2] - freqs) / (mel_f[i + 2] - mel_f[i + 1])
+        w[i] = np.maximum(0.0, np.minimum(lower, upper)) * (2.0 / (mel_f[i + 2] - mel_f[i]))
+    return w.astype(np.float32).astype(np.float64)          # librosa returns float32 weights
+
+
+def log_melspec(y, sr=16000, n_fft=1024, hop=1096, n_mels=128, amin=1e-10, top_db=80.0):
+    """y (n_samples,) -> (1 + n_samples // hop, n_mels) float64."""
+    y = np.asarray(y, dtype=np.float64)
+    ypad = np.pad(y, n_fft // 2, mode="reflect")
+    k = np.arange(n_fft)
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n_fft)    # periodic Hann
+    n_frames = 1 + y.size // hop
+    frames = np.stack([ypad[t * hop:t * hop + n_fft] * window for t in range(n_frames)])
+    power = np.abs(np.fft.rfft(frames, axis=1)) ** 2        # (frames, 513)
+    mel = power @ mel_basis(sr, n_fft, n_mels).T            # (frames, mels)
+    log_spec = 10.0 * np.log10(np.maximum(amin, mel)) - 10.0 * np.log10(np.maximum(amin, mel.max()))
+    return np.maximum(log_spec, log_spec.max() - top_db)

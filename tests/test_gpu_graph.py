@@ -213,3 +213,66 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch):
         # elements whose gradient is at rounding level may take a +-lr Adam step the other way (4 steps of 1e-3)
         assert row["worst_max"] <= 8.5e-3 and row["worst_mean"] <= 5e-5, row
         assert row["replica_spread"] <= 1e-6, row
+
+
+# ------------------------------------------------------------------------------------------- input stage (feeder)
+def test_logmel_vs_float64_restatement():
+    """hopmi_logmel (GPU: reflect-padded framing, periodic Hann, radix-2 FFT in LDS, Slaney mel filters, power_to_db with
+    ref = max and an 80 dB floor) against oracle/mel_ref.py, the float64 restatement of librosa 0.8.1's published
+    definitions of the reference's call (lmdb_data_loader.py:216-218).  PARITY UNPINNED for this row: librosa itself cannot
+    be imported in the build container, so no fixture from it exists.  Tolerance: 2e-2 dB absolute on the [-80, 0] dB
+    range (fp32 FFT and log10), i.e. 2.5e-4 of the feature's range."""
+    import numpy as np
+    import hopmi
+    from oracle import mel_ref
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    n = 36267
+    t = np.arange(n) / 16000.0
+    clips = np.stack([rng.standard_normal(n) * 0.1,                                   # noise
+                      np.sin(2 * np.pi * 440.0 * t) + 0.3 * np.sin(2 * np.pi * 3000.0 * t),   # tones: most bands at the floor
+                      np.concatenate([np.zeros(n // 2), rng.standard_normal(n - n // 2)]),       # half silence
+                      np.zeros(n)]).astype(np.float32)                                 # silence: every value at amin
+    got = hopmi.log_melspec(torch.from_numpy(clips).to(dev)).cpu().double().numpy()
+    assert got.shape == (4, 34, 128)
+    for i in range(clips.shape[0]):
+        want = mel_ref.log_melspec(clips[i].astype(np.float64))
+        err = np.abs(got[i] - want).max()
+        assert err <= 2e-2, (i, err)
+    assert np.abs(got[3]).max() <= 1e-5 and got[1].min() == -80.0 and abs(got[0].max()) <= 1e-5
+
+
+def test_host_feeder_feeds_the_step(monkeypatch):
+    """HostFeeder: host batches in the reference collate's dtypes (text as float64) arrive as device tensors equal to a
+    plain copy, log_melspec equals the kernel on that audio, batches come in order, and train_llm runs on them."""
+    import numpy as np
+    import hopmi
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m, d, inp = _pair(9, dev)
+    rng = np.random.default_rng(0)
+    host = []
+    for k in range(5):
+        host.append(dict(audio_padded=rng.standard_normal((2, 36267)).astype(np.float32) * 0.1,
+                         text_token_padded=rng.integers(0, 90, (2, 34)).astype(np.float64),      # np.zeros(34) rows -> float64
+                         vec_seq=(rng.standard_normal((2, 34, 27)) * 0.1).astype(np.float32),
+                         vid_indices=torch.from_numpy(rng.integers(0, 11, (2,)))))
+    feeder = hopmi.HostFeeder(iter(host), dev)
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    seen = 0
+    for k, batch in enumerate(feeder):
+        assert batch["text"].dtype == torch.float64 and batch["in_audio"].dtype == torch.float32
+        assert batch["vid_indices"].dtype == torch.int64 and batch["log_melspec"].shape == (2, 34, 128)
+        # (the device buffers are reused by the next batch: compare before asking for it)
+        assert torch.equal(batch["in_audio"].cpu(), torch.from_numpy(host[k]["audio_padded"]))
+        assert torch.equal(batch["text"].cpu(), torch.from_numpy(host[k]["text_token_padded"]))
+        assert torch.equal(batch["target_dir_vec"].cpu(), torch.from_numpy(host[k]["vec_seq"]))
+        assert torch.equal(batch["log_melspec"], hopmi.log_melspec(batch["in_audio"]))
+        ret = hopmi.train_llm(step_args(9), 0, batch["in_audio"], batch["log_melspec"], batch["text"], batch["target_dir_vec"],
+                              batch["vid_indices"], m, d, g_opt, d_opt, Accel())
+        feeder.refill()
+        assert ret["loss"] == ret["loss"]
+        seen += 1
+    assert seen == 5
