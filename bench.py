@@ -153,6 +153,9 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # host threads: the box's CPU share per GPU is 16 cores; torch's default (every hardware thread) oversubscribes it, and
+    # spinning intra-op workers starve the ROCm runtime's completion threads (seen as 60-160 ms stalls of the step)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
