@@ -44,6 +44,9 @@ def parse():
                     help="fp32 = the headline configuration (configs[1]); bf16 = configs 2/4 (bf16 GEMMs + bf16 gradient exchange)")
     ap.add_argument("--eager", action="store_true", help="time steps.train_llm itself instead of its recorded hipGraphs")
     ap.add_argument("--kernel-steps", type=int, default=6, help="instrumented eager steps for the roofline object (0 = none)")
+    ap.add_argument("--bert-gemm", default="split3", choices=["library", "split3", "split2"],
+                    help="the frozen BERT's linears: the library's fp32 GEMM, or hopmi_gemm_split with 3 bf16 parts per operand "
+                         "(six MFMA terms: fp32-equivalent, default) or 2 parts (three terms: 2^-16-class products)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
     ap.add_argument("--rehearse-sync", action="store_true",
                     help="N=1 only: run the N>1 exchange path on a 1-rank RCCL group (overhead rehearsal)")
@@ -184,6 +187,7 @@ def main():
     V = 9 if args.dataset == "TED" else 42
     B = args.batch
     hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
+    hopmi.gemm_parts({"library": 0, "split3": 3, "split2": 2}[args.bert_gemm])      # (fp32 mode only: bf16 mode autocasts)
     tuned = (not args.no_tuned_gemms) and args.dtype == "fp32" and hopmi.use_tuned_gemms()
     torch.manual_seed(0)                                       # identical replicas
     model = hopmi.Model(synth.model_configs(args.dataset), synth.build_bert(6), synth.SyntheticTokenizer(),
@@ -303,6 +307,11 @@ def main():
                                    "prototype rows of the mapping layer sharded over ranks (all-gather S, all-reduce dS), "
                                    "one flat all-reduce of the other gradients per module, eager RCCL calls between graph launches",
                        "llm": "BERT-base geometry, 6 layers, random init, frozen",
+                       "bert_gemm": ("library bf16 GEMMs (autocast)" if args.dtype != "fp32" else
+                                     {"library": "library fp32 GEMMs (hipBLASLt)",
+                                      "split3": "hopmi_gemm_split, 3 bf16 parts per operand, 6 MFMA terms: fp32-equivalent (error vs float64 "
+                                                "equal to the library's fp32 GEMM, tools/bench_gemm.py)",
+                                      "split2": "hopmi_gemm_split, 2 bf16 parts per operand, 3 MFMA terms (2^-16-class products)"}[args.bert_gemm]),
                        "library_gemm_selection": "shipped TunableOp table (replay only)" if tuned else "library default",
                        "losses": last},
         }

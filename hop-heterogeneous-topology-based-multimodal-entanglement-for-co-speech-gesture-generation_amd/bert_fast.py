@@ -41,6 +41,7 @@ class FrozenBertEncoder:
     def __init__(self, llm):
         self.llm = llm
         self._qkv = {}
+        self._img = {}
 
     def _fused_qkv(self, i, att):
         ver = (att.query.weight._version, att.key.weight._version, att.value.weight._version, att.query.weight.data_ptr())
@@ -52,6 +53,21 @@ class FrozenBertEncoder:
             hit = (ver, w, b)
             self._qkv[i] = hit
         return hit[1], hit[2]
+
+    def _linear(self, key, x, weight, bias):
+        """x W^T (+ bias) for one of the module's frozen linears: the library's fp32 GEMM, or -- ops.gemm_parts(2 | 3) --
+        hopmi_gemm_split on images of W and W^T that are built once per weight version."""
+        parts = ops.GEMM_PARTS
+        N, K = weight.shape
+        if parts == 0 or torch.is_autocast_enabled() or not ops.split_gemm_supported(N, K) or not ops.split_gemm_supported(K, N):
+            return F.linear(x, weight, bias)
+        ver = (weight._version, weight.data_ptr(), parts)
+        hit = self._img.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, ops.split_weight_image(weight, parts), ops.split_weight_image(weight.t().contiguous(), parts))
+            self._img[key] = hit
+        return ops.split_linear(x, hit[1], hit[2], bias, N, K, parts)
 
     def _seed(self):
         FrozenBertEncoder._calls += 1
@@ -73,18 +89,18 @@ class FrozenBertEncoder:
         for i, lay in enumerate(llm.encoder.layer):
             att = lay.attention
             wqkv, bqkv = self._fused_qkv(i, att.self)
-            qkv = F.linear(h, wqkv, bqkv).view(B, L, 3, H, D // H)
+            qkv = self._linear((i, "qkv"), h, wqkv, bqkv).view(B, L, 3, H, D // H)
             if D // H == 64 and L <= 64:
                 a = ops.bert_attention(qkv, p_a, self._seed())                                   # (B,L,D), HIP
             else:                                                                                # other head sizes
                 qkv = qkv.permute(2, 0, 3, 1, 4)                                                 # (3,B,H,L,dh)
                 a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p_a)
                 a = a.transpose(1, 2).reshape(B, L, D)
-            o = F.linear(a, att.output.dense.weight)
+            o = self._linear((i, "ao"), a, att.output.dense.weight, None)
             h = ops.bias_dropout_residual_layernorm(o, att.output.dense.bias, h, att.output.LayerNorm.weight,
                                                     att.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
-            f = ops.bias_gelu(F.linear(h, lay.intermediate.dense.weight), lay.intermediate.dense.bias)
-            o = F.linear(f, lay.output.dense.weight)
+            f = ops.bias_gelu(self._linear((i, "f1"), h, lay.intermediate.dense.weight, None), lay.intermediate.dense.bias)
+            o = self._linear((i, "f2"), f, lay.output.dense.weight, None)
             h = ops.bias_dropout_residual_layernorm(o, lay.output.dense.bias, h, lay.output.LayerNorm.weight,
                                                     lay.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
         return h

@@ -1,0 +1,224 @@
+// fp32 GEMM against frozen weights on the bf16 matrix cores: C[M][N] = A[M][K] . Bt[N][K]^T (+ bias[N]).
+//
+// The frozen BERT (HOP.py:90-91,204) is 70 % of the step's FLOPs: ~1.1 TFLOP of fp32 GEMMs per training step against
+// weights that never change.  The exact-fp32 MFMA peaks at 157 TFLOP/s (the library reaches 115-140 on these shapes); the
+// bf16 MFMA is 16x faster per instruction.  Here every fp32 operand is carried as NP bf16 parts (bf16_dev.h):
+//   NP = 3:  x = x0 + x1 + x2 holds all 24 significand bits; a.b = sum over i + j <= 2 of a_i b_j  (6 MFMAs per product block);
+//            the dropped terms are < 2^-24 |a b| -- the rounding error of an fp32 multiply -- so the GEMM is fp32-EQUIVALENT
+//            (measured against float64: same error as the library's fp32 GEMM, tests/test_gpu_parity.py)
+//   NP = 2:  x = x0 + x1 (2^-17), three terms: 2^-16-class products at twice the rate (the WaveNet kernels' arithmetic)
+// with fp32 accumulation in the MFMA.  The weights are split ONCE (hopmi_gemm_split_prepare: they are frozen, also their
+// transpose for the activation gradient dX = dY . W); the activations are split on the fly when a tile is committed to LDS.
+//
+// Workgroup = 128 x 128 output tile, 8 waves of 64 x 32 (4 x 2 MFMA tiles, 32 accumulator registers: two waves per SIMD, so
+// one wave's LDS reads / splits / commits run beside its partner's MFMAs), K steps of 32 (one v_mfma_f32_16x16x32_bf16
+// k-step); the next tile's global loads are issued before the MFMAs of the current one and committed behind them.  Two
+// forms, chosen by the tile count: DB (two LDS buffers, one barrier per step, 144 KiB: one workgroup per CU) when the tiles
+// fit the chip about once; !DB (one buffer, two barriers per step, 72 KiB: TWO workgroups per CU that cover each other's
+// commit phases and halve the tile-count quantisation) for the larger grids.  LDS rows are 96 bytes (64 data + 32 pad): the 16 lanes
+// of every ds_read_b128 service group then hit 16 distinct 16-byte bank slots.  Tiles are enumerated XCD-aware: the tiles
+// of one XCD walk one panel of A against consecutive panels of B, so both stay in that XCD's L2.
+#include "bf16_dev.h"
+
+namespace hopmi {
+
+constexpr int GM = 128, GN = 128, GK = 32;
+constexpr int GLD = 48;                            // LDS row stride in bf16 units (96 bytes)
+
+template <int NP>
+struct SplitN { u32x2 p[NP]; };                    // NP packed pairs for two consecutive values
+
+template <int NP>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NP]) {
+  float ra = a, rb = b;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const unsigned h = pk_bf16(ra, rb);
+    out[i] = h;
+    if (i + 1 < NP) { ra -= bf_lo(h); rb -= bf_hi(h); }
+  }
+}
+
+// weights -> NP bf16 part images [NP][N][K] (row-major, the MFMA B-operand's 8 consecutive k are contiguous)
+template <int NP>
+__global__ __launch_bounds__(256) void gemm_split_prepare_kernel(const float* __restrict__ W, size_t n, unsigned* __restrict__ img) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // pair index
+  if (2 * i >= n) return;
+  const float2 v = reinterpret_cast<const float2*>(W)[i];
+  unsigned parts[NP];
+  split_pair<NP>(v.x, v.y, parts);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) img[(size_t)p * (n / 2) + i] = parts[p];
+}
+
+constexpr int GT = 512;                            // threads: 8 waves as 2 (M) x 4 (N)
+
+template <int NP, bool DB>
+__global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bimg,
+                                                         const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
+                                                         int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // [buffer 2][operand A|B][part NP][128 rows][GLD]
+  __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
+  constexpr int PART = GM * GLD;                   // one part image of one operand (bf16 units)
+  constexpr int OPER = NP * PART, BUF = DB ? 2 * OPER : 0;
+  int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wv >> 2, wc = wv & 3;
+  const int lane = tid & 63, q = lane >> 4, n = lane & 15;
+
+  // XCD-aware tile order: workgroups b and b + 8 share an XCD (round-robin dispatch); give each XCD a contiguous run of tiles,
+  // tiles of a run ordered n fastest, so an XCD re-reads one A panel and streams neighbouring B panels through its own L2
+  const int ntiles = tiles_m * tiles_n;
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+  const int per = ntiles >> 3, rem = ntiles & 7;
+  const int tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+  if (idx >= per + (xcd < rem ? 1 : 0)) return;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * GM, n0 = tn * GN;
+
+  // staging map: thread t moves 32 bytes of row (t >> 2): columns 8 (t & 3) .. +7 of the 32-wide K slice
+  const int srow = tid >> 2, sq = tid & 3;
+  const float* a_src = A + (size_t)min(m0 + srow, M - 1) * K + 8 * sq;
+  const __bf16* b_src = Bimg + (size_t)(n0 + srow) * K + 8 * sq;
+  const size_t b_part = (size_t)N * K;
+  const int st_off = srow * GLD + 8 * sq;
+
+  float4 a_st[2];
+  u32x4 b_st[NP];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_st[i] = reinterpret_cast<const float4*>(a_src + k0)[i];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) b_st[p] = *reinterpret_cast<const u32x4*>(b_src + p * b_part + k0);
+  };
+  auto commit = [&](int buf) {
+    __bf16* la = lds + buf * BUF + st_off;
+    __bf16* lb = la + OPER;
+    unsigned parts[4][NP];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      split_pair<NP>(a_st[i].x, a_st[i].y, parts[2 * i]);
+      split_pair<NP>(a_st[i].z, a_st[i].w, parts[2 * i + 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      *reinterpret_cast<u32x4*>(la + p * PART) = u32x4{parts[0][p], parts[1][p], parts[2][p], parts[3][p]};
+      *reinterpret_cast<u32x4*>(lb + p * PART) = b_st[p];
+    }
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / GK;
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    // (the lane index is hidden from the optimiser per iteration: keeps loop-invariant LDS addresses from being hoisted into
+    // dozens of registers held across the whole loop)
+    asm volatile("" : "+v"(tid));
+    const int ln = tid & 63, qq = ln >> 4, nn = ln & 15;
+    const bool more = kt + 1 < nk;
+    if (more) issue((kt + 1) * GK);
+    const __bf16* la = lds + (DB ? (kt & 1) : 0) * BUF + (64 * wr + nn) * GLD + 8 * qq;
+    const __bf16* lb = lds + (DB ? (kt & 1) : 0) * BUF + OPER + (32 * wc + nn) * GLD + 8 * qq;
+    u32x4 af[4][NP];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) af[mi][p] = *reinterpret_cast<const u32x4*>(la + p * PART + 16 * mi * GLD);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      u32x4 bf[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const u32x4*>(lb + p * PART + 16 * ni * GLD);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        f32x4 c = acc[mi][ni];
+        // smallest terms first: i + j = NP - 1, ..., 0
+#pragma unroll
+        for (int s = NP - 1; s >= 0; --s)
+#pragma unroll
+          for (int i = 0; i <= s; ++i) c = mfma_bf16(af[mi][i], bf[s - i], c);
+        acc[mi][ni] = c;
+      }
+    }
+    if (!DB) __syncthreads();                      // one buffer: every wave has read this step's fragments
+    if (more) commit(DB ? ((kt + 1) & 1) : 0);
+    __syncthreads();
+  }
+
+  // epilogue: lane (q, n) holds rows 4q + r, column n of every 16 x 16 tile
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + 32 * wc + 16 * ni + n;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 64 * wr + 16 * mi + 4 * q + r;
+        if (row < M) C[(size_t)row * N + col] = acc[mi][ni][r] + bv;
+      }
+  }
+}
+
+template <int NP>
+static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
+  const int tiles_m = (M + GM - 1) / GM, tiles_n = N / GN;
+  const size_t lds1 = (size_t)2 * NP * GM * GLD * sizeof(__bf16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+  const int ntiles = tiles_m * tiles_n;
+  const int grid = ((ntiles + 7) / 8) * 8;                // every XCD gets the same number of slots; surplus ones return at once
+  if (ntiles > env_int("HOPMI_GEMM_DB_MAX_TILES", 320))
+    hipLaunchKernelGGL((gemm_split_kernel<NP, false>), dim3(grid), dim3(GT), lds1, st, A, static_cast<const __bf16*>(Bimg), bias, C, M,
+                       N, K, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_split_kernel<NP, true>), dim3(grid), dim3(GT), 2 * lds1, st, A, static_cast<const __bf16*>(Bimg), bias, C,
+                       M, N, K, tiles_m, tiles_n);
+  return check_launch("hopmi_gemm_split");
+}
+
+}  // namespace hopmi
+
+using namespace hopmi;
+
+extern "C" size_t hopmi_gemm_split_image_bytes(int N, int K, int parts) {
+  return (N > 0 && K > 0 && (parts == 2 || parts == 3)) ? (size_t)parts * N * K * sizeof(__bf16) : 0;
+}
+
+extern "C" int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts, void* image, void* stream) {
+  if (!W || !image || N <= 0 || K <= 0 || (K & 1) || (parts != 2 && parts != 3)) {
+    set_error("hopmi_gemm_split_prepare: need W, image, even K and parts in {2, 3} (N=%d K=%d parts=%d)", N, K, parts);
+    return HOPMI_EINVAL;
+  }
+  const size_t n = (size_t)N * K;
+  const unsigned grid = (unsigned)((n / 2 + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (parts == 2) hipLaunchKernelGGL(gemm_split_prepare_kernel<2>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
+  else hipLaunchKernelGGL(gemm_split_prepare_kernel<3>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
+  return check_launch("hopmi_gemm_split_prepare");
+}
+
+extern "C" int hopmi_gemm_split(const float* A, const void* Bimage, const float* bias, float* C, int M, int N, int K, int parts,
+                                void* stream) {
+  if (!A || !Bimage || !C) { set_error("hopmi_gemm_split: null pointer argument"); return HOPMI_EINVAL; }
+  if (M <= 0 || N <= 0 || K <= 0 || N % GN || K % GK || (parts != 2 && parts != 3)) {
+    set_error("hopmi_gemm_split: need N %% 128 == 0, K %% 32 == 0, parts in {2, 3} (M=%d N=%d K=%d parts=%d)", M, N, K, parts);
+    return HOPMI_EINVAL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return parts == 2 ? launch_gemm_split<2>(A, Bimage, bias, C, M, N, K, st) : launch_gemm_split<3>(A, Bimage, bias, C, M, N, K, st);
+}

@@ -200,6 +200,73 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
     return _GcnFn.apply(x, A1, A2, Wm, bm, prep)
 
 
+# ------------------------------------------------------- frozen-weight linears on split-bf16 MFMA (hopmi_gemm_split)
+GEMM_PARTS = 3      # 3: six-term split (fp32-equivalent, default);  2: three-term split (2^-16 class);  0: library fp32 GEMM (hipBLASLt)
+
+
+def gemm_parts(parts=None):
+    """Select how the frozen BERT's linears are computed (bert_fast): 0 = the library's fp32 GEMM, 3 = hopmi_gemm_split
+    with three bf16 parts per operand (six MFMA terms, fp32-equivalent), 2 = two parts (three terms).  Returns the
+    previous setting; `None` only reads it."""
+    global GEMM_PARTS
+    prev = GEMM_PARTS
+    if parts is not None:
+        if parts not in (0, 2, 3):
+            raise ValueError("hopmi gemm_parts: 0 (library fp32), 2 or 3")
+        GEMM_PARTS = parts
+    return prev
+
+
+def split_weight_image(w: torch.Tensor, parts: int) -> torch.Tensor:
+    """bf16 part images of a frozen (N, K) fp32 weight for hopmi_gemm_split (as its Bt operand)."""
+    w = _dev_f32(w.detach(), "weight")
+    N, K = w.shape
+    L = _lib.lib()
+    nbytes = L.hopmi_gemm_split_image_bytes(N, K, parts)
+    if nbytes == 0 or K % 2:
+        raise _lib.HopmiError(f"hopmi split_weight_image: unsupported shape {tuple(w.shape)} / parts {parts}")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(L.hopmi_gemm_split_prepare(w.data_ptr(), N, K, parts, img.data_ptr(), _stream()), "hopmi_gemm_split_prepare")
+    return img
+
+
+def split_gemm_supported(N: int, K: int) -> bool:
+    return N % 128 == 0 and K % 32 == 0
+
+
+def _split_gemm(a2d, img, bias, N, K, parts):
+    M = a2d.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
+    L = _lib.lib()
+    _lib.check(_timed("gemm_split", 4 * (M * K + M * N) + 2 * parts * N * K, 2 * M * N * K,
+                      lambda: L.hopmi_gemm_split(a2d.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, parts, _stream())),
+               "hopmi_gemm_split")
+    return out
+
+
+class _SplitLinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) against a FROZEN weight: forward and activation gradient on hopmi_gemm_split; no weight gradient."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, img_w, img_wt, bias, N, K, parts):
+        x = _dev_f32(x, "x")
+        y = _split_gemm(x.reshape(-1, K), img_w, None if bias is None else _dev_f32(bias.detach(), "bias"), N, K, parts)
+        ctx.img_wt, ctx.N, ctx.K, ctx.parts = img_wt, N, K, parts
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        dy = _dev_f32(dy, "dy")
+        dx = _split_gemm(dy.reshape(-1, ctx.N), ctx.img_wt, None, ctx.K, ctx.N, ctx.parts)      # dX = dY . W = dY . (W^T)^T
+        return dx.view(*dy.shape[:-1], ctx.K), None, None, None, None, None, None
+
+
+def split_linear(x, img_w, img_wt, bias, N, K, parts):
+    return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
+
+
 # ------------------------------------------------------- fused BERT epilogues (frozen LLM: no parameter grads)
 class _BiasGeluFn(torch.autograd.Function):
     @staticmethod

@@ -223,6 +223,20 @@ size_t hopmi_gru_bwd_ws_floats(int B, int H);
 int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
                   float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);
 
+/* ---- fp32 GEMM against frozen weights on the bf16 matrix cores (the frozen BERT's linears, HOP.py:90-91,204 ->
+ *      transformers BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput nn.Linear calls)
+ *   C[M][N] = A[M][K] . Bt[N][K]^T (+ bias[N]);  A, C fp32 row-major.
+ * Every operand is carried as `parts` bf16 numbers and the product taken as the terms a_i b_j with i + j < parts on
+ * v_mfma_f32_16x16x32_bf16, fp32 accumulation:  parts = 3 keeps all 24 significand bits (6 terms; the dropped ones are below
+ * an fp32 multiply's rounding error: fp32-equivalent), parts = 2 gives 2^-16-class products (3 terms) at twice the rate.
+ * The weight operand is split once (frozen weights): hopmi_gemm_split_prepare(W [N][K]) -> image of
+ * hopmi_gemm_split_image_bytes(N, K, parts) bytes; for the activation gradient dX = dY . W pass the image of W^T.
+ * N % 128 == 0, K % 32 == 0, any M. */
+size_t hopmi_gemm_split_image_bytes(int N, int K, int parts);
+int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts, void* image, void* stream);
+int hopmi_gemm_split(const float* A, const void* Bimage, const float* bias, float* C, int M, int N, int K, int parts,
+                     void* stream);
+
 /* ---- log-mel spectrogram of the audio clips: data_loader/lmdb_data_loader.py:216-218
  *      melspec = librosa.feature.melspectrogram(y, sr=16000, n_fft=1024, hop_length=hop, power=2)   (librosa 0.8.1:
  *      periodic Hann window, center=True with reflect padding, Slaney mel filters);  out = power_to_db(melspec, ref=np.max).T

@@ -1010,3 +1010,60 @@ def test_native_library_is_loaded():
     _lib.lib()
     maps = open("/proc/self/maps").read()
     assert "libhopmi.so" in maps
+
+
+# ------------------------------------------------------------------------ split-bf16 GEMM against frozen weights
+@pytest.mark.parametrize("parts,tol", [(3, 4e-6), (2, 2e-5)])
+@pytest.mark.parametrize("M,N,K", [(68, 128, 128), (300, 256, 384), (4352, 768, 768), (2176, 2304, 768), (4352, 768, 3072)])
+def test_gemm_split_vs_float64(M, N, K, parts, tol):
+    """hopmi_gemm_split (the frozen BERT's linears on the bf16 matrix cores, operands carried as `parts` bf16 numbers) against
+    the float64 product: three parts must be fp32-EQUIVALENT (error no larger than a few fp32 roundings of the result's
+    scale, the same as the library's fp32 GEMM), two parts stay in the 2^-16 class; forward, bias, ragged M and the
+    activation gradient (the image of W^T)."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    gy = torch.randn(M, N, generator=g).to(dev)
+    y = ops.split_linear(x, ops.split_weight_image(w, parts), ops.split_weight_image(w.t().contiguous(), parts), b, N, K, parts)
+    y.backward(gy)
+    want = x.detach().double() @ w.double().t() + b.double()
+    wdx = gy.double() @ w.double()
+    lib = torch.nn.functional.linear(x.detach(), w, b)
+    err, err_lib = rel_err(y.double(), want), rel_err(lib.double(), want)
+    assert err <= tol, (err, err_lib)
+    assert rel_err(x.grad.double(), wdx) <= tol
+    if parts == 3:
+        assert err <= 3 * err_lib + 1e-7, (err, err_lib)          # fp32-equivalent: on a par with the library's fp32 GEMM
+
+
+def test_bert_fast_path_split_gemm_vs_reference_golden(golden):
+    """The frozen BERT through hopmi_gemm_split (3 and 2 parts) against the HF reference golden (BERT-base geometry)."""
+    import hopmi
+    from transformers import BertConfig, BertModel
+    from hopmi import bert_fast, ops
+    from oracle import fill
+    dev = _dev()
+    g = golden("bert_base2")
+    cfg = BertConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = BertModel(cfg)
+    fill.fill_state_(m)
+    for p in m.parameters():
+        p.requires_grad = False
+    m.to(dev).train()
+    x = fill.uniform("bert.inputs_embeds", (1, 34, cfg.hidden_size)).to(dev)
+    prev = ops.gemm_parts()
+    try:
+        for parts, tol in ((3, RTOL), (2, RTOL)):
+            ops.gemm_parts(parts)
+            enc = bert_fast.FrozenBertEncoder(m)
+            xi = x.clone().requires_grad_()
+            out = enc(xi)
+            assert any(k[1] == "qkv" for k in enc._img), "the split GEMM was not taken"
+            assert_close(out, g["out"], tol, what=f"bert out parts={parts}")
+            (out * fill.uniform("bert.gout", out.shape).to(dev)).sum().backward()
+            assert_close(xi.grad, g["dx"], tol, what=f"bert dx parts={parts}")
+    finally:
+        ops.gemm_parts(prev)

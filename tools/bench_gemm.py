@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""hopmi_gemm_split (split-bf16 GEMM against frozen weights) vs the library's fp32 GEMM at the frozen BERT's shapes:
+time per call (HIP events over back-to-back launches) and error against a float64 product."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hopmi
+from hopmi import ops
+
+dev = torch.device("cuda:0")
+if "--tuned" in sys.argv:
+    hopmi.use_tuned_gemms()
+g = torch.Generator().manual_seed(0)
+M = 4352
+for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    ref = (x.double() @ w.double().t() + b.double())
+    def timed(fn, iters=50):
+        for _ in range(5): fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    t_lib = timed(lambda: torch.nn.functional.linear(x, w, b))
+    err_lib = ((torch.nn.functional.linear(x, w, b).double() - ref).abs().max() / ref.abs().max()).item()
+    line = f"M={M} N={N} K={K}: library fp32 {t_lib:7.1f} us ({2*M*N*K/t_lib/1e6:6.1f} TF) err {err_lib:.1e}"
+    for parts in (3, 2):
+        img = ops.split_weight_image(w, parts)
+        t = timed(lambda: ops._split_gemm(x, img, b, N, K, parts))
+        err = ((ops._split_gemm(x, img, b, N, K, parts).double() - ref).abs().max() / ref.abs().max()).item()
+        line += f" | parts={parts}: {t:7.1f} us ({2*M*N*K/t/1e6:6.1f} TF-equiv) err {err:.1e}"
+    print(line, flush=True)
