@@ -22,7 +22,7 @@
 
 namespace hopmi {
 
-constexpr int GM = 128, GN = 128, GK = 32;
+constexpr int GN = 128, GK = 32;                   // (the tile's M extent BM is a template parameter: 128 or 64)
 constexpr int GLD = 48;                            // LDS row stride in bf16 units (96 bytes)
 
 template <int NP>
@@ -53,15 +53,18 @@ __global__ __launch_bounds__(256) void gemm_split_prepare_kernel(const float* __
 
 constexpr int GT = 512;                            // threads: 8 waves as 2 (M) x 4 (N)
 
-template <int NP, bool DB>
+// BM = 64 halves the tile (8 waves of 32 x 32) for shapes whose 128-row tiling leaves CUs idle or quantises badly.
+template <int NP, bool DB, int BM>
 __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bimg,
                                                          const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                          int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // [buffer 2][operand A|B][part NP][128 rows][GLD]
+  // [buffer 2][A: part NP x BM rows | B: part NP x 128 rows][GLD]
   __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
-  constexpr int PART = GM * GLD;                   // one part image of one operand (bf16 units)
-  constexpr int OPER = NP * PART, BUF = DB ? 2 * OPER : 0;
+  constexpr int MI = BM / 32;                      // 16-row MFMA tiles per wave (wave rows = BM / 2)
+  constexpr int PART_A = BM * GLD, PART_B = GN * GLD;        // one part image of an operand (bf16 units)
+  constexpr int OPER = NP * PART_A;                // offset of the B images inside a buffer
+  constexpr int BUFSZ = NP * (PART_A + PART_B), BUF = DB ? BUFSZ : 0;
   int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wv >> 2, wc = wv & 3;
   const int lane = tid & 63, q = lane >> 4, n = lane & 15;
@@ -74,42 +77,48 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   const int tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
   if (idx >= per + (xcd < rem ? 1 : 0)) return;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * GM, n0 = tn * GN;
+  const int m0 = tm * BM, n0 = tn * GN;
 
-  // staging map: thread t moves 32 bytes of row (t >> 2): columns 8 (t & 3) .. +7 of the 32-wide K slice
-  const int srow = tid >> 2, sq = tid & 3;
-  const float* a_src = A + (size_t)min(m0 + srow, M - 1) * K + 8 * sq;
-  const __bf16* b_src = Bimg + (size_t)(n0 + srow) * K + 8 * sq;
+  // staging maps.  B (128 rows x 64 bytes per part): thread t moves 16 bytes of row (t >> 2), k = 8 (t & 3) .. +7.
+  // A (BM rows x 128 bytes): BM = 128: the 32 bytes of row (t >> 2) at k = 8 (t & 3); BM = 64: 16 bytes of row (t >> 3) at
+  // k = 4 (t & 7).
+  constexpr int AF4 = BM / 64;                     // float4 loads of A per thread and k step
+  const int brow = tid >> 2, bq = tid & 3;
+  const int arow = (BM == 128) ? (tid >> 2) : (tid >> 3);
+  const int acol = (BM == 128) ? 8 * (tid & 3) : 4 * (tid & 7);
+  const float* a_src = A + (size_t)min(m0 + arow, M - 1) * K + acol;
+  const __bf16* b_src = Bimg + (size_t)(n0 + brow) * K + 8 * bq;
   const size_t b_part = (size_t)N * K;
-  const int st_off = srow * GLD + 8 * sq;
+  const int a_off = arow * GLD + acol, b_off = brow * GLD + 8 * bq;
 
-  float4 a_st[2];
+  float4 a_st[AF4];
   u32x4 b_st[NP];
   auto issue = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a_st[i] = reinterpret_cast<const float4*>(a_src + k0)[i];
+    for (int i = 0; i < AF4; ++i) a_st[i] = reinterpret_cast<const float4*>(a_src + k0)[i];
 #pragma unroll
     for (int p = 0; p < NP; ++p) b_st[p] = *reinterpret_cast<const u32x4*>(b_src + p * b_part + k0);
   };
   auto commit = [&](int buf) {
-    __bf16* la = lds + buf * BUF + st_off;
-    __bf16* lb = la + OPER;
-    unsigned parts[4][NP];
+    __bf16* la = lds + buf * BUF + a_off;
+    __bf16* lb = lds + buf * BUF + OPER + b_off;
+    unsigned parts[2 * AF4][NP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AF4; ++i) {
       split_pair<NP>(a_st[i].x, a_st[i].y, parts[2 * i]);
       split_pair<NP>(a_st[i].z, a_st[i].w, parts[2 * i + 1]);
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      *reinterpret_cast<u32x4*>(la + p * PART) = u32x4{parts[0][p], parts[1][p], parts[2][p], parts[3][p]};
-      *reinterpret_cast<u32x4*>(lb + p * PART) = b_st[p];
+      if (BM == 128) *reinterpret_cast<u32x4*>(la + p * PART_A) = u32x4{parts[0][p], parts[1][p], parts[2][p], parts[3][p]};
+      else *reinterpret_cast<u32x2*>(la + p * PART_A) = u32x2{parts[0][p], parts[1][p]};
+      *reinterpret_cast<u32x4*>(lb + p * PART_B) = b_st[p];
     }
   };
 
-  f32x4 acc[4][2];
+  f32x4 acc[MI][2];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
 
@@ -124,20 +133,20 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
     const int ln = tid & 63, qq = ln >> 4, nn = ln & 15;
     const bool more = kt + 1 < nk;
     if (more) issue((kt + 1) * GK);
-    const __bf16* la = lds + (DB ? (kt & 1) : 0) * BUF + (64 * wr + nn) * GLD + 8 * qq;
+    const __bf16* la = lds + (DB ? (kt & 1) : 0) * BUF + ((BM / 2) * wr + nn) * GLD + 8 * qq;
     const __bf16* lb = lds + (DB ? (kt & 1) : 0) * BUF + OPER + (32 * wc + nn) * GLD + 8 * qq;
-    u32x4 af[4][NP];
+    u32x4 af[MI][NP];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) af[mi][p] = *reinterpret_cast<const u32x4*>(la + p * PART + 16 * mi * GLD);
+      for (int p = 0; p < NP; ++p) af[mi][p] = *reinterpret_cast<const u32x4*>(la + p * PART_A + 16 * mi * GLD);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       u32x4 bf[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const u32x4*>(lb + p * PART + 16 * ni * GLD);
+      for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const u32x4*>(lb + p * PART_B + 16 * ni * GLD);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
         f32x4 c = acc[mi][ni];
         // smallest terms first: i + j = NP - 1, ..., 0
 #pragma unroll
@@ -158,36 +167,44 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
     const int col = n0 + 32 * wc + 16 * ni + n;
     const float bv = bias != nullptr ? bias[col] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + 64 * wr + 16 * mi + 4 * q + r;
+        const int row = m0 + (BM / 2) * wr + 16 * mi + 4 * q + r;
         if (row < M) C[(size_t)row * N + col] = acc[mi][ni][r] + bv;
       }
   }
 }
 
-template <int NP>
-static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
-  const int tiles_m = (M + GM - 1) / GM, tiles_n = N / GN;
-  const size_t lds1 = (size_t)2 * NP * GM * GLD * sizeof(__bf16);
+template <int NP, bool DB, int BM>
+static void launch_gemm_variant(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = N / GN;
+  const size_t lds = (size_t)(DB ? 2 : 1) * NP * (BM + GN) * GLD * sizeof(__bf16);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, DB, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;                // every XCD gets the same number of slots; surplus ones return at once
-  if (ntiles > env_int("HOPMI_GEMM_DB_MAX_TILES", 320))
-    hipLaunchKernelGGL((gemm_split_kernel<NP, false>), dim3(grid), dim3(GT), lds1, st, A, static_cast<const __bf16*>(Bimg), bias, C, M,
-                       N, K, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL((gemm_split_kernel<NP, true>), dim3(grid), dim3(GT), 2 * lds1, st, A, static_cast<const __bf16*>(Bimg), bias, C,
-                       M, N, K, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
+                     K, tiles_m, tiles_n);
+}
+
+// Tile choice, measured at the frozen BERT's shapes (tools/bench_gemm.py, HOPMI_GEMM_TILE forces a form): 128-row tiles,
+// double-buffered with one workgroup per CU when the tiles cover the chip about once (N = 768: 204 tiles), single-buffered
+// with two workgroups per CU for the larger grids (N = 2304 / 3072: 612 / 816 tiles).  64-row tiles (form 3) fill idle CUs
+// and quantise better on paper but lost 5-15 % everywhere (more weight traffic and barriers per MFMA): kept for experiments.
+template <int NP>
+static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
+  const int t128 = ((M + 127) / 128) * (N / GN);
+  const int forced = env_int("HOPMI_GEMM_TILE", 0);       // diagnostics: 1 = 128/DB, 2 = 128/!DB, 3 = 64/!DB
+  const int mode = (forced >= 1 && forced <= 3) ? forced : (t128 <= 320 ? 1 : 2);
+  if (mode == 1) launch_gemm_variant<NP, true, 128>(A, Bimg, bias, C, M, N, K, st);
+  else if (mode == 2) launch_gemm_variant<NP, false, 128>(A, Bimg, bias, C, M, N, K, st);
+  else launch_gemm_variant<NP, false, 64>(A, Bimg, bias, C, M, N, K, st);
   return check_launch("hopmi_gemm_split");
 }
 
