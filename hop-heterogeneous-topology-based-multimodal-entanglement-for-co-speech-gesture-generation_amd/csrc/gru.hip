@@ -19,7 +19,7 @@
 // zero-padded to a multiple of 64 and split over the 4 waves in 16-wide chunks read back as ds_read_b128
 // MFMA operands; the 4 partial tiles are summed through LDS and the gate math is the epilogue.
 // h_prev is read from the layer output y itself.
-#include "common.h"
+#include "bf16_dev.h"
 
 namespace hopmi {
 
@@ -313,17 +313,23 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Persistent forward: ONE launch per layer.  Workgroup (slice group g = (dir, batch group), unit block jb) keeps its
-// 48 x H slice of W_hh in LDS for all T steps and walks the time steps itself; the nJ workgroups of a group
-// exchange h_t through HBM/L2 with the placement-independent hand-off of the CDNA4 guide (Guideline 16, "sc1" form):
-//   producer: h_t stored with sc1 (write-through) stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup
-//             barrier -> one lane adds 1 to the group's arrival counter of step t (agent-scope relaxed atomic)
-//   consumer: one lane polls that counter with sc1 loads until all nJ workgroups arrived -> workgroup barrier ->
-//             EVERY load of the h_{t} panel is an sc1 load (L1 is never trusted for handed-off bytes)
-// Requirements: the whole grid is resident at once (host checks grid <= #CUs, one workgroup per CU by LDS size);
-// linear ids are group-major (a group's workgroups are dispatched together) with the unit-block count padded to a
-// multiple of 8 so a given unit block always lands on the same XCD.  Every spin is bounded: on timeout the
-// workgroup raises the status word and leaves, so the launch always drains.
+// Persistent schedule: ONE launch per layer.  Workgroup (group = (direction, 16 batch rows), unit block jb of 32 hidden
+// units) walks all T steps itself; the nJ = ceil(H / 32) workgroups of a group exchange h_t (forward) / dgh_t (backward)
+// through the layer's own output arrays.
+//   * The recurrent weights never touch LDS: every wave keeps the MFMA B-operand fragments of its (unit half, K quarter)
+//     in registers for the whole launch, split into two bf16 parts once at kernel start (72 VGPRs at H = 350).
+//   * The product runs on v_mfma_f32_16x16x32_bf16 with both operands carried as hi + lo bf16 pairs (three terms,
+//     bf16_dev.h; ~2^-16 relative per product, fp32 accumulation): 27 MFMAs of 16 cycles per wave and step instead of the
+//     72 exact-fp32 MFMAs of 32 cycles that were 32 % of a step (tools/probes/gru_stamps.py).
+//   * Hand-off without counters: the hand-off array is filled with a NaN bit pattern no computation produces before the
+//     kernel starts; a producer simply stores its values (sc1: write-through), a consumer loads the rows it needs with sc1
+//     loads (never served from a stale cache) and re-loads whatever still reads as the pattern.  One memory round trip
+//     per step instead of three (drain stores + arrive, poll the counter, load the panel).
+//   * 16 x 32 tiles instead of 32 x 16: each handed-off row is read by half as many workgroups (the exchange is
+//     bandwidth-bound: every workgroup of a group reads the whole group's rows; 22x -> 11x read amplification).
+// Requirements: the whole grid is resident at once (host checks grid <= #CUs).  Every spin is bounded: on timeout the wave
+// raises the status word, stops waiting for the rest of the launch and runs to completion, so the launch always drains
+// (results are then garbage and the host raises on the status word).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float2 ld_sc1_f2(const float* p) {
   const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
@@ -334,32 +340,31 @@ __device__ __forceinline__ void st_sc1_f(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// stage `nrows` rows (row r from src_of(r), nullptr -> zeros) with sc1 8-B loads; same shape as stage_rows
-template <int MAXROWS_PER_WAVE, int MAXK2, int NW = 4, typename SrcOf>
-__device__ __forceinline__ void stage_rows_sc1(float* dst, int ldk, int nrows, int K, int KP, SrcOf src_of, int w, int lane) {
-  float2 v[MAXROWS_PER_WAVE][MAXK2];
-#pragma unroll
-  for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
-    const int r = w + NW * rr;
-    const float* src = src_of(min(r, nrows - 1));
-    const bool row_ok = (r < nrows) && (src != nullptr);
-#pragma unroll
-    for (int c = 0; c < MAXK2; ++c) {
-      const int k = 2 * lane + 128 * c;
-      float2 t = make_float2(0.f, 0.f);
-      if (row_ok && k < K) t = ld_sc1_f2(src + k);
-      v[rr][c] = t;
-    }
-  }
-#pragma unroll
-  for (int rr = 0; rr < MAXROWS_PER_WAVE; ++rr) {
-    const int r = w + NW * rr;
-#pragma unroll
-    for (int c = 0; c < MAXK2; ++c) {
-      const int k = 2 * lane + 128 * c;
-      if (r < nrows && k < KP) *reinterpret_cast<float2*>(dst + r * ldk + k) = v[rr][c];
-    }
-  }
+constexpr int GP_BM = 16;                          // batch rows per persistent workgroup (one MFMA row tile)
+constexpr int GP_NU = 32;                          // hidden units per persistent workgroup (two MFMA column tiles)
+constexpr int GP_RED_F = 100;                      // LDS stride of the forward partial tiles  [16][3 x 32]
+constexpr int GP_RED_B = 36;                       // ... of the backward partial tiles        [16][32]
+constexpr unsigned GRU_SENTINEL = 0x7FC5A3E1u;     // "not written yet": a NaN payload neither the ALUs nor torch generate
+constexpr int GRU_POLL_LIMIT = 1 << 21;            // re-load rounds before a wave gives up (seconds)
+
+// Workgroup -> (direction, batch group, unit block).  Linear ids are dealt round-robin over the 8 XCDs; all workgroups of
+// a group (the ones that exchange rows) take the same id % 8, so a hand-off stays inside one XCD's L2 when the dispatcher
+// places workgroups that way (speed only: the hand-off is correct for any placement).
+struct GpWork { int d, bb, jb; bool valid; };
+__device__ __forceinline__ GpWork gp_decode(int nJ, int nbb) {
+  const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+  const int gsel = k / nJ, group = xcd + 8 * gsel;
+  GpWork wk;
+  wk.jb = k - gsel * nJ;
+  wk.valid = group < 2 * nbb;
+  wk.d = group / nbb;
+  wk.bb = group - wk.d * nbb;
+  return wk;
+}
+static int gp_grid(int nJ, int nbb) { return 8 * ((2 * nbb + 7) / 8) * nJ; }
+
+__device__ __forceinline__ bool gru_unwritten(float2 v) {
+  return __float_as_uint(v.x) == GRU_SENTINEL || __float_as_uint(v.y) == GRU_SENTINEL;
 }
 
 // Diagnostic build only (-DHOPMI_STAMPS, tools/probes/gru_stamps.py): s_memtime stamps of one mid-sequence step.
@@ -380,54 +385,108 @@ extern "C" int hopmi_debug_set_stamps_gru(long long* p) {
 #define GRU_STAMP(slot) do { } while (0)
 #endif
 
-constexpr int GRU_SPIN_LIMIT = 1 << 23;            // ~8 s of polling before giving up (a peer rank's collective may hold CUs)
-
-// returns false on timeout (uniform over the workgroup)
-__device__ __forceinline__ bool gru_wait(const int* cnt, int want, int* status, int* flag_lds) {
-  if (threadIdx.x == 0) {
-    int ok = 1, spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > GRU_SPIN_LIMIT) { ok = 0; __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+// Load NSEG row segments of K floats (segment m from src(m); nullptr -> zeros): lane l takes the float2 at k = 2 l + 128 c.
+// Values that still hold the fill pattern are loaded again until they do not (bounded).
+template <int NSEG, int MAXK2, typename SrcOf>
+__device__ __forceinline__ void poll_segments(float2 (&v)[NSEG][MAXK2], SrcOf src, int K, int lane, bool& dead, int* status) {
+  bool pend = false;
+#pragma unroll
+  for (int m = 0; m < NSEG; ++m) {
+    const float* p = src(m);
+#pragma unroll
+    for (int c = 0; c < MAXK2; ++c) {
+      const int k = 2 * lane + 128 * c;
+      float2 t = make_float2(0.f, 0.f);
+      if (p != nullptr && k < K) t = ld_sc1_f2(p + k);
+      v[m][c] = t;
+      pend |= gru_unwritten(t);
     }
-    *flag_lds = ok;
   }
-  __syncthreads();
-  return *flag_lds != 0;
+  int spins = 0;
+  while (!dead && __ballot(pend) != 0ull) {                            // wave-uniform
+    if (++spins > GRU_POLL_LIMIT) {
+      dead = true;
+      if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    pend = false;
+#pragma unroll
+    for (int m = 0; m < NSEG; ++m) {
+      const float* p = src(m);
+#pragma unroll
+      for (int c = 0; c < MAXK2; ++c) {
+        if (gru_unwritten(v[m][c])) {                                   // (never true for a zero-filled slot)
+          v[m][c] = ld_sc1_f2(p + 2 * lane + 128 * c);
+          pend |= gru_unwritten(v[m][c]);
+        }
+      }
+    }
+  }
 }
 
-// 8 waves: wave w owns K quarter (w & 3) of batch-row tile (w >> 2), so a step's 144 MFMAs per SIMD become 72 and the
-// gate epilogue is one element per thread (tools/probes/gru_stamps.py: the MFMA phase was 37 % of a step).
+// commit one loaded segment to LDS row `row` of a split panel (hi image, lo image; WS2 32-bit words per row)
+template <int MAXK2>
+__device__ __forceinline__ void commit_split_row(unsigned* hi, unsigned* lo, int ws2, int row, const float2 (&v)[MAXK2], int lane) {
+#pragma unroll
+  for (int c = 0; c < MAXK2; ++c) {
+    const u32x2 p = split2(v[c].x, v[c].y);
+    hi[row * ws2 + lane + 64 * c] = p[0];
+    lo[row * ws2 + lane + 64 * c] = p[1];
+  }
+}
+
+// the 8 values W[k0 .. k0 + 8) of a weight row (nullptr row or k >= K -> 0) as one split MFMA operand
+__device__ __forceinline__ Split8 load_w_frag(const float* row, int k0, int K) {
+  float2 f[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = k0 + 2 * e;
+    f[e] = (row != nullptr && k < K) ? *reinterpret_cast<const float2*>(row + k) : make_float2(0.f, 0.f);
+  }
+  return split8(make_float4(f[0].x, f[0].y, f[1].x, f[1].y), make_float4(f[2].x, f[2].y, f[3].x, f[3].y));
+}
+
+// KP = 128 MAXK2 >= H: K padded so that each of the 4 K quarters is MAXK2 MFMA steps of 32.
+// 8 waves: wave w owns K quarter (w & 3) of unit half (w >> 2); the gate epilogue is one element per thread.
 template <int MAXK2>
 __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
                                                                  const float* __restrict__ bhh, float* y,
-                                                                 float* __restrict__ gates, int* cnt, int* status, int B, int T,
-                                                                 int H, int KP, int nJ, int nJp, int nbb) {
+                                                                 float* __restrict__ gates, int* status, int B, int T,
+                                                                 int H, int nJ, int nbb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int group = blockIdx.x / nJp, jb = blockIdx.x % nJp;
-  if (jb >= nJ) return;
-  const int d = group / nbb, bb = group % nbb;
-  const int ldk = KP + 4;
-  float* As = smem;                                // [32][ldk]  h_prev rows
-  float* Ws = As + GRU_BM * ldk;                   // [48][ldk]  resident W_hh slice
-  float* red = Ws + 3 * GRU_NU * ldk;              // [4 K quarters][32][RED_LD]
-  int* flag = reinterpret_cast<int*>(red + 4 * GRU_BM * RED_LD);
+  constexpr int KP = 128 * MAXK2, WS2 = (KP + 48) / 2;                 // 32-bit words per LDS row: 16-byte reads conflict-free
+  unsigned* Ahi = reinterpret_cast<unsigned*>(smem);                   // [16][WS2]  h_prev rows, bf16 hi parts
+  unsigned* Alo = Ahi + GP_BM * WS2;                                   //            ... lo parts
+  float* red = reinterpret_cast<float*>(Alo + GP_BM * WS2);            // [4 K quarters][16][GP_RED_F]
+  const GpWork wk = gp_decode(nJ, nbb);
+  if (!wk.valid) return;
+  const int d = wk.d, bb = wk.bb, jb = wk.jb;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
-  const int kq = w & 3, mh = w >> 2;
-  const int j0 = jb * GRU_NU, b0 = bb * GRU_BM;
+  const int kq = w & 3, ch = w >> 2;
+  const int j0 = jb * GP_NU, b0 = bb * GP_BM;
   const size_t ystride = (size_t)2 * H;
-  const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
-  const int row = tid >> 4, b = b0 + row, bc = min(b, B - 1);     // the thread's element in the gate epilogue
-  int* gcnt = cnt + (size_t)group * T;
+  const int jj = tid & 31, j = j0 + jj, jc = min(j, H - 1);
+  const int row = tid >> 5, b = b0 + row, bc = min(b, B - 1);           // the thread's element in the gate epilogue
 
-  stage_rows<3 * GRU_NU / 8, MAXK2, 8>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
-    const int g = r >> 4, ju = j0 + (r & 15);
-    return ju < H ? whh + ((size_t)(d * 3 + g) * H + ju) * H : nullptr;
-  }, w, lane);
+  u32x4 wh[3][MAXK2], wl[3][MAXK2];                                    // resident W_hh fragments of this wave
+  {
+    const int ju = j0 + 16 * ch + i;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const float* wrow = ju < H ? whh + ((size_t)(d * 3 + g) * H + ju) * H : nullptr;
+#pragma unroll
+      for (int kk = 0; kk < MAXK2; ++kk) {
+        const Split8 f = load_w_frag(wrow, (kq * MAXK2 + kk) * 32 + 8 * q, H);
+        wh[g][kk] = f.hi; wl[g][kk] = f.lo;
+      }
+    }
+  }
   float e_bhh[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) e_bhh[g] = bhh[(d * 3 + g) * H + jc];
-  const int nc = KP >> 6;
+  float h_own = 0.f;                                                   // this thread's h_{t-1}[b][j]
+  bool dead = false;
 
   for (int s = 0; s < T; ++s) {
     const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
@@ -439,23 +498,33 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __
       for (int g = 0; g < 3; ++g) e_gi[g] = gip[g * H];
     }
     if (s > 0) {
-      if (!gru_wait(gcnt + (s - 1), nJ, status, flag)) return;     // h_{s-1} of this group complete
-      GRU_STAMP(1);
-      stage_rows_sc1<GRU_BM / 8, MAXK2, 8>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
-        const int br = b0 + r;
+      float2 v[2][MAXK2];                                              // wave w stages rows w and w + 8
+      poll_segments<2, MAXK2>(v, [&](int m) -> const float* {
+        const int br = b0 + w + 8 * m;
         return br < B ? y + ((size_t)br * T + tp) * ystride + d * H : nullptr;
-      }, w, lane);
+      }, H, lane, dead, status);
+      GRU_STAMP(1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane);
       __syncthreads();
       GRU_STAMP(2);
       f32x4 acc[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
-      panel_mfma_1<3>(acc, As + 16 * mh * ldk, Ws, ldk, kq * nc, nc, q, i);
+      const unsigned* ahp = Ahi + i * WS2 + 4 * q + kq * MAXK2 * 16;
+      const unsigned* alp = Alo + i * WS2 + 4 * q + kq * MAXK2 * 16;
+#pragma unroll
+      for (int kk = 0; kk < MAXK2; ++kk) {
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + 16 * kk);
+        const u32x4 al = *reinterpret_cast<const u32x4*>(alp + 16 * kk);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = mfma_split3(ah, al, wh[g][kk], wl[g][kk], acc[g]);
+      }
       GRU_STAMP(3);
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(kq * GRU_BM + 16 * mh + 4 * q + r) * RED_LD + 16 * g + i] = acc[g][r];
+        for (int r = 0; r < 4; ++r) red[(kq * GP_BM + 4 * q + r) * GP_RED_F + 32 * g + 16 * ch + i] = acc[g][r];
       __syncthreads();
       GRU_STAMP(4);
     }
@@ -463,70 +532,72 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __
       float gh[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        float v = e_bhh[g];
+        float a = e_bhh[g];
         if (s > 0) {
 #pragma unroll
-          for (int ww = 0; ww < 4; ++ww) v += red[(ww * GRU_BM + row) * RED_LD + 16 * g + jj];
+          for (int ww = 0; ww < 4; ++ww) a += red[(ww * GP_BM + row) * GP_RED_F + 32 * g + jj];
         }
-        gh[g] = v;
+        gh[g] = a;
       }
       const float r = sigmoidf_(e_gi[0] + gh[0]);
       const float z = sigmoidf_(e_gi[1] + gh[1]);
       const float n = tanhf_(e_gi[2] + r * gh[2]);
-      const float hp = (s > 0) ? As[row * ldk + j] : 0.f;
-      st_sc1_f(y + ((size_t)b * T + t) * ystride + d * H + j, (1.f - z) * n + z * hp);      // handed off: write-through
+      h_own = (1.f - z) * n + z * h_own;
+      st_sc1_f(y + ((size_t)b * T + t) * ystride + d * H + j, h_own);   // handed off: write-through
       float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
       gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = gh[2];
     }
     GRU_STAMP(5);
-    if (s + 1 < T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
-      __syncthreads();                                             // (also: As / red free for the next step)
-      if (tid == 0) __hip_atomic_fetch_add(gcnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      GRU_STAMP(6);
-    }
+    // no trailing barrier: the next step's panel commit follows this step's second barrier (all MFMA reads done), and its
+    // partial-tile writes follow the next step's first barrier (all epilogue reads of `red` done)
   }
 }
 
-// Persistent BPTT: same structure; the workgroup keeps its 16 x 3H slice of W_hh^T in LDS (three gate blocks) and
-// hands dgh_t over (sc1 stores / sc1 loads + arrival counters); dgi, dhz stay private to the workgroup.
+// Persistent BPTT: same structure.  The workgroup's W_hh^T fragments (K = 3 gate blocks of H) stay in registers, the
+// dgh rows of all three gate blocks are staged at once (83 KB of LDS at H = 350), dgi and the D z carry stay private.
 template <int MAXK2>
 __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ gates, const float* __restrict__ whhT,
-                                                                 float* __restrict__ dgi, float* dgh, float* dhz, int* cnt,
-                                                                 int* status, int B, int T, int H, int KP, int nJ, int nJp, int nbb) {
+                                                                 float* __restrict__ dgi, float* dgh, int* status, int B, int T,
+                                                                 int H, int nJ, int nbb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int group = blockIdx.x / nJp, jb = blockIdx.x % nJp;
-  if (jb >= nJ) return;
-  const int d = group / nbb, bb = group % nbb;
-  const int ldk = KP + 4;
-  float* As = smem;                                // [32][ldk]      dgh rows of one gate block
-  float* Ws = As + GRU_BM * ldk;                   // [3][16][ldk]   resident W_hh^T slice, one image per gate block
-  float* red = Ws + 3 * GRU_NU * ldk;              // [4 K quarters][32][RED_LD]
-  int* flag = reinterpret_cast<int*>(red + 4 * GRU_BM * RED_LD);
+  constexpr int KP = 128 * MAXK2, WS2 = (KP + 48) / 2;
+  unsigned* Ahi = reinterpret_cast<unsigned*>(smem);                   // [3 gate blocks][16][WS2]  dgh rows, hi parts
+  unsigned* Alo = Ahi + 3 * GP_BM * WS2;
+  float* red = reinterpret_cast<float*>(Alo + 3 * GP_BM * WS2);        // [4 K quarters][16][GP_RED_B]
+  const GpWork wk = gp_decode(nJ, nbb);
+  if (!wk.valid) return;
+  const int d = wk.d, bb = wk.bb, jb = wk.jb;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
-  const int kq = w & 3, mh = w >> 2;               // 8 waves: K quarter x batch-row tile, as in the forward kernel
-  const int j0 = jb * GRU_NU, b0 = bb * GRU_BM;
+  const int kq = w & 3, ch = w >> 2;
+  const int j0 = jb * GP_NU, b0 = bb * GP_BM;
   const int K = 3 * H;
-  const int jj = tid & 15, j = j0 + jj, jc = min(j, H - 1);
-  const int row = tid >> 4, b = b0 + row, bc = min(b, B - 1);      // the thread's element in the epilogue
-  int* gcnt = cnt + (size_t)group * T;
+  const int jj = tid & 31, j = j0 + jj, jc = min(j, H - 1);
+  const int row = tid >> 5, b = b0 + row, bc = min(b, B - 1);
 
-  stage_rows<3 * GRU_NU / 8, MAXK2, 8>(Ws, ldk, 3 * GRU_NU, H, KP, [&](int r) -> const float* {
-    const int g = r >> 4, ju = j0 + (r & 15);
-    return ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr;
-  }, w, lane);
-  const int nc = KP >> 6;
+  u32x4 wh[3][MAXK2], wl[3][MAXK2];
+  {
+    const int ju = j0 + 16 * ch + i;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const float* wrow = ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr;
+#pragma unroll
+      for (int kk = 0; kk < MAXK2; ++kk) {
+        const Split8 f = load_w_frag(wrow, (kq * MAXK2 + kk) * 32 + 8 * q, H);
+        wh[g][kk] = f.hi; wl[g][kk] = f.lo;
+      }
+    }
+  }
+  float dhz_own = 0.f;                                                 // D_{p+1} z_{p+1} of this thread's element
+  bool dead = false;
 
   for (int s = 0; s < T; ++s) {
     const int t = d ? s : T - 1 - s;
     const int tn = d ? t - 1 : t + 1, tp = d ? t + 1 : t - 1;
-    const float* dhz_in = dhz + ((size_t)((s + 1) & 1) * 2 + d) * B * H;
-    float* dhz_out = dhz + ((size_t)(s & 1) * 2 + d) * B * H;
-    float e_dy, e_dhz, e_g[4], e_hp;
+    GRU_STAMP(0);
+    float e_dy, e_g[4], e_hp;
     {
       e_dy = dy[((size_t)bc * T + t) * 2 * H + d * H + jc];
-      e_dhz = dhz_in[(size_t)bc * H + jc];                         // this workgroup's own write of the previous step
       const float* gp = gates + (((size_t)bc * T + t) * 2 + d) * 4 * H + jc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) e_g[g] = gp[g * H];
@@ -534,61 +605,71 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
       e_hp = y[((size_t)bc * T + tpc) * 2 * H + d * H + jc];
     }
     if (s > 0) {
-      if (!gru_wait(gcnt + (s - 1), nJ, status, flag)) return;     // dgh of the previous BPTT step complete
-      f32x4 acc[1];
-      acc[0] = {0.f, 0.f, 0.f, 0.f};
+      float2 v[6][MAXK2];                                              // wave w stages segments w + 8 m = (gate block, row)
+      poll_segments<6, MAXK2>(v, [&](int m) -> const float* {
+        const int idx = w + 8 * m, g = idx >> 4, br = b0 + (idx & 15);
+        return br < B ? dgh + (((size_t)br * T + tn) * 2 + d) * K + g * H : nullptr;
+      }, H, lane, dead, status);
+      GRU_STAMP(1);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane);
+      __syncthreads();
+      GRU_STAMP(2);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
       for (int g = 0; g < 3; ++g) {
-        if (g) __syncthreads();
-        stage_rows_sc1<GRU_BM / 8, MAXK2, 8>(As, ldk, GRU_BM, H, KP, [&](int r) -> const float* {
-          const int br = b0 + r;
-          return br < B ? dgh + (((size_t)br * T + tn) * 2 + d) * K + g * H : nullptr;
-        }, w, lane);
-        __syncthreads();
-        panel_mfma_1<1>(acc, As + 16 * mh * ldk, Ws + g * GRU_NU * ldk, ldk, kq * nc, nc, q, i);
-      }
+        const unsigned* ahp = Ahi + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
+        const unsigned* alp = Alo + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(kq * GRU_BM + 16 * mh + 4 * q + r) * RED_LD + i] = acc[0][r];
-      __syncthreads();
-    }
-    {
-      if (b < B && j < H) {
-        float D = e_dy;
-        if (s > 0) {
-          D += e_dhz;
-#pragma unroll
-          for (int ww = 0; ww < 4; ++ww) D += red[(ww * GRU_BM + row) * RED_LD + jj];
+        for (int kk = 0; kk < MAXK2; ++kk) {
+          const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + 16 * kk);
+          const u32x4 al = *reinterpret_cast<const u32x4*>(alp + 16 * kk);
+          acc = mfma_split3(ah, al, wh[g][kk], wl[g][kk], acc);
         }
-        const float r = e_g[0], z = e_g[1], n = e_g[2], hn = e_g[3];
-        const float hp = (s < T - 1) ? e_hp : 0.f;
-        const float dn = D * (1.f - z) * (1.f - n * n);
-        const float dz = D * (hp - n) * z * (1.f - z);
-        const float dr = dn * hn * r * (1.f - r);
-        const size_t o = (((size_t)b * T + t) * 2 + d) * K + j;
-        dgi[o] = dr; dgi[o + H] = dz; dgi[o + 2 * H] = dn;
-        st_sc1_f(dgh + o, dr); st_sc1_f(dgh + o + H, dz); st_sc1_f(dgh + o + 2 * H, dn * r);   // handed off
-        dhz_out[(size_t)b * H + j] = D * z;
       }
-    }
-    if (s + 1 < T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GRU_STAMP(3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(kq * GP_BM + 4 * q + r) * GP_RED_B + 16 * ch + i] = acc[r];
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(gcnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      GRU_STAMP(4);
     }
+    if (b < B && j < H) {
+      float D = e_dy;
+      if (s > 0) {
+        D += dhz_own;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) D += red[(ww * GP_BM + row) * GP_RED_B + jj];
+      }
+      const float r = e_g[0], z = e_g[1], n = e_g[2], hn = e_g[3];
+      const float hp = (s < T - 1) ? e_hp : 0.f;
+      const float dn = D * (1.f - z) * (1.f - n * n);
+      const float dz = D * (hp - n) * z * (1.f - z);
+      const float dr = dn * hn * r * (1.f - r);
+      const size_t o = (((size_t)b * T + t) * 2 + d) * K + j;
+      st_sc1_f(dgh + o, dr); st_sc1_f(dgh + o + H, dz); st_sc1_f(dgh + o + 2 * H, dn * r);   // handed off
+      dgi[o] = dr; dgi[o + H] = dz; dgi[o + 2 * H] = dn;
+      dhz_own = D * z;
+    }
+    GRU_STAMP(5);
   }
 }
 
-// Arrival counters and status word are cleared by a kernel, not by hipMemsetAsync: inside a replayed hipGraph a memset
-// node was observed to land AFTER the dependent persistent kernel had started (the counters still held the previous
-// replay's arrivals, then were zeroed under the running kernel, whose hand-offs then timed out); kernel -> kernel
-// ordering holds in graphs and eagerly alike.
-__global__ void gru_clear_ws_kernel(int* __restrict__ ws, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) ws[i] = 0;
+// Before a persistent launch: zero the status word and fill the hand-off array with the "not written yet" pattern.  A
+// kernel, not hipMemsetAsync: inside a replayed hipGraph a memset node was observed to land AFTER the dependent persistent
+// kernel had started; kernel -> kernel ordering holds in graphs and eagerly alike.
+__global__ __launch_bounds__(256) void gru_prepare_kernel(int* __restrict__ ws, int nws, u32x2* __restrict__ fill, size_t npairs) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (gid < (size_t)nws) ws[gid] = 0;
+  for (size_t k = gid; k < npairs; k += stride) fill[k] = u32x2{GRU_SENTINEL, GRU_SENTINEL};
 }
 
-static void gru_clear_ws(void* ws, size_t bytes, hipStream_t st) {
-  const int n = (int)(bytes / sizeof(int));
-  hipLaunchKernelGGL(gru_clear_ws_kernel, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<int*>(ws), n);
+static void gru_prepare(void* ws, size_t ws_bytes, float* handoff, size_t n_floats, hipStream_t st) {
+  const int nws = (int)(ws_bytes / sizeof(int));
+  const size_t npairs = n_floats / 2;                                   // (n_floats is even: H is)
+  const size_t want = (npairs > (size_t)nws ? npairs : (size_t)nws) / 256 + 1;
+  const int blocks = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(gru_prepare_kernel, dim3(blocks), dim3(256), 0, st, static_cast<int*>(ws), nws,
+                     reinterpret_cast<u32x2*>(handoff), npairs);
 }
 
 static int gru_validate(const void* const* ptrs, int n, int B, int T, int H) {
@@ -631,54 +712,52 @@ static int gru_num_cus() {
 
 // persistent path iff the caller gave a workspace (the host side withholds it when it cannot promise that nothing else
 // competes for the CUs: HOPMI_GRU_PERSISTENT=0, an RCCL exchange in flight, a shared device) and every workgroup can be
-// resident at once (one per CU)
+// resident at once (at most one per CU asked for)
 static bool gru_persistent_ok(int B, int H, const void* ws) {
-  const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
-  const int nJp = (nJ + 7) / 8 * 8;
-  return ws != nullptr && 2 * nbb * nJp <= gru_num_cus();
+  const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
+  return ws != nullptr && gp_grid(nJ, nbb) <= gru_num_cus();
 }
 
 extern "C" size_t hopmi_gru_ws_bytes(int B, int T, int H) {
   if (B <= 0 || T <= 0 || H <= 0) return 0;
-  const int nbb = (B + GRU_BM - 1) / GRU_BM;
-  return ((size_t)2 * nbb * T + 16) * sizeof(int);               // arrival counters [2*nbb][T] + status word
+  return (size_t)32 * sizeof(int);                               // status word at int index [size - 16]; the rest is spare
+}
+
+static int* gru_status_word(void* ws, int B, int T, int H) {
+  return static_cast<int*>(ws) + hopmi_gru_ws_bytes(B, T, H) / sizeof(int) - 16;
 }
 
 template <int MAXK2>
-static void launch_gru_fwd_persistent(int grid, size_t lds, hipStream_t st, const float* gi, const float* whh,
-                                      const float* bhh, float* y, float* gates, int* cnt, int* status, int B, int T, int H,
-                                      int KP, int nJ, int nJp, int nbb) {
-  hipLaunchKernelGGL(gru_fwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, cnt, status, B,
-                     T, H, KP, nJ, nJp, nbb);
+static void launch_gru_fwd_persistent(int grid, hipStream_t st, const float* gi, const float* whh, const float* bhh, float* y,
+                                      float* gates, int* status, int B, int T, int H, int nJ, int nbb) {
+  constexpr int WS2 = (128 * MAXK2 + 48) / 2;
+  const size_t lds = (size_t)2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_F * sizeof(float);
+  hipLaunchKernelGGL(gru_fwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, status, B, T, H,
+                     nJ, nbb);
 }
 
 extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws,
                              int B, int T, int H, void* stream) {
   const void* ptrs[] = {gi, whh, bhh, y, gates};
   if (int e = gru_validate(ptrs, 5, B, T, H)) return e;
+  hipStream_t st = static_cast<hipStream_t>(stream);
   if (gru_persistent_ok(B, H, ws)) {
-    const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM, nJp = (nJ + 7) / 8 * 8;
-    const int KP = ceil_to(H, 64);
-    const size_t lds = ((size_t)(GRU_BM + 3 * GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD + 4) * sizeof(float);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int* cnt = static_cast<int*>(ws);
-    int* status = cnt + (size_t)2 * nbb * T;
-    gru_clear_ws(ws, hopmi_gru_ws_bytes(B, T, H), st);
-    const int grid = 2 * nbb * nJp;
-    switch ((KP + 127) / 128) {
-      case 1: launch_gru_fwd_persistent<1>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
-      case 2: launch_gru_fwd_persistent<2>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
-      case 3: launch_gru_fwd_persistent<3>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
-      default: launch_gru_fwd_persistent<4>(grid, lds, st, gi, whh, bhh, y, gates, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+    const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
+    int* status = gru_status_word(ws, B, T, H);
+    gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), y, (size_t)B * T * 2 * H, st);
+    const int grid = gp_grid(nJ, nbb);
+    switch ((H + 127) / 128) {
+      case 1: launch_gru_fwd_persistent<1>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      case 2: launch_gru_fwd_persistent<2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      default: launch_gru_fwd_persistent<3>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
     }
     return check_launch("hopmi_gru_fwd(persistent)");
   }
-  if (ws != nullptr) gru_clear_ws(ws, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));   // status = 0
+  if (ws != nullptr) gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), nullptr, 0, st);                        // status = 0
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);
   const size_t lds = ((size_t)(GRU_BM + 3 * GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD) * sizeof(float);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   switch ((KP + 127) / 128) {
     case 1: launch_gru_fwd<1>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
     case 2: launch_gru_fwd<2>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
@@ -693,40 +772,37 @@ extern "C" size_t hopmi_gru_bwd_ws_floats(int B, int H) {
 }
 
 template <int MAXK2>
-static void launch_gru_bwd_persistent(int grid, size_t lds, hipStream_t st, const float* dy, const float* y,
-                                      const float* gates, const float* whhT, float* dgi, float* dgh, float* dhz, int* cnt,
-                                      int* status, int B, int T, int H, int KP, int nJ, int nJp, int nbb) {
-  hipLaunchKernelGGL(gru_bwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, dy, y, gates, whhT, dgi, dgh, dhz, cnt,
-                     status, B, T, H, KP, nJ, nJp, nbb);
+static void launch_gru_bwd_persistent(int grid, hipStream_t st, const float* dy, const float* y, const float* gates,
+                                      const float* whhT, float* dgi, float* dgh, int* status, int B, int T, int H, int nJ,
+                                      int nbb) {
+  constexpr int WS2 = (128 * MAXK2 + 48) / 2;
+  const size_t lds = (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_B * sizeof(float);
+  hipLaunchKernelGGL(gru_bwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, dy, y, gates, whhT, dgi, dgh, status, B,
+                     T, H, nJ, nbb);
 }
 
 extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
                              float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream) {
   const void* ptrs[] = {dy, y, gates, whhT, dgi, dgh, ws};
   if (int e = gru_validate(ptrs, 7, B, T, H)) return e;
+  hipStream_t st = static_cast<hipStream_t>(stream);
   if (gru_persistent_ok(B, H, ws2)) {
-    const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM, nJp = (nJ + 7) / 8 * 8;
-    const int KP = ceil_to(H, 64);
-    const size_t lds = ((size_t)(GRU_BM + 3 * GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD + 4) * sizeof(float);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int* cnt = static_cast<int*>(ws2);
-    int* status = cnt + (size_t)2 * nbb * T;
-    gru_clear_ws(ws2, hopmi_gru_ws_bytes(B, T, H), st);
-    const int grid = 2 * nbb * nJp;
-    switch ((KP + 127) / 128) {
-      case 1: launch_gru_bwd_persistent<1>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
-      case 2: launch_gru_bwd_persistent<2>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
-      case 3: launch_gru_bwd_persistent<3>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
-      default: launch_gru_bwd_persistent<4>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, cnt, status, B, T, H, KP, nJ, nJp, nbb); break;
+    const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
+    int* status = gru_status_word(ws2, B, T, H);
+    gru_prepare(ws2, hopmi_gru_ws_bytes(B, T, H), dgh, (size_t)B * T * 2 * 3 * H, st);
+    const int grid = gp_grid(nJ, nbb);
+    switch ((H + 127) / 128) {
+      case 1: launch_gru_bwd_persistent<1>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
+      case 2: launch_gru_bwd_persistent<2>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
+      default: launch_gru_bwd_persistent<3>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
     }
     return check_launch("hopmi_gru_bwd(persistent)");
   }
-  if (ws2 != nullptr) gru_clear_ws(ws2, hopmi_gru_ws_bytes(B, T, H), static_cast<hipStream_t>(stream));  // status = 0
+  if (ws2 != nullptr) gru_prepare(ws2, hopmi_gru_ws_bytes(B, T, H), nullptr, 0, st);                      // status = 0
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
   const dim3 grid(8 * ((2 * nJ + 7) / 8) * nbb, 1, 1);
   const int KP = ceil_to(H, 64);
   const size_t lds = ((size_t)(GRU_BM + GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD) * sizeof(float);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   switch ((KP + 127) / 128) {
     case 1: launch_gru_bwd<1>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
     case 2: launch_gru_bwd<2>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;

@@ -205,10 +205,14 @@ int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xh
  *   y     [B][T][2H]     layer output, forward direction in [:H], reverse in [H:]  (torch layout)
  *   gates [B][T][2][4H]  saved for the backward: r, z, n and (W_hn h + b_hn)
  * ws: nullable workspace of hopmi_gru_ws_bytes(B, T, H) bytes.  With it, and when every workgroup of the layer can
- * be resident at once (2 * ceil(B/32) * ceil8(ceil(H/16)) <= #CUs), the layer is ONE persistent launch (W_hh
- * slices stay in LDS, time steps hand h_t over through arrival counters); its last int is a status word that
- * is non-zero if a hand-off ever timed out.  Otherwise one launch per time step is enqueued (both directions
- * per launch).
+ * be resident at once (8 * ceil(2 ceil(B/16) / 8) * ceil(H/32) <= #CUs), the layer is ONE persistent launch: each
+ * workgroup owns 16 batch rows x 32 hidden units for all T steps, keeps its W_hh fragments in registers (split into
+ * hi + lo bf16 pairs; the product runs as three v_mfma_f32_16x16x32_bf16 terms, ~2^-16 relative per product, fp32
+ * accumulation) and the workgroups of a (direction, batch group) hand h_t over through y itself: y is filled with a
+ * "not written yet" NaN pattern before the launch and a consumer re-loads whatever still reads as that pattern
+ * (bounded).  The int at index [size - 16] of ws is a status word, non-zero if a hand-off ever timed out (y is then
+ * garbage).  Otherwise one exact-fp32 launch per time step is enqueued (both directions per launch).  y must be
+ * 8-byte aligned.
  */
 size_t hopmi_gru_ws_bytes(int B, int T, int H);
 int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws,
@@ -217,8 +221,9 @@ int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y,
 /* Back-propagation through time of the above.  dy [B][T][2H] -> dgi [B][T][2][3H] (gradient w.r.t. the
  * input projections) and dgh [B][T][2][3H] (w.r.t. the recurrent pre-activations); the caller turns them
  * into dx, dW_ih, db_ih, dW_hh, db_hh with four GEMMs / reductions.  whhT [2][H][3H] is W_hh transposed
- * per direction; ws holds hopmi_gru_bwd_ws_floats(B, H) floats; ws2 (nullable) = hopmi_gru_ws_bytes(B, T, H) bytes
- * enables the persistent one-launch form exactly as in hopmi_gru_fwd. */
+ * per direction; ws holds hopmi_gru_bwd_ws_floats(B, H) floats (used by the per-step form); ws2 (nullable) =
+ * hopmi_gru_ws_bytes(B, T, H) bytes enables the persistent one-launch form exactly as in hopmi_gru_fwd (the hand-off
+ * array is dgh). */
 size_t hopmi_gru_bwd_ws_floats(int B, int H);
 int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
                   float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);

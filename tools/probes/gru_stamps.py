@@ -20,8 +20,8 @@ def main():
     L.hopmi_gru_ws_bytes.restype = ctypes.c_size_t
     dev = torch.device("cuda:0")
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    names = ["gi prefetch + wait for h_{t-1}", "stage h (sc1) + sync", "MFMA (+ operand reads)", "partials -> LDS + sync",
-             "gates + stores", "drain stores + sync + signal"]
+    names = ["gi prefetch + load h_{t-1} rows until written", "split + LDS commit + sync", "MFMA (+ operand reads)",
+             "partials -> LDS + sync", "gates + stores"]
     for B, T, H in ((128, 34, 350), (128, 28, 64)):
         gi = torch.randn(B, T, 2, 3 * H, device=dev) * 0.3
         whh = torch.randn(2, 3 * H, H, device=dev) / H ** 0.5
@@ -38,9 +38,9 @@ def main():
         for _ in range(20): L.hopmi_gru_fwd(*args)
         e1.record(); torch.cuda.synchronize()
         st = stamps.view(-1, 8).cpu(); st = st[st[:, 0] > 0]
-        d = (st[:, 1:7] - st[:, 0:6]).double()
-        print(f"B={B} T={T} H={H}: {st.shape[0]} workgroups, {e0.elapsed_time(e1) * 50 / T:.2f} us per step; step total median {(st[:,6]-st[:,0]).double().median().item():.0f} cycles")
-        for i in range(6):
+        d = (st[:, 1:6] - st[:, 0:5]).double()
+        print(f"B={B} T={T} H={H}: {st.shape[0]} workgroups, {e0.elapsed_time(e1) * 50 / T:.2f} us per step; step total median {(st[:,5]-st[:,0]).double().median().item():.0f} cycles")
+        for i in range(5):
             print(f"    {names[i]:34s} median {d[:, i].median().item():7.0f}  max {d[:, i].max().item():7.0f}")
 
 if __name__ == "__main__":
