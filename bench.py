@@ -294,7 +294,11 @@ def main():
                                    + "; inside one step the batch-independent prototype branch (mapping layer, K/V projections) and the "
                                      "dropout-free audio branch (beat MLP, gwnet: 8 fused-layer launches) are computed ONCE and reused by the "
                                      "step's other forwards, whose BatchNorm running-statistics update is replayed on the same partial "
-                                     "sums (bit-identical to recomputing, tests/test_gpu_parity.py::test_step_cache_audio_branch_equals_recompute)",
+                                     "sums (bit-identical to recomputing, tests/test_gpu_parity.py::test_step_cache_audio_branch_equals_recompute)"
+                                   + ("" if gan else "; the discriminator score that train_llm.py:43-44 computes in every epoch and :81 never "
+                                      "uses before epoch 11 is not computed, only its lasting effect (the BatchNorm statistics update of the "
+                                      "discriminator's pre_conv) is (bit-identical losses, parameters and buffers, "
+                                      "tests/test_gpu_parity.py::test_train_llm_unused_score_elision)"),
                        "execution": "steps.train_llm issued from Python every step (--eager)" if args.eager else
                                     "hopmi.GraphedTrainStep: the launches of one steps.train_llm call recorded once as hipGraphs "
                                     "(cut behind the loss copy and around every collective) and replayed; dropout advances through a "

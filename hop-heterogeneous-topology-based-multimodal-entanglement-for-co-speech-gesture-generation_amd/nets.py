@@ -198,6 +198,16 @@ class ConvDiscriminator(nn.Module):
         x = self._bn_cl(self._conv3_cl(x, self.pre_conv[3]), self.pre_conv[4], self.training)
         return self._conv3_cl(x, self.pre_conv[6])
 
+    @torch.no_grad()
+    def update_statistics(self, poses):
+        """The only lasting effect of a training-mode `forward` whose score is discarded: the running-statistics update
+        of the two BatchNorm1d layers of pre_conv (steps.train_llm, epoch <= 10: train_llm.py:43-44 computes the score and
+        gen_error and :81 leaves them out of the loss)."""
+        if not self.training:
+            return
+        x = self._bn_cl(self._conv3_cl(poses.detach(), self.pre_conv[0]), self.pre_conv[1], True)
+        self._bn_cl(self._conv3_cl(x, self.pre_conv[3]), self.pre_conv[4], True)
+
     def forward(self, poses, in_text=None):
         # GEMM-shaped convs + the hand-written GRU recurrence (same cell as the decoder); like the generator this only
         # runs on a ROCm device (ops.gru_bidirectional raises for host tensors: no second, stock-torch path)

@@ -447,9 +447,10 @@ class _ReprogAttnFn(torch.autograd.Function):
         lse = torch.empty(B, Lq, H, dtype=torch.float32, device=q.device)
         Lb, st, sp = _lib.lib(), _stream(), _seed_ptr()
         N = B * Lq
+        ws = torch.empty(Lb.hopmi_reprog_attn_ws_bytes(S, H, E), dtype=torch.uint8, device=q.device)
         _lib.check(_timed("reprog_attn_fwd", 4 * (2 * N * H * E + 2 * S * H * E), 4 * N * H * S * E,
                           lambda: Lb.hopmi_reprog_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
-                                                           lse.data_ptr(), N, S, H, E, float(scale), float(p_drop),
+                                                           lse.data_ptr(), ws.data_ptr(), N, S, H, E, float(scale), float(p_drop),
                                                            int(seed) & _M32, sp, st)), "hopmi_reprog_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale, ctx.p_drop, ctx.seed, ctx.sp = float(scale), float(p_drop), int(seed) & _M32, sp

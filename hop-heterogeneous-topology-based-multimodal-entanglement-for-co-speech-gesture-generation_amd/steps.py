@@ -158,6 +158,11 @@ class _LossFetch:
         return self.decode(self.terms, self.host.tolist(), self.status is not None)
 
 
+# epoch <= 10: do not compute the discriminator score that train_llm.py:43-44 computes and never uses (same parameters, buffers
+# and returned losses; tests/test_gpu_parity.py::test_train_llm_unused_score_elision)
+ELIDE_UNUSED_SCORE = True
+
+
 def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,
               model, discriminator, model_optim, dis_optimizer, accelerator):
     pre_seq = target_dir_vec[:, 0:16]
@@ -178,9 +183,15 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
         model_optim.zero_grad()
         with _amp(args, target_dir_vec):
             outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
-            dis_output = discriminator(outputs, text_token_padded)
+            if epoch > 10 or not ELIDE_UNUSED_SCORE:
+                dis_output = discriminator(outputs, text_token_padded)
+                gen_error = -torch.mean(torch.log(dis_output.float() + 1e-8))
+            else:
+                # train_llm.py:43-44 scores the output here in every epoch, and :81 leaves gen_error out of the loss and of
+                # the returned dict until epoch 11: all that survives of the call is the BatchNorm statistics update
+                discriminator.update_statistics(outputs)
+                gen_error = None
             outputs = outputs.float()                                          # losses in fp32
-            gen_error = -torch.mean(torch.log(dis_output.float() + 1e-8))
             huber_loss = F.smooth_l1_loss(outputs / 0.1, target_dir_vec / 0.1) * 0.1
             kld = div_reg = None
             if (args.z_type == "speaker" or args.z_type == "random") and args.loss_reg_weight > 0.0:

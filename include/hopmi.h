@@ -155,8 +155,12 @@ int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, 
  *   pointer, nullable) is given: the stream position then lives in device memory, so a captured hipGraph of the
  *   training step draws fresh masks on every replay (the host adds to *seed_dev inside the graph).  Every seeded
  *   entry point below takes the same (seed, seed_dev) pair.
+ *   Both contractions run on v_mfma_f32_16x16x32_bf16 with every operand carried as a hi + lo bf16 pair (three terms,
+ *   ~2^-16 relative per product, fp32 accumulation and fp32 softmax).  ws: hopmi_reprog_attn_ws_bytes(S, H, E) bytes, the
+ *   bf16 operand images of k and v, rebuilt by every call (two small launches in front of the main kernel).
  */
-int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
+size_t hopmi_reprog_attn_ws_bytes(int S, int H, int E);
+int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, void* ws,
                           int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* Backward of the above: d_o [N][H][E] -> dq [N][H][E] and PARTIAL dk, dv [R][S][H][E] with

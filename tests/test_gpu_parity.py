@@ -592,6 +592,41 @@ def test_train_llm_vs_reference_golden(golden, V, epoch, monkeypatch):
             assert checksum_close(checksum(sd[str(n)]), want, RTOL, atol), (n, checksum(sd[str(n)]), want)
 
 
+def test_train_llm_unused_score_elision(monkeypatch):
+    """epoch <= 10: train_llm.py:43-44 scores the generated poses and :81 never uses the score.  steps.train_llm keeps only
+    the lasting effect of that call (pre_conv's BatchNorm statistics): the returned losses and every parameter / buffer of
+    both networks are bit-identical to a step that computes the score (the reference-golden test above pins the same
+    state against the reference itself)."""
+    import hopmi
+    from hopmi import steps
+    from oracle import fill
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    V = 9
+    monkeypatch.setattr(steps, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
+    monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))
+    out = []
+    for elide in (True, False):
+        monkeypatch.setattr(steps, "ELIDE_UNUSED_SCORE", elide)
+        m, bcfg = _make_model(V, dev)
+        d = hopmi.ConvDiscriminator(3 * V)
+        d.gru.dropout = 0.0                 # (inter-layer dropout would draw from the generator that the later steps also use)
+        fill.fill_state_(d, salt=1)
+        d.to(dev)
+        m.train(); d.train()
+        g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+        d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        inp = _inputs(V, bcfg, dev)
+        torch.manual_seed(777)
+        ret = hopmi.train_llm(step_args(V), 3, inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"],
+                              inp["vid_indices"], m, d, g_opt, d_opt, Accel())
+        out.append((ret, {k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in d.state_dict().items()}))
+    (ra, ma, da), (rb, mb, db) = out
+    assert ra == rb
+    assert all(torch.equal(ma[k], mb[k]) for k in ma) and all(torch.equal(da[k], db[k]) for k in da)
+    assert not torch.equal(da["pre_conv.1.running_mean"], torch.zeros_like(da["pre_conv.1.running_mean"]))
+
+
 _FULL = {}      # (V, B, epoch) -> the oracle's full-size step (loss dict, outputs, post-step state), computed once per session
 
 
