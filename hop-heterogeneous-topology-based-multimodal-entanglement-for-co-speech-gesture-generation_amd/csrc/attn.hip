@@ -18,14 +18,8 @@
 namespace hopmi {
 
 constexpr int AE = 128;            // head dim (d_keys = d_ff = 128, HOP.py:119)
-constexpr int AKC = 32;            // keys per chunk in the forward / dQ kernels: 43 KB of LDS => 3 workgroups per CU
 constexpr int ABM = 64;            // query rows per workgroup (16 per wave)
-constexpr int ALD = AE + 4;        // LDS row stride of the K / V (Q / dO) images
-constexpr int APLD = AKC + 4;      // LDS row stride of a wave's P tile
 constexpr int KVK = 64;            // dK/dV kernel: keys per workgroup (16 per wave)
-constexpr int KVR = 32;            // dK/dV kernel: query rows per staged tile
-constexpr int KVPLD = KVR + 4;     // LDS row stride of its transposed P / dS tiles
-constexpr int AKT = AKC / 16;      // key tiles per chunk
 
 // ------------------------------------------------------------------------------------------------------
 // bf16 operand images (split: hi + lo, bf16_dev.h) of a [S][H][E] fp32 tensor, made once per call by
@@ -135,7 +129,7 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
     }
   const int nchunk = Sp / 32;
   unsigned char* Pw = Pl_ + w * 2 * 16 * 64;
-  const int row_c0 = tile * ABM + 16 * w + 4 * q;
+  const unsigned row_c0 = (unsigned)(tile * ABM + 16 * w + 4 * q);
   HOPMI_ATTN_ISSUE(0)
 
   for (int c = 0; c < nchunk; ++c) {
@@ -159,49 +153,42 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
       }
     // ---- online softmax over this chunk (lane holds rows 4q + r, keys 2j + nt) ------------------------
     const int key0 = c * 32 + 2 * j;
+    const bool pad0 = key0 >= S, pad1 = key0 + 1 >= S;               // (the padded keys of the last chunk)
     float p[2][4], alpha[4];
+    bool moved = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float mx = -1e30f;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float sv = (key0 + nt < S) ? acc_s[nt][r] : -1e30f;
-        p[nt][r] = sv;
-        mx = fmaxf(mx, sv);
-      }
-      mx = row16_max(mx);
+      const float s0 = pad0 ? -1e30f : acc_s[0][r], s1 = pad1 ? -1e30f : acc_s[1][r];
+      const float mx = row16_max(fmaxf(s0, s1));
       const float m_new = fmaxf(m_run[r], mx);
+      moved |= m_new != m_run[r];
       alpha[r] = __expf(m_run[r] - m_new);
-      float sum = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float e = __expf(p[nt][r] - m_new);
-        p[nt][r] = e;
-        sum += e;
-      }
-      sum = row16_sum(sum);
-      l_run[r] = l_run[r] * alpha[r] + sum;
+      p[0][r] = __expf(s0 - m_new);
+      p[1][r] = __expf(s1 - m_new);
+      l_run[r] = l_run[r] * alpha[r] + (p[0][r] + p[1][r]);         // this lane's keys only: summed over the row at the end
       m_run[r] = m_new;
     }
     // dropout on the probabilities (HOP.py:296), P -> this wave's LDS tile, [row][key] order, hi and lo images
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float pv[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        pv[nt] = p[nt][r];
-        if (drop_thresh) pv[nt] = (attn_hash(seed, row_c0 + r, h, key0 + nt) >= drop_thresh) ? pv[nt] * drop_scale : 0.f;
+      float pv0 = p[0][r], pv1 = p[1][r];
+      if (drop_thresh) {
+        const unsigned x = attn_hash_pair(attn_rowhead(seed, row_c0 + r, (unsigned)h), (unsigned)(c * 16 + j));
+        pv0 = ((x & 0xFFFFu) >= drop_thresh) ? pv0 * drop_scale : 0.f;
+        pv1 = ((x >> 16) >= drop_thresh) ? pv1 * drop_scale : 0.f;
       }
-      const u32x2 sp = split2(pv[0], pv[1]);
+      const u32x2 sp = split2(pv0, pv1);
       const int prow = 4 * q + r;
       const int off = prow * 64 + (((j >> 2) ^ swz64(prow)) << 4) + ((j & 3) << 2);
       *reinterpret_cast<unsigned*>(Pw + off) = sp[0];
       *reinterpret_cast<unsigned*>(Pw + 16 * 64 + off) = sp[1];
     }
+    if (__ballot(moved) != 0ull) {                                  // some row's running maximum moved: rescale O
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
+      for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc_o[nt][r] *= alpha[r];
+        for (int r = 0; r < 4; ++r) acc_o[nt][r] *= alpha[r];
+    }
     // (the P tile is private to the wave: LDS operations of one wave complete in order, no barrier)
     // ---- O[16 rows][128] += P[16][32 keys] V[32 keys][128] --------------------------------------------
     {
@@ -223,11 +210,12 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = tile * ABM + 16 * w + 4 * q + r;
+    const float l_row = row16_sum(l_run[r]);
     if (row < N) {
-      const float inv = 1.f / l_run[r];
+      const float inv = 1.f / l_row;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) O[(size_t)row * rs + (size_t)h * AE + 16 * nt + j] = acc_o[nt][r] * inv;
-      if (j == 0) lse[(size_t)row * H + h] = m_run[r] + __logf(l_run[r]);
+      if (j == 0) lse[(size_t)row * H + h] = m_run[r] + __logf(l_row);
     }
   }
 }
@@ -242,27 +230,43 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
 //   reprog_attn_bwd_dkv_kernel  grid (64-key chunk, head): wave w owns 16 keys (K/V rows in registers, dK/dV
 //                               in accumulators) and loops over the query tiles staged through LDS
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                                 const float* __restrict__ Vv, const float* __restrict__ dO,
-                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 float* __restrict__ dQ, int N, int S, int H, float scale,
-                                                                 unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+// Both kernels take their B operands from the bf16 images of attn_images_kernel and run every contraction as three
+// v_mfma_f32_16x16x32_bf16 terms.  The softmax scale is folded into Q (the dQ kernel's fragments, the dK/dV kernel's Q
+// images: dK = dS^T Q with dS = P o (dP - delta) * scale is computed as (P o (dP - delta))^T (scale Q)).
+//
+// dQ kernel, per 32-key chunk: K image rows, V image rows (both 256 B, key-permuted as in the forward) and K^T image rows
+// (64 B) in LDS (48 KB => 3 workgroups per CU); S and dP = 48 MFMAs; dS -> the wave's packed tile, which reuses the V
+// region (one extra barrier per chunk); dQ += 24 MFMAs.
+__global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float* __restrict__ Q, const u16* __restrict__ Knat,
+                                                                 const u16* __restrict__ Vnat, const u16* __restrict__ Ktr,
+                                                                 const float* __restrict__ dO, const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta, float* __restrict__ dQ, int N,
+                                                                 int S, int Sp, int H, float scale, unsigned drop_thresh,
+                                                                 float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ks = smem;
-  float* Vs = Ks + AKC * ALD;
-  float* Ps = Vs + AKC * ALD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* Kl_ = lds;                        // [2 parts][32 rows][256 B]
+  unsigned char* Vl_ = lds + 2 * 32 * 256;         // [2 parts][32 rows][256 B]; then [4 waves][2 parts][16][64 B] dS tiles
+  unsigned char* Tl_ = Vl_ + 2 * 32 * 256;         // [2 parts][128 rows][64 B]  K^T
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int h = blockIdx.x % H, tile = blockIdx.x / H;
   const size_t rs = (size_t)H * AE;
   const int row_a = min(tile * ABM + 16 * w + j, N - 1);
 
-  float4 qf[8], dof[8];
+  u32x4 qh[4], ql[4], dh[4], dl[4];
   {
-    const float4* qp = reinterpret_cast<const float4*>(Q + (size_t)row_a * rs + (size_t)h * AE + 4 * q);
-    const float4* dp = reinterpret_cast<const float4*>(dO + (size_t)row_a * rs + (size_t)h * AE + 4 * q);
+    const f32x4* qp = reinterpret_cast<const f32x4*>(Q + (size_t)row_a * rs + (size_t)h * AE + 8 * q);
+    const f32x4* dp = reinterpret_cast<const f32x4*>(dO + (size_t)row_a * rs + (size_t)h * AE + 8 * q);
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii) { qf[ii] = qp[4 * ii]; dof[ii] = dp[4 * ii]; }
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = qp[8 * ks], b = qp[8 * ks + 1];
+      const Split8 f = split8(make_float4(a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale),
+                              make_float4(b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale));
+      qh[ks] = f.hi; ql[ks] = f.lo;
+      const f32x4 c = dp[8 * ks], d = dp[8 * ks + 1];
+      const Split8 g = split8(make_float4(c[0], c[1], c[2], c[3]), make_float4(d[0], d[1], d[2], d[3]));
+      dh[ks] = g.hi; dl[ks] = g.lo;
+    }
   }
   float lse_r[4], del_r[4];
 #pragma unroll
@@ -275,73 +279,102 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) acc_dq[nt] = {0.f, 0.f, 0.f, 0.f};
 
-  const int srow = tid >> 5, sc4 = tid & 31;
-  f32x4 kreg[AKC / 8], vreg[AKC / 8];          // native vectors: HIP's float4 struct arrays stayed in scratch here
-#define HOPMI_ATTN_ISSUE_KV(c_)                                                                          \
-  _Pragma("unroll") for (int it = 0; it < AKC / 8; ++it) {                                               \
-    const int key_ = min((c_) * AKC + srow + 8 * it, S - 1);                                             \
-    kreg[it] = reinterpret_cast<const f32x4*>(K + (size_t)key_ * rs + (size_t)h * AE)[sc4];              \
-    vreg[it] = reinterpret_cast<const f32x4*>(Vv + (size_t)key_ * rs + (size_t)h * AE)[sc4];             \
+  const u16* kbase = Knat + (size_t)h * 2 * Sp * AE;
+  const u16* vbase = Vnat + (size_t)h * 2 * Sp * AE;
+  const u16* tbase = Ktr + (size_t)h * 2 * AE * Sp;
+  int dst_k[2], dst_t[2];                                           // LDS offsets inside a part's image
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int u = tid + 256 * it;
+    const int k = u >> 4, s = u & 15, lrow = (k & 1) * 16 + (k >> 1);
+    dst_k[it] = lrow * 256 + ((s ^ (lrow & 15)) << 4);
+    const int e = u >> 2, s4 = u & 3;
+    dst_t[it] = e * 64 + ((s4 ^ swz64(e)) << 4);
   }
-  const int nchunk = (S + AKC - 1) / AKC;
-  float* Pw = Ps + w * 16 * APLD;
-  const int row_c0 = tile * ABM + 16 * w + 4 * q;
+  const int nchunk = Sp / 32;
+  unsigned char* Pw = Vl_ + w * 2 * 16 * 64;
+  const unsigned row_c0 = (unsigned)(tile * ABM + 16 * w + 4 * q);
 
   for (int c = 0; c < nchunk; ++c) {
-    HOPMI_ATTN_ISSUE_KV(c)
-    __syncthreads();
+    u32x4 pre[8];                                                   // other resident workgroups cover this latency
 #pragma unroll
-    for (int it = 0; it < AKC / 8; ++it) {
-      *reinterpret_cast<f32x4*>(Ks + (srow + 8 * it) * ALD + 4 * sc4) = kreg[it];
-      *reinterpret_cast<f32x4*>(Vs + (srow + 8 * it) * ALD + 4 * sc4) = vreg[it];
-    }
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int u = tid + 256 * it;
+        const size_t nat_off = ((size_t)part * Sp + c * 32 + (u >> 4)) * AE + 8 * (u & 15);
+        pre[part * 2 + it] = *reinterpret_cast<const u32x4*>(kbase + nat_off);
+        pre[4 + part * 2 + it] = *reinterpret_cast<const u32x4*>(vbase + nat_off);
+      }
+    __syncthreads();                                               // previous chunk's images and dS tiles consumed
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        *reinterpret_cast<u32x4*>(Kl_ + part * 32 * 256 + dst_k[it]) = pre[part * 2 + it];
+        *reinterpret_cast<u32x4*>(Vl_ + part * 32 * 256 + dst_k[it]) = pre[4 + part * 2 + it];
+      }
     __syncthreads();
+    u32x4 pret[4];                                                  // K^T rows: in flight under the S / dP products
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int u = tid + 256 * it;
+        pret[part * 2 + it] = *reinterpret_cast<const u32x4*>(tbase + ((size_t)part * AE + (u >> 2)) * Sp + c * 32 + 8 * (u & 3));
+      }
 
-    f32x4 acc_s[AKT], acc_dp[AKT];
+    f32x4 acc_s[2], acc_dp[2];
 #pragma unroll
-    for (int nt = 0; nt < AKT; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
+    for (int nt = 0; nt < 2; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii) {
-      float4 bk[AKT], bv[AKT];
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < AKT; ++nt) {
-        bk[nt] = *reinterpret_cast<const float4*>(Ks + (16 * nt + j) * ALD + 16 * ii + 4 * q);
-        bv[nt] = *reinterpret_cast<const float4*>(Vs + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+      for (int nt = 0; nt < 2; ++nt) {
+        const int off = (16 * nt + j) * 256 + (((4 * ks + q) ^ j) << 4);
+        const u32x4 kh = *reinterpret_cast<const u32x4*>(Kl_ + off);
+        const u32x4 kl = *reinterpret_cast<const u32x4*>(Kl_ + 32 * 256 + off);
+        acc_s[nt] = mfma_split3(qh[ks], ql[ks], kh, kl, acc_s[nt]);
+        const u32x4 vh = *reinterpret_cast<const u32x4*>(Vl_ + off);
+        const u32x4 vl = *reinterpret_cast<const u32x4*>(Vl_ + 32 * 256 + off);
+        acc_dp[nt] = mfma_split3(dh[ks], dl[ks], vh, vl, acc_dp[nt]);
       }
 #pragma unroll
-      for (int nt = 0; nt < AKT; ++nt) {
-        acc_s[nt] = mfma16(qf[ii].x, bk[nt].x, acc_s[nt]);
-        acc_dp[nt] = mfma16(dof[ii].x, bv[nt].x, acc_dp[nt]);
-        acc_s[nt] = mfma16(qf[ii].y, bk[nt].y, acc_s[nt]);
-        acc_dp[nt] = mfma16(dof[ii].y, bv[nt].y, acc_dp[nt]);
-        acc_s[nt] = mfma16(qf[ii].z, bk[nt].z, acc_s[nt]);
-        acc_dp[nt] = mfma16(dof[ii].z, bv[nt].z, acc_dp[nt]);
-        acc_s[nt] = mfma16(qf[ii].w, bk[nt].w, acc_s[nt]);
-        acc_dp[nt] = mfma16(dof[ii].w, bv[nt].w, acc_dp[nt]);
-      }
-    }
-    const int key0 = c * AKC;
+    for (int part = 0; part < 2; ++part)
 #pragma unroll
-    for (int nt = 0; nt < AKT; ++nt)
+      for (int it = 0; it < 2; ++it) *reinterpret_cast<u32x4*>(Tl_ + part * 128 * 64 + dst_t[it]) = pret[part * 2 + it];
+    __syncthreads();                                               // K^T rows visible; every wave is done with the V rows: their region takes the dS tiles
+    const int key0 = c * 32 + 2 * j;
+    const bool tail = c == nchunk - 1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + 16 * nt + j;
-        const float pr = (key < S) ? __expf(acc_s[nt][r] * scale - lse_r[r]) : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      float ds[2];
+      unsigned x = 0xFFFFFFFFu;
+      if (drop_thresh) x = attn_hash_pair(attn_rowhead(seed, row_c0 + r, (unsigned)h), (unsigned)(c * 16 + j));
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float pr = __expf(acc_s[nt][r] - lse_r[r]);
+        if (tail && key0 + nt >= S) pr = 0.f;
         float dp = acc_dp[nt][r];
-        if (drop_thresh) dp = (attn_hash(seed, row_c0 + r, h, key) >= drop_thresh) ? dp * drop_scale : 0.f;
-        Pw[(4 * q + r) * APLD + 16 * nt + j] = pr * (dp - del_r[r]) * scale;              // dS
+        if (drop_thresh) dp = (((nt ? x >> 16 : x & 0xFFFFu)) >= drop_thresh) ? dp * drop_scale : 0.f;
+        ds[nt] = pr * (dp - del_r[r]) * scale;
       }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < AKT; ++i) {
-      const float4 a = *reinterpret_cast<const float4*>(Pw + j * APLD + 16 * i + 4 * q);     // dS[row j][key]
-      const float* kb = Ks + (16 * i + 4 * q) * ALD + j;                                      // B[k = key][n = e]
+      const u32x2 sp = split2(ds[0], ds[1]);
+      const int prow = 4 * q + r;
+      const int off = prow * 64 + (((j >> 2) ^ swz64(prow)) << 4) + ((j & 3) << 2);
+      *reinterpret_cast<unsigned*>(Pw + off) = sp[0];
+      *reinterpret_cast<unsigned*>(Pw + 16 * 64 + off) = sp[1];
+    }
+    {
+      const int poff = j * 64 + ((q ^ swz64(j)) << 4);
+      const u32x4 ph = *reinterpret_cast<const u32x4*>(Pw + poff);
+      const u32x4 pl = *reinterpret_cast<const u32x4*>(Pw + 16 * 64 + poff);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-        acc_dq[nt] = mfma16(a.x, kb[16 * nt], acc_dq[nt]);
-        acc_dq[nt] = mfma16(a.y, kb[ALD + 16 * nt], acc_dq[nt]);
-        acc_dq[nt] = mfma16(a.z, kb[2 * ALD + 16 * nt], acc_dq[nt]);
-        acc_dq[nt] = mfma16(a.w, kb[3 * ALD + 16 * nt], acc_dq[nt]);
+        const int toff = (16 * nt + j) * 64 + ((q ^ swz64(j)) << 4);
+        const u32x4 th = *reinterpret_cast<const u32x4*>(Tl_ + toff);
+        const u32x4 tl = *reinterpret_cast<const u32x4*>(Tl_ + 128 * 64 + toff);
+        acc_dq[nt] = mfma_split3(ph, pl, th, tl, acc_dq[nt]);
       }
     }
   }
@@ -355,127 +388,161 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
   }
 }
 
-__global__ __launch_bounds__(256) void reprog_attn_bwd_dkv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                                  const float* __restrict__ Vv, const float* __restrict__ dO,
+// dK/dV kernel: workgroup = (64-key chunk, head, row split), wave w owns 16 keys: their K and V rows are MFMA A fragments
+// in registers, dK / dV live in accumulators.  The query-row tiles t = split, split + nsplit, ... (32 rows each) are
+// staged from the Q / dO images: natural rows for S^T = K Q^T and dP^T = V dO^T, transposed rows for dV += (P o M)^T dO
+// and dK += dS^T Q.  The partial dK / dV go to slab `split` of dKp / dVp ([nsplit][S][H][E]); the caller adds the slabs
+// in a fixed order.  80 KB of LDS => 2 workgroups per CU.
+__global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const float* __restrict__ K, const float* __restrict__ Vv,
+                                                                  const u16* __restrict__ Qnat, const u16* __restrict__ Qtr,
+                                                                  const u16* __restrict__ Dnat, const u16* __restrict__ Dtr,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                  float* __restrict__ dKp, float* __restrict__ dVp, int N, int S,
-                                                                  int H, int nsplit, float scale, unsigned drop_thresh,
+                                                                  float* __restrict__ dKp, float* __restrict__ dVp, int N, int Np,
+                                                                  int S, int H, int nsplit, unsigned drop_thresh,
                                                                   float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
-  // workgroup = (key chunk of 64, head, row split): the query-row tiles t = split, split + nsplit, ... are
-  // walked here and the partial dK / dV go to slab `split` of dKp / dVp ([nsplit][S][H][E]); the caller
-  // adds the slabs in a fixed order.
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;                                // [32 rows][ALD]
-  float* Ds = Qs + KVR * ALD;                      // [32 rows][ALD]  dO
-  float* Ps = Ds + KVR * ALD;                      // [4 waves][2][16][KVPLD]   (P o M)^T and dS^T tiles
-  float* Ls = Ps + 4 * 2 * 16 * KVPLD;             // [32] lse, [32] delta
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* Ql_ = lds;                        // [2 parts][32 rows][256 B]   (scaled) Q rows
+  unsigned char* Dl_ = Ql_ + 2 * 32 * 256;         //                            dO rows
+  unsigned char* QT_ = Dl_ + 2 * 32 * 256;         // [2 parts][128 rows][64 B]   (scaled) Q^T
+  unsigned char* DT_ = QT_ + 2 * 128 * 64;         //                            dO^T
+  unsigned char* Pl_ = DT_ + 2 * 128 * 64;         // [4 waves][2 tiles][2 parts][16][64 B]   (P o M)^T and dS^T
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int nchunk = (S + KVK - 1) / KVK;
   const int h = blockIdx.x % H, chunk = (blockIdx.x / H) % nchunk, split = blockIdx.x / (H * nchunk);
   const size_t rs = (size_t)H * AE;
   const int key_a = min(chunk * KVK + 16 * w + j, S - 1);        // A-layout key row of this lane
 
-  float4 kf[8], vf[8];
+  u32x4 kh[4], kl[4], vh[4], vl[4];
   {
-    const float4* kp = reinterpret_cast<const float4*>(K + (size_t)key_a * rs + (size_t)h * AE + 4 * q);
-    const float4* vp = reinterpret_cast<const float4*>(Vv + (size_t)key_a * rs + (size_t)h * AE + 4 * q);
+    const f32x4* kp = reinterpret_cast<const f32x4*>(K + (size_t)key_a * rs + (size_t)h * AE + 8 * q);
+    const f32x4* vp = reinterpret_cast<const f32x4*>(Vv + (size_t)key_a * rs + (size_t)h * AE + 8 * q);
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii) { kf[ii] = kp[4 * ii]; vf[ii] = vp[4 * ii]; }
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = kp[8 * ks], b = kp[8 * ks + 1];
+      const Split8 f = split8(make_float4(a[0], a[1], a[2], a[3]), make_float4(b[0], b[1], b[2], b[3]));
+      kh[ks] = f.hi; kl[ks] = f.lo;
+      const f32x4 c = vp[8 * ks], d = vp[8 * ks + 1];
+      const Split8 g = split8(make_float4(c[0], c[1], c[2], c[3]), make_float4(d[0], d[1], d[2], d[3]));
+      vh[ks] = g.hi; vl[ks] = g.lo;
+    }
   }
   f32x4 acc_dk[8], acc_dv[8];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) { acc_dk[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dv[nt] = {0.f, 0.f, 0.f, 0.f}; }
 
-  const int srow = tid >> 5, sc4 = tid & 31;
-  f32x4 qreg[KVR / 8], dreg[KVR / 8];
-  float lreg = 0.f, greg = 0.f;
-#define HOPMI_ATTN_ISSUE_QD(t_)                                                                          \
-  {                                                                                                      \
-    _Pragma("unroll") for (int it = 0; it < KVR / 8; ++it) {                                             \
-      const int row_ = min((t_) * KVR + srow + 8 * it, N - 1);                                           \
-      qreg[it] = reinterpret_cast<const f32x4*>(Q + (size_t)row_ * rs + (size_t)h * AE)[sc4];           \
-      dreg[it] = reinterpret_cast<const f32x4*>(dO + (size_t)row_ * rs + (size_t)h * AE)[sc4];          \
-    }                                                                                                    \
-    const int lrow_ = min((t_) * KVR + (tid & (KVR - 1)), N - 1);                                        \
-    lreg = lse[(size_t)lrow_ * H + h];                                                                   \
-    greg = delta[(size_t)lrow_ * H + h];                                                                 \
+  const u16* qn = Qnat + (size_t)h * 2 * Np * AE;
+  const u16* dn = Dnat + (size_t)h * 2 * Np * AE;
+  const u16* qt = Qtr + (size_t)h * 2 * AE * Np;
+  const u16* dt = Dtr + (size_t)h * 2 * AE * Np;
+  int dst_k[2], dst_t[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int u = tid + 256 * it;
+    const int k = u >> 4, s = u & 15, lrow = (k & 1) * 16 + (k >> 1);
+    dst_k[it] = lrow * 256 + ((s ^ (lrow & 15)) << 4);
+    const int e = u >> 2, s4 = u & 3;
+    dst_t[it] = e * 64 + ((s4 ^ swz64(e)) << 4);
   }
-  const int ntile = (N + KVR - 1) / KVR;
-  if (split < ntile) HOPMI_ATTN_ISSUE_QD(split)
-  float* Pw = Ps + w * 2 * 16 * KVPLD;             // (P o M)^T
-  float* Sw = Pw + 16 * KVPLD;                     // dS^T
+  const int ntile = Np / 32;
+  unsigned char* Pw = Pl_ + w * 2 * 2 * 16 * 64;   // (P o M)^T: hi, lo; then dS^T: hi, lo
   const int key_c0 = chunk * KVK + 16 * w + 4 * q; // C-layout key rows 4q + r of this wave's tile
 
   for (int t = split; t < ntile; t += nsplit) {
+    u32x4 pre[16];
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int u = tid + 256 * it;
+        const size_t nat_off = ((size_t)part * Np + t * 32 + (u >> 4)) * AE + 8 * (u & 15);
+        const size_t tr_off = ((size_t)part * AE + (u >> 2)) * Np + t * 32 + 8 * (u & 3);
+        pre[part * 2 + it] = *reinterpret_cast<const u32x4*>(qn + nat_off);
+        pre[4 + part * 2 + it] = *reinterpret_cast<const u32x4*>(dn + nat_off);
+        pre[8 + part * 2 + it] = *reinterpret_cast<const u32x4*>(qt + tr_off);
+        pre[12 + part * 2 + it] = *reinterpret_cast<const u32x4*>(dt + tr_off);
+      }
+    // lane holds key rows 4q + r, query rows row0 + 2j + nt
+    const int row0 = t * 32 + 2 * j;
+    float lrow[2], drow[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int rr = min(row0 + nt, N - 1);
+      lrow[nt] = lse[(size_t)rr * H + h];
+      drow[nt] = delta[(size_t)rr * H + h];
+    }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < KVR / 8; ++it) {
-      *reinterpret_cast<f32x4*>(Qs + (srow + 8 * it) * ALD + 4 * sc4) = qreg[it];
-      *reinterpret_cast<f32x4*>(Ds + (srow + 8 * it) * ALD + 4 * sc4) = dreg[it];
-    }
-    if (tid < KVR) { Ls[tid] = lreg; Ls[KVR + tid] = greg; }
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        *reinterpret_cast<u32x4*>(Ql_ + part * 32 * 256 + dst_k[it]) = pre[part * 2 + it];
+        *reinterpret_cast<u32x4*>(Dl_ + part * 32 * 256 + dst_k[it]) = pre[4 + part * 2 + it];
+        *reinterpret_cast<u32x4*>(QT_ + part * 128 * 64 + dst_t[it]) = pre[8 + part * 2 + it];
+        *reinterpret_cast<u32x4*>(DT_ + part * 128 * 64 + dst_t[it]) = pre[12 + part * 2 + it];
+      }
     __syncthreads();
-    if (t + nsplit < ntile) HOPMI_ATTN_ISSUE_QD(t + nsplit)
 
-    // S^T[16 keys][32 rows] = K_w Q^T ;  dP^T = V_w dO^T
+    // S^T[16 keys][32 rows] = K_w (scale Q)^T ;  dP^T = V_w dO^T
     f32x4 acc_s[2], acc_dp[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) { acc_s[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dp[nt] = {0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii) {
-      float4 bq[2], bd[2];
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        bq[nt] = *reinterpret_cast<const float4*>(Qs + (16 * nt + j) * ALD + 16 * ii + 4 * q);
-        bd[nt] = *reinterpret_cast<const float4*>(Ds + (16 * nt + j) * ALD + 16 * ii + 4 * q);
+        const int off = (16 * nt + j) * 256 + (((4 * ks + q) ^ j) << 4);
+        const u32x4 bqh = *reinterpret_cast<const u32x4*>(Ql_ + off);
+        const u32x4 bql = *reinterpret_cast<const u32x4*>(Ql_ + 32 * 256 + off);
+        acc_s[nt] = mfma_split3(kh[ks], kl[ks], bqh, bql, acc_s[nt]);
+        const u32x4 bdh = *reinterpret_cast<const u32x4*>(Dl_ + off);
+        const u32x4 bdl = *reinterpret_cast<const u32x4*>(Dl_ + 32 * 256 + off);
+        acc_dp[nt] = mfma_split3(vh[ks], vl[ks], bdh, bdl, acc_dp[nt]);
       }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        acc_s[nt] = mfma16(kf[ii].x, bq[nt].x, acc_s[nt]);
-        acc_dp[nt] = mfma16(vf[ii].x, bd[nt].x, acc_dp[nt]);
-        acc_s[nt] = mfma16(kf[ii].y, bq[nt].y, acc_s[nt]);
-        acc_dp[nt] = mfma16(vf[ii].y, bd[nt].y, acc_dp[nt]);
-        acc_s[nt] = mfma16(kf[ii].z, bq[nt].z, acc_s[nt]);
-        acc_dp[nt] = mfma16(vf[ii].z, bd[nt].z, acc_dp[nt]);
-        acc_s[nt] = mfma16(kf[ii].w, bq[nt].w, acc_s[nt]);
-        acc_dp[nt] = mfma16(vf[ii].w, bd[nt].w, acc_dp[nt]);
-      }
-    }
-    // lane holds key rows 4q + r, query-row column 16 nt + j
-    const int row0 = t * KVR;
+    unsigned xk[2][2];                                              // [row nt][key pair]: keys key_c0 + 0/1 and key_c0 + 2/3
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const int row = row0 + 16 * nt + j;
-      const float lrow = Ls[16 * nt + j], drow = Ls[KVR + 16 * nt + j];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key_c0 + r;
-        const float pr = (key < S && row < N) ? __expf(acc_s[nt][r] * scale - lrow) : 0.f;
-        float keepf = 1.f;
-        if (drop_thresh) keepf = (attn_hash(seed, row, h, key) >= drop_thresh) ? drop_scale : 0.f;
-        Pw[(4 * q + r) * KVPLD + 16 * nt + j] = pr * keepf;                                   // (P o M)^T
-        Sw[(4 * q + r) * KVPLD + 16 * nt + j] = pr * (acc_dp[nt][r] * keepf - drow) * scale;  // dS^T
-      }
+      const unsigned rh = attn_rowhead(seed, (unsigned)(row0 + nt), (unsigned)h);
+      xk[nt][0] = attn_hash_pair(rh, (unsigned)(key_c0 >> 1));
+      xk[nt][1] = attn_hash_pair(rh, (unsigned)(key_c0 >> 1) + 1u);
     }
-    __syncthreads();
-    // dV_w[16 keys][128] += (P o M)^T[16][32 rows] dO[32 rows][128];  dK_w += dS^T Q
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float4 ap = *reinterpret_cast<const float4*>(Pw + j * KVPLD + 16 * i + 4 * q);  // A[key j][row 16i+4q+e]
-      const float4 as = *reinterpret_cast<const float4*>(Sw + j * KVPLD + 16 * i + 4 * q);
-      const float* db = Ds + (16 * i + 4 * q) * ALD + j;                                     // B[k = row][n = e]
-      const float* qb = Qs + (16 * i + 4 * q) * ALD + j;
+    for (int r = 0; r < 4; ++r) {
+      const int key = key_c0 + r;
+      float pm[2], ds[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int row = row0 + nt;
+        const float pr = (key < S && row < N) ? __expf(acc_s[nt][r] - lrow[nt]) : 0.f;
+        float keepf = 1.f;
+        if (drop_thresh) keepf = (((r & 1) ? xk[nt][r >> 1] >> 16 : xk[nt][r >> 1] & 0xFFFFu) >= drop_thresh) ? drop_scale : 0.f;
+        pm[nt] = pr * keepf;                                          // (P o M)^T
+        ds[nt] = pr * (acc_dp[nt][r] * keepf - drow[nt]);             // dS^T / scale (the scale rides on the Q images)
+      }
+      const u32x2 sp = split2(pm[0], pm[1]), ss = split2(ds[0], ds[1]);
+      const int prow = 4 * q + r;
+      const int off = prow * 64 + (((j >> 2) ^ swz64(prow)) << 4) + ((j & 3) << 2);
+      *reinterpret_cast<unsigned*>(Pw + off) = sp[0];
+      *reinterpret_cast<unsigned*>(Pw + 16 * 64 + off) = sp[1];
+      *reinterpret_cast<unsigned*>(Pw + 2 * 16 * 64 + off) = ss[0];
+      *reinterpret_cast<unsigned*>(Pw + 3 * 16 * 64 + off) = ss[1];
+    }
+    // dV_w[16 keys][128] += (P o M)^T[16][32 rows] dO[32 rows][128];  dK_w += dS^T (scale Q)    (tiles are wave-private)
+    {
+      const int poff = j * 64 + ((q ^ swz64(j)) << 4);
+      const u32x4 ph = *reinterpret_cast<const u32x4*>(Pw + poff);
+      const u32x4 pl = *reinterpret_cast<const u32x4*>(Pw + 16 * 64 + poff);
+      const u32x4 sh = *reinterpret_cast<const u32x4*>(Pw + 2 * 16 * 64 + poff);
+      const u32x4 sl = *reinterpret_cast<const u32x4*>(Pw + 3 * 16 * 64 + poff);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-        acc_dv[nt] = mfma16(ap.x, db[16 * nt], acc_dv[nt]);
-        acc_dk[nt] = mfma16(as.x, qb[16 * nt], acc_dk[nt]);
-        acc_dv[nt] = mfma16(ap.y, db[ALD + 16 * nt], acc_dv[nt]);
-        acc_dk[nt] = mfma16(as.y, qb[ALD + 16 * nt], acc_dk[nt]);
-        acc_dv[nt] = mfma16(ap.z, db[2 * ALD + 16 * nt], acc_dv[nt]);
-        acc_dk[nt] = mfma16(as.z, qb[2 * ALD + 16 * nt], acc_dk[nt]);
-        acc_dv[nt] = mfma16(ap.w, db[3 * ALD + 16 * nt], acc_dv[nt]);
-        acc_dk[nt] = mfma16(as.w, qb[3 * ALD + 16 * nt], acc_dk[nt]);
+        const int toff = (16 * nt + j) * 64 + ((q ^ swz64(j)) << 4);
+        const u32x4 dth = *reinterpret_cast<const u32x4*>(DT_ + toff);
+        const u32x4 dtl = *reinterpret_cast<const u32x4*>(DT_ + 128 * 64 + toff);
+        acc_dv[nt] = mfma_split3(ph, pl, dth, dtl, acc_dv[nt]);
+        const u32x4 qth = *reinterpret_cast<const u32x4*>(QT_ + toff);
+        const u32x4 qtl = *reinterpret_cast<const u32x4*>(QT_ + 128 * 64 + toff);
+        acc_dk[nt] = mfma_split3(sh, sl, qth, qtl, acc_dk[nt]);
       }
     }
   }
@@ -513,7 +580,7 @@ extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float
     return HOPMI_EINVAL;
   }
   if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_reprog_attn_fwd: p_drop=%f outside [0,1)", p_drop); return HOPMI_EINVAL; }
-  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 65536.0) : 0u;   // 16-bit keep fields (attn_hash_pair)
   const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const int Sp = attn_sp(S);
   const size_t img = (size_t)2 * H * Sp * AE;                       // elements per image
@@ -534,25 +601,45 @@ extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float
 // it exactly 3 full rounds at the B = 128 shape
 extern "C" int hopmi_reprog_attn_bwd_splits(void) { return 8; }
 
+static int attn_np(int N) { return (N + 31) / 32 * 32; }
+extern "C" size_t hopmi_reprog_attn_bwd_ws_bytes(int N, int S, int H, int E) {
+  if (N <= 0 || S <= 0 || H <= 0 || E != AE) return 0;
+  return hopmi_reprog_attn_ws_bytes(S, H, E) + (size_t)4 * 2 * H * attn_np(N) * AE * sizeof(u16);
+}
+
 extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
-                                     const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
+                                     const float* delta, float* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
                                      float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
-  if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv) { set_error("hopmi_reprog_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv || !ws) { set_error("hopmi_reprog_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
   if (E != AE || N <= 0 || S <= 0 || H <= 0) {
     set_error("hopmi_reprog_attn_bwd: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", N, S, H, E);
     return HOPMI_EINVAL;
   }
   if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_reprog_attn_bwd: p_drop=%f outside [0,1)", p_drop); return HOPMI_EINVAL; }
-  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 65536.0) : 0u;   // 16-bit keep fields (attn_hash_pair)
   const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t lds_q = (size_t)(2 * AKC * ALD + 4 * 16 * APLD) * sizeof(float);
-  hipLaunchKernelGGL(reprog_attn_bwd_dq_kernel, dim3(((N + ABM - 1) / ABM) * H), dim3(256), lds_q, st, q, k, v, d_o, lse, delta,
-                     dq, N, S, H, scale, thresh, dscale, seed, seed_dev);
+  const int Sp = attn_sp(S), Np = attn_np(N);
+  const size_t kimg = (size_t)2 * H * Sp * AE, qimg = (size_t)2 * H * Np * AE;
+  u16* knat = static_cast<u16*>(ws);
+  u16* ktr = knat + kimg;
+  u16* vnat = ktr + kimg;
+  u16* qnat = knat + 4 * kimg;
+  u16* qtr = qnat + qimg;
+  u16* dnat = qtr + qimg;
+  u16* dtr = dnat + qimg;
+  hipLaunchKernelGGL(attn_images_kernel, dim3((Sp / 32) * H), dim3(256), 0, st, k, S, Sp, H, 1.f, knat, ktr);
+  hipLaunchKernelGGL(attn_images_kernel, dim3((Sp / 32) * H), dim3(256), 0, st, v, S, Sp, H, 1.f, vnat, (u16*)nullptr);
+  hipLaunchKernelGGL(attn_images_kernel, dim3((Np / 32) * H), dim3(256), 0, st, q, N, Np, H, scale, qnat, qtr);
+  hipLaunchKernelGGL(attn_images_kernel, dim3((Np / 32) * H), dim3(256), 0, st, d_o, N, Np, H, 1.f, dnat, dtr);
+  if (int e = check_launch("hopmi_reprog_attn_bwd(images)")) return e;
+  const size_t lds_q = (size_t)2 * 2 * 32 * 256 + 2 * 128 * 64;
+  hipLaunchKernelGGL(reprog_attn_bwd_dq_kernel, dim3(((N + ABM - 1) / ABM) * H), dim3(256), lds_q, st, q, knat, vnat, ktr, d_o,
+                     lse, delta, dq, N, S, Sp, H, scale, thresh, dscale, seed, seed_dev);
   if (int e = check_launch("hopmi_reprog_attn_bwd(dq)")) return e;
   const int nsplit = hopmi_reprog_attn_bwd_splits();
-  const size_t lds_kv = (size_t)(2 * KVR * ALD + 4 * 2 * 16 * KVPLD + 2 * KVR) * sizeof(float);
-  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel, dim3(((S + KVK - 1) / KVK) * H * nsplit), dim3(256), lds_kv, st, q, k, v, d_o,
-                     lse, delta, dk, dv, N, S, H, nsplit, scale, thresh, dscale, seed, seed_dev);
+  const size_t lds_kv = (size_t)2 * 2 * 32 * 256 + 2 * 2 * 128 * 64 + 4 * 2 * 2 * 16 * 64;
+  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel, dim3(((S + KVK - 1) / KVK) * H * nsplit), dim3(256), lds_kv, st, k, v, qnat, qtr,
+                     dnat, dtr, lse, delta, dk, dv, N, Np, S, H, nsplit, thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_reprog_attn_bwd(dkv)");
 }

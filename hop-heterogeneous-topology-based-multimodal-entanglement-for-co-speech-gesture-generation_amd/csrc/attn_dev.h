@@ -34,4 +34,15 @@ __device__ __forceinline__ unsigned attn_hash(unsigned seed, unsigned row, unsig
   return x;
 }
 
+// One hash per pair of adjacent keys (reprogramming attention): keep bits of keys 2 p and 2 p + 1 are the low and the high
+// 16 bits of the hash compared with p_drop * 2^16.  `rowhead` = attn_rowhead(seed, row, head) is hoisted per row.
+__device__ __forceinline__ unsigned attn_rowhead(unsigned seed, unsigned row, unsigned head) {
+  return seed ^ (row * 0x9E3779B1u) ^ (head * 0xC2B2AE3Du);
+}
+__device__ __forceinline__ unsigned attn_hash_pair(unsigned rowhead, unsigned pair) {
+  unsigned x = rowhead ^ (pair * 0x85EBCA77u);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;      // murmur3 fmix32
+  return x;
+}
+
 }  // namespace hopmi

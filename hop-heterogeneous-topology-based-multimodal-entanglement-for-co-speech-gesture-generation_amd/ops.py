@@ -374,12 +374,15 @@ def _seed_ptr():
     return None if SEED_DEV is None else SEED_DEV.data_ptr()
 
 
-def attn_keep_mask(seed: int, N: int, H: int, S: int, p_drop: float, device) -> torch.Tensor:
-    """The dropout keep-mask of hopmi_reprog_attn_fwd as a (N,H,S) bool tensor: the same stateless hash
-    (murmur3 finaliser of seed ^ row*c1 ^ key*c2 ^ head*c3) evaluated with integer tensor ops."""
+def attn_keep_mask(seed: int, N: int, H: int, S: int, p_drop: float, device, pairs: bool = False) -> torch.Tensor:
+    """The dropout keep-mask of the attention kernels as a (N,H,S) bool tensor: the same stateless hash (murmur3 finaliser of
+    seed ^ row*c1 ^ key*c2 ^ head*c3) evaluated with integer tensor ops.  pairs=False: hopmi_bert_attn_* (one hash per key,
+    compared with p_drop * 2^32); pairs=True: hopmi_reprog_attn_* (one hash per pair of adjacent keys 2p, 2p+1: its low and
+    high 16 bits compared with p_drop * 2^16)."""
     row = torch.arange(N, device=device, dtype=torch.int64).view(N, 1, 1)
     head = torch.arange(H, device=device, dtype=torch.int64).view(1, H, 1)
-    key = torch.arange(S, device=device, dtype=torch.int64).view(1, 1, S)
+    nk = (S + 1) // 2 if pairs else S
+    key = torch.arange(nk, device=device, dtype=torch.int64).view(1, 1, nk)
     x = (seed & _M32) ^ ((row * 0x9E3779B1) & _M32) ^ ((key * 0x85EBCA77) & _M32) ^ ((head * 0xC2B2AE3D) & _M32)
     x = x ^ (x >> 16)
     x = (x * 0x85EBCA6B) & _M32
@@ -389,6 +392,9 @@ def attn_keep_mask(seed: int, N: int, H: int, S: int, p_drop: float, device) -> 
     # the kernels receive p_drop as a C float and form the threshold from that value: round the same way here (with
     # the double 0.1 the thresholds differ by 7, i.e. one mask bit in ~6e8 elements)
     p32 = float(torch.tensor(p_drop, dtype=torch.float32))
+    if pairs:
+        t16 = int(p32 * 65536.0)
+        return torch.stack([(x & 0xFFFF) >= t16, (x >> 16) >= t16], dim=-1).reshape(N, H, 2 * nk)[:, :, :S]
     return x >= int(p32 * 4294967296.0)
 
 
@@ -470,10 +476,11 @@ class _ReprogAttnFn(torch.autograd.Function):
         dk = torch.empty((R,) + tuple(k.shape), dtype=torch.float32, device=q.device)
         dv = torch.empty_like(dk)
         N = B * Lq
+        ws = torch.empty(Lb.hopmi_reprog_attn_bwd_ws_bytes(N, S, H, E), dtype=torch.uint8, device=q.device)
         _lib.check(_timed("reprog_attn_bwd", 4 * (4 * N * H * E + 4 * S * H * E), 14 * N * H * S * E,
                           lambda: Lb.hopmi_reprog_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(),
                                                            lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                                           dv.data_ptr(), N, S, H, E, ctx.scale, ctx.p_drop, ctx.seed, ctx.sp, st)),
+                                                           dv.data_ptr(), ws.data_ptr(), N, S, H, E, ctx.scale, ctx.p_drop, ctx.seed, ctx.sp, st)),
                    "hopmi_reprog_attn_bwd")
         return dq, dk.sum(0), dv.sum(0), None, None, None
 

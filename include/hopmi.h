@@ -165,11 +165,14 @@ int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float*
 
 /* Backward of the above: d_o [N][H][E] -> dq [N][H][E] and PARTIAL dk, dv [R][S][H][E] with
  * R = hopmi_reprog_attn_bwd_splits() (the query rows are split R ways over workgroups; the caller adds the
- * R slabs in order).  delta [N][H] = sum_e d_o * o (one small reduction by the caller).  Two launches,
- * every output element has one owner: no atomics, bitwise reproducible. */
+ * R slabs in order).  delta [N][H] = sum_e d_o * o (one small reduction by the caller).  ws:
+ * hopmi_reprog_attn_bwd_ws_bytes(N, S, H, E) bytes (bf16 operand images of k, v, q, d_o, rebuilt by every call).  Four
+ * image launches + two main launches (same split-bf16 arithmetic as the forward); every output element has one owner:
+ * no atomics, bitwise reproducible. */
 int hopmi_reprog_attn_bwd_splits(void);
+size_t hopmi_reprog_attn_bwd_ws_bytes(int N, int S, int H, int E);
 int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
-                          const float* delta, float* dq, float* dk, float* dv, int N, int S, int H, int E,
+                          const float* delta, float* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
                           float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* ---- self-attention of the frozen BERT encoder (HOP.py:204 -> transformers BertSelfAttention.forward; replaces

@@ -218,7 +218,7 @@ def test_reprogramming_layer_vs_oracle(golden, tag, B, S, d_llm, p_drop):
     seed = (torch.initial_seed() * 2654435761 + 101 * 40503) & 0xFFFFFFFF
     mask = None
     if p_drop > 0:
-        mask = ops.attn_keep_mask(seed, B * 34, 8, S, p_drop, "cpu").view(B, 34, 8, S).permute(0, 2, 1, 3).float()
+        mask = ops.attn_keep_mask(seed, B * 34, 8, S, p_drop, "cpu", pairs=True).view(B, 34, 8, S).permute(0, 2, 1, 3).float()
         assert 0.85 < mask.mean().item() < 0.95
     sd = spec.build_sd(spec.reprog_spec(d_llm, prefix=""))
     for v in sd.values():
