@@ -27,6 +27,8 @@
 
 namespace hopmi {
 
+constexpr int WN_FIN_G = 16;     // workgroups of the BatchNorm finalisation (wn_bn_finalize_kernel)
+
 // gate non-linearities on the hardware exp (v_exp_f32): absolute error ~1e-7, far inside the 1e-3 bar
 __device__ __forceinline__ float sigmoid_(float x) { return __frcp_rn(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
@@ -433,54 +435,89 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
       *reinterpret_cast<f32x4*>(p + 16 * w + 4 * q) = st1;
       *reinterpret_cast<f32x4*>(p + C + 16 * w + 4 * q) = st2;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0)                         // arrival counter of wn_bn_finalize_kernel (behind its tail)
+      *reinterpret_cast<int*>(stats_part + (size_t)gridDim.x * 2 * 2 * C + (size_t)WN_FIN_G * 2 * C * 2) = 0;
   }
 }
 
-// BatchNorm2d training-mode finalisation (gwnet.py:237; torch semantics: biased variance normalises,
-// unbiased variance feeds running_var, momentum 0.1): fixed-order sum of the per-workgroup partials.
-__global__ __launch_bounds__(1024) void wn_bn_finalize_kernel(const float* __restrict__ part, int nblk, double n,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                              float momentum, float eps, float* __restrict__ scsh_out,
-                                                              float* __restrict__ mean_rstd_out) {
-  // 8 chunks x 128 columns (64 sums, 64 sums of squares): thread (chunk, col) adds the partials of the
-  // workgroups b = chunk (mod 8) in a fixed order with 8 independent loads in flight; then the 8 chunk
-  // sums are added in a fixed order (bitwise reproducible).
-  __shared__ double red[8][2 * C];
-  const int col = threadIdx.x & 127, chunk = threadIdx.x >> 7;
-  double acc = 0.0;
-  for (int b0 = chunk; b0 < nblk; b0 += 256) {       // 32 loads in flight: one memory round trip for up to 256 partials
-    float v[32];
+// BatchNorm2d training-mode finalisation (gwnet.py:237; torch semantics: biased variance normalises, unbiased variance feeds
+// running_var, momentum 0.1) from the per-workgroup partial rows of the layer kernel.  A single workgroup adding 512 rows
+// is bound by the memory requests one CU can keep in flight (~20 us measured, more than the layer kernel itself): the rows
+// are summed by WN_FIN_G workgroups (fixed order inside each), and the last one to arrive adds the WN_FIN_G sums in index
+// order and finalises -- bitwise reproducible, no waiting anywhere.  `tail` (behind the partial rows in ws): WN_FIN_G x 256
+// doubles + the arrival counter (zeroed by the layer kernel, left at zero again here).
+__global__ __launch_bounds__(256) void wn_bn_finalize_kernel(const float* __restrict__ part, int nblk, double n,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             float momentum, float eps, float* __restrict__ scsh_out,
+                                                             float* __restrict__ mean_rstd_out, double* tail) {
+  __shared__ double red[2][2 * C];
+  __shared__ int last;
+  const int col = threadIdx.x & 127, half = threadIdx.x >> 7, g = blockIdx.x;
+  int* counter = reinterpret_cast<int*>(tail + (size_t)WN_FIN_G * 2 * C);
+  {
+    // rows g + WN_FIN_G (2 k + half), k = 0, 1, ...: up to 16 per thread, all loads in flight at once
+    float v[16];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      const int b = b0 + 8 * u;
-      v[u] = (b < nblk) ? part[(size_t)min(b, nblk - 1) * 2 * C + col] : 0.f;
+    for (int u = 0; u < 16; ++u) {
+      const int b = g + WN_FIN_G * (2 * u + half);
+      v[u] = (b < nblk) ? part[(size_t)b * 2 * C + col] : 0.f;
     }
+    double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) acc += (double)v[u];
+    for (int u = 0; u < 16; ++u) acc += (double)v[u];
+    for (int b = g + WN_FIN_G * (32 + half); b < nblk; b += 2 * WN_FIN_G) acc += (double)part[(size_t)b * 2 * C + col];   // (grids beyond 256)
+    red[half][col] = acc;
   }
-  red[chunk][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < 2 * C) {
+    const double sum = red[0][threadIdx.x] + red[1][threadIdx.x];
+    __hip_atomic_store(tail + (size_t)g * 2 * C + threadIdx.x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int seen = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = seen == WN_FIN_G - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < WN_FIN_G; ++k) t += __hip_atomic_load(tail + (size_t)k * 2 * C + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[0][threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (threadIdx.x < C) {
     const int c = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { s1 += red[k][c]; s2 += red[k][C + c]; }
+    const double s1 = red[0][c], s2 = red[0][C + c];
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * rstd;
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
     scsh_out[c] = sc;
     scsh_out[C + c] = beta[c] - (float)mean * sc;
     mean_rstd_out[c] = (float)mean;
     mean_rstd_out[C + c] = rstd;
+    mean_rstd_out[2 * C + c] = (float)unbiased;
     if (running_mean != nullptr) {
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   }
+}
+
+// the same running-statistics update once more, from the (mean, rstd, unbiased variance) a finalisation left behind
+__global__ __launch_bounds__(64) void wn_bn_replay_kernel(const float* __restrict__ stats, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum) {
+  const int c = threadIdx.x;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * stats[c];
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * stats[2 * C + c];
 }
 
 // forward tiling: one 8-wave workgroup per CU, tiles of up to 80 rows, sized so that the grid covers the launch in one
@@ -580,7 +617,8 @@ extern "C" int hopmi_wn_prepare_weights(const float* const* wf, const float* con
 extern "C" size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation) {
   if (wn_validate(B, T_in, V, dilation)) return 0;
   const LayerGeom L = make_fwd_geom(B, T_in, V, dilation);
-  return (size_t)wn_grid(L) * 2 * 2 * C;                 // one (sum, sum of squares) row per (workgroup, row half)
+  // one (sum, sum of squares) row per (workgroup, row half) + the finalisation's tail (WN_FIN_G x 256 doubles, counter)
+  return (size_t)wn_grid(L) * 2 * 2 * C + (size_t)WN_FIN_G * 2 * C * 2 + 4;
 }
 
 extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const void* wimg, const float* bf, const float* bg,
@@ -615,7 +653,15 @@ extern "C" int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const f
   if (int e = wn_validate(B, T_in, V, dilation)) return e;
   if (!ws || !gamma || !beta || !scsh_out || !mean_rstd_out) { set_error("hopmi_wn_bn_finalize: null pointer argument"); return HOPMI_EINVAL; }
   const LayerGeom L = make_fwd_geom(B, T_in, V, dilation);
-  hipLaunchKernelGGL(wn_bn_finalize_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), ws, 2 * wn_grid(L),
-                     (double)L.n_slabs * V, gamma, beta, running_mean, running_var, momentum, eps, scsh_out, mean_rstd_out);
+  double* tail = reinterpret_cast<double*>(const_cast<float*>(ws) + (size_t)wn_grid(L) * 2 * 2 * C);
+  hipLaunchKernelGGL(wn_bn_finalize_kernel, dim3(WN_FIN_G), dim3(256), 0, static_cast<hipStream_t>(stream), ws, 2 * wn_grid(L),
+                     (double)L.n_slabs * V, gamma, beta, running_mean, running_var, momentum, eps, scsh_out, mean_rstd_out, tail);
   return check_launch("hopmi_wn_bn_finalize");
+}
+
+extern "C" int hopmi_wn_bn_replay(const float* mean_rstd, float* running_mean, float* running_var, float momentum, void* stream) {
+  if (!mean_rstd || !running_mean || !running_var) { set_error("hopmi_wn_bn_replay: null pointer argument"); return HOPMI_EINVAL; }
+  hipLaunchKernelGGL(wn_bn_replay_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), mean_rstd, running_mean,
+                     running_var, momentum);
+  return check_launch("hopmi_wn_bn_replay");
 }

@@ -535,7 +535,7 @@ def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_
     stack-level Function.  xin (B,T_in,V,64) contiguous; wimg: this layer's row of wn_prepare_weights(); utail: a
     (B,4,V,64) view whose last-dim stride is 1 (a channel slice of the (B,4,V,512) skip-tail buffer).  bn = (gamma, beta,
     running_mean, running_var, momentum, eps) for training-mode batch statistics -> returns scale/shift for the next
-    layer and (mean, rstd).  `stats_keep`: a list that receives (partial-sum workspace, B, T_in, V, dilation) so
+    layer and (mean, rstd).  `stats_keep`: a list that receives the layer's (mean, rstd, unbiased variance) row so
     that the same running-statistics update can be applied again (wn_bn_replay).  `want_fs` (diagnostic): also return the
     tanh / sigmoid gate values.  Returns (y, fs, scsh_out, mean_rstd)."""
     B, T_in, V, _ = xin.shape
@@ -550,7 +550,7 @@ def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_
     if bn is not None:
         gamma, beta, rm, rv, momentum, eps = bn
         scsh_out = torch.empty(128, dtype=torch.float32, device=dev)
-        mean_rstd = torch.empty(128, dtype=torch.float32, device=dev)
+        mean_rstd = torch.empty(192, dtype=torch.float32, device=dev)       # mean, rstd, unbiased variance
         ws = torch.empty(L.hopmi_wn_layer_ws_floats(B, T_in, V, dilation), dtype=torch.float32, device=dev)
     if utail is not None and (utail.stride(-1) != 1 or utail.stride(2) % 4 or utail.shape != (B, 4, V, 64)):
         raise _lib.HopmiError(f"hopmi wn_layer: bad utail view {tuple(utail.shape)} strides {utail.stride()}")
@@ -572,7 +572,7 @@ def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_
                                           float(momentum), float(eps), scsh_out.data_ptr(), mean_rstd.data_ptr(),
                                           B, T_in, V, dilation, st), "hopmi_wn_bn_finalize")
         if stats_keep is not None:
-            stats_keep.append((ws, B, T_in, V, dilation))
+            stats_keep.append(mean_rstd)
     return y, fs, scsh_out, mean_rstd
 
 
@@ -583,14 +583,10 @@ def wn_fused_training_supported(V: int) -> bool:
 
 
 def wn_bn_replay(kept, bn):
-    """Advance bn's running statistics once more with the batch statistics of an earlier wn_layer_fwd call
-    (the same hopmi_wn_bn_finalize on the same partial sums, so the update is bit-identical to recomputing)."""
-    ws, B, T_in, V, dilation = kept
-    scratch = torch.empty(256, dtype=torch.float32, device=ws.device)
-    _lib.check(_lib.lib().hopmi_wn_bn_finalize(ws.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                               bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum),
-                                               float(bn.eps), scratch.data_ptr(), scratch[128:].data_ptr(),
-                                               B, T_in, V, dilation, _stream()), "hopmi_wn_bn_finalize")
+    """Advance bn's running statistics once more with the batch statistics of an earlier wn_layer_fwd call (`kept` = its
+    mean / rstd / unbiased-variance row: the same floats the first update used, so this is bit-identical to recomputing)."""
+    _lib.check(_lib.lib().hopmi_wn_bn_replay(kept.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                             float(bn.momentum), _stream()), "hopmi_wn_bn_replay")
 
 
 def wn_layer_bwd(xin, scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next, y, bn_coef, dutail, gamma_prev, mean_rstd_prev,

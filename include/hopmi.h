@@ -115,12 +115,16 @@ int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const void* wimg,
                        int utail_ld, float* ws, int B, int T_in, int V, int dilation, int do_gcn, void* stream);
 
 /* BatchNorm2d training-mode finalisation (gwnet.py:237) from the partials of the layer call with the same
- * (B, T_in, V, dilation): fixed-order sums -> mean_rstd_out [128] (mean, rstd), scsh_out [128] = the scale / shift
- * the next layer applies on load, running_mean / running_var [64] updated in place (nullable) with torch
- * semantics (biased variance normalises, unbiased feeds running_var). */
+ * (B, T_in, V, dilation): fixed-order sums (16 workgroups, the last to arrive combines them in index order) ->
+ * mean_rstd_out [192] (mean, rstd, unbiased variance), scsh_out [128] = the scale / shift the next layer applies on
+ * load, running_mean / running_var [64] updated in place (nullable) with torch semantics (biased variance normalises,
+ * unbiased feeds running_var).  ws is the layer call's workspace (the kernel uses its tail as scratch).
+ * hopmi_wn_bn_replay applies the same running-statistics update once more from a mean_rstd_out (the step's second
+ * generator forward reuses the audio branch: model/HOP.py:186-196 would run it, and update the statistics, again). */
 int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float momentum, float eps, float* scsh_out, float* mean_rstd_out,
                          int B, int T_in, int V, int dilation, void* stream);
+int hopmi_wn_bn_replay(const float* mean_rstd, float* running_mean, float* running_var, float momentum, void* stream);
 
 /* Backward of one fused WaveNet layer (autograd of gwnet.py:181-237), see csrc/wavenet_bwd.hip.
  *   xin, scsh_in, fs, wf, wg, prep, Wm : as in / saved by the forward
