@@ -31,6 +31,9 @@ SIGNATURES = {
     "hopmi_wn_bn_finalize": (_I, [_VP] * 5 + [ctypes.c_float, ctypes.c_float] + [_VP] * 2 + [_I] * 4 + [_VP]),
     "hopmi_wn_layer_bwd_ws_floats": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "hopmi_wn_layer_bwd": (_I, [_VP] * 9 + [_I] + [_VP] * 3 + [_I] + [_VP] * 11 + [_I] + [_VP] * 4 + [_I] * 5 + [_VP]),
+    "hopmi_hop_losses_ws_floats": (ctypes.c_size_t, [_I]),
+    "hopmi_hop_losses_fwd": (_I, [_VP] * 7 + [_I] * 3 + [ctypes.c_float] * 3 + [_VP] * 3),
+    "hopmi_hop_losses_bwd": (_I, [_VP] * 7 + [_I] * 3 + [ctypes.c_float] * 2 + [_VP] * 4),
     "hopmi_reprog_attn_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_reprog_attn_fwd": (_I, [_VP] * 6 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_reprog_attn_bwd_splits": (_I, []),

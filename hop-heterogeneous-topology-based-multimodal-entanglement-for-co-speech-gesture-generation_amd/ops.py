@@ -485,6 +485,54 @@ class _ReprogAttnFn(torch.autograd.Function):
         return dq, dk.sum(0), dv.sum(0), None, None, None
 
 
+class _HopLossesFn(torch.autograd.Function):
+    """The generator losses of one train_llm step (train_llm.py:46-79) in two launches (hopmi_hop_losses_fwd) and their
+    gradient in one (hopmi_hop_losses_bwd).  Returns (total, vals): total = w_reg huber + w_div div_reg + w_kld kld is the
+    differentiable scalar, vals = (huber, div_reg, kld, total) for reporting."""
+
+    @staticmethod
+    def forward(ctx, out, target, out_rand, zc, zr, mu, lv, w_reg, w_div, w_kld):
+        f = lambda t, n: None if t is None else _dev_f32(t, n)
+        out, target = _dev_f32(out, "out"), _dev_f32(target, "target")
+        out_rand, zc, zr, mu, lv = f(out_rand, "out_rand"), f(zc, "z_context"), f(zr, "z_rand"), f(mu, "mu"), f(lv, "logvar")
+        B = out.shape[0]
+        F_ = out.numel() // B
+        zt = zc if zc is not None else mu
+        Z = 0 if zt is None else zt.numel() // B
+        if target.shape != out.shape or (out_rand is not None and out_rand.shape != out.shape):
+            raise _lib.HopmiError(f"hopmi hop_losses: shapes out{tuple(out.shape)} target{tuple(target.shape)}")
+        L, st = _lib.lib(), _stream()
+        vals = torch.empty(4, dtype=torch.float32, device=out.device)
+        ws = torch.empty(L.hopmi_hop_losses_ws_floats(B), dtype=torch.float32, device=out.device)
+        _lib.check(L.hopmi_hop_losses_fwd(out.data_ptr(), target.data_ptr(), _ptr(out_rand), _ptr(zc), _ptr(zr), _ptr(mu), _ptr(lv),
+                                          B, F_, Z, float(w_reg), float(w_div), float(w_kld), vals.data_ptr(), ws.data_ptr(), st),
+                   "hopmi_hop_losses_fwd")
+        ctx.save_for_backward(out, target, out_rand, mu, lv, ws)
+        ctx.dims, ctx.w = (B, F_, Z), (float(w_reg), float(w_kld))
+        total = vals[3].clone()
+        ctx.mark_non_differentiable(vals)
+        return total, vals
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        out, target, out_rand, mu, lv, ws = ctx.saved_tensors
+        B, F_, Z = ctx.dims
+        g = _dev_f32(g, "g")
+        d_out = torch.empty_like(out)
+        d_mu = torch.empty_like(mu) if mu is not None else None
+        d_lv = torch.empty_like(lv) if lv is not None else None
+        _lib.check(_lib.lib().hopmi_hop_losses_bwd(out.data_ptr(), target.data_ptr(), _ptr(out_rand), _ptr(mu), _ptr(lv),
+                                                   ws.data_ptr(), g.data_ptr(), B, F_, Z, ctx.w[0], ctx.w[1], d_out.data_ptr(),
+                                                   _ptr(d_mu), _ptr(d_lv), _stream()), "hopmi_hop_losses_bwd")
+        return d_out, None, None, None, None, d_mu, d_lv, None, None, None
+
+
+def hop_losses(out, target, out_rand=None, z_context=None, z_rand=None, mu=None, logvar=None, w_reg=1.0, w_div=0.0, w_kld=0.0):
+    """(total, vals): see _HopLossesFn.  out_rand / z_context / z_rand (all or none) enable the diversity regulariser,
+    mu / logvar (both or none) the KLD term; out_rand, z_context, z_rand and target take no gradient."""
+    return _HopLossesFn.apply(out, target, out_rand, z_context, z_rand, mu, logvar, w_reg, w_div, w_kld)
+
+
 def reprog_attention(q, k, v, scale, p_drop=0.0, seed=0):
     return _ReprogAttnFn.apply(q, k, v, scale, p_drop, seed)
 

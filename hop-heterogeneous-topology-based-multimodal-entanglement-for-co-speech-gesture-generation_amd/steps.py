@@ -192,7 +192,6 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
                 discriminator.update_statistics(outputs)
                 gen_error = None
             outputs = outputs.float()                                          # losses in fp32
-            huber_loss = F.smooth_l1_loss(outputs / 0.1, target_dir_vec / 0.1) * 0.1
             kld = div_reg = None
             if (args.z_type == "speaker" or args.z_type == "random") and args.loss_reg_weight > 0.0:
                 rand_vids = None
@@ -200,13 +199,15 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
                     rand_vids = vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)]
                 with torch.no_grad():                                          # only used detached (:60,65)
                     out_rand, z_rand, _, _ = model(in_audio, log_melspec, text_token_padded, pre_seq, rand_vids)
-                div_reg, kld = _regularisers(args, outputs, z_context.float(), z_mu.float(), z_logvar.float(),
-                                             out_rand.float(), z_rand.float())
-                loss = huber_loss * args.loss_regression_weight + div_reg * args.loss_reg_weight
-                if kld is not None:
-                    loss = loss + kld * args.loss_kld_weight
+                speaker = args.z_type == "speaker"
+                # train_llm.py:46-79: huber, diversity regulariser, KLD and their weighted sum, fused (ops.hop_losses)
+                loss, vals = _ops.hop_losses(outputs, target_dir_vec, out_rand.float(), z_context.float(), z_rand.float(),
+                                             z_mu.float() if speaker else None, z_logvar.float() if speaker else None,
+                                             args.loss_regression_weight, args.loss_reg_weight, args.loss_kld_weight)
+                huber_loss, div_reg, kld = vals[0], vals[1], (vals[2] if speaker else None)
             else:
-                loss = huber_loss * args.loss_regression_weight
+                loss, vals = _ops.hop_losses(outputs, target_dir_vec, w_reg=args.loss_regression_weight)
+                huber_loss = vals[0]
             if epoch > 10:                                                     # literal gate, train_llm.py:81
                 loss = loss + gen_error * args.loss_gan_weight
         fetch = _LossFetch(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)

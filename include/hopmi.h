@@ -239,6 +239,23 @@ size_t hopmi_gru_bwd_ws_floats(int B, int H);
 int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
                   float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);
 
+/* ---- the generator losses of one training step: train_eval/train_llm.py:46-79
+ *   huber   = smooth_l1(out / 0.1, target / 0.1) * 0.1 (mean);  pose_b = sum_f smooth_l1(out[b] / .05, out_rand[b] / .05) * .05;
+ *   z_b = mean_j |z_context[b] - z_rand[b]|;  div_reg = mean_b max(-pose_b / (z_b + 1e-5), -1000);
+ *   kld = -0.5 mean(1 + logvar - mu^2 - exp(logvar));  total = w_reg huber + w_div div_reg + w_kld kld.
+ *   out, target, out_rand [B][F]; z_context, z_rand, mu, logvar [B][Z].  out_rand / z_context / z_rand are nullable
+ *   together (no div_reg term), mu / logvar together (no kld term).  vals [4] = huber, div_reg, kld, total.
+ *   ws: hopmi_hop_losses_ws_floats(B) floats, kept for the backward.  Backward: gradient of total times the device scalar
+ *   *g w.r.t. out (d_out [B][F]), mu and logvar (d_mu, d_logvar [B][Z], nullable with mu); target, out_rand, z_context and
+ *   z_rand take none (the reference detaches them).  Fixed-order reductions: bitwise reproducible. */
+size_t hopmi_hop_losses_ws_floats(int B);
+int hopmi_hop_losses_fwd(const float* out, const float* target, const float* out_rand, const float* z_context,
+                         const float* z_rand, const float* mu, const float* logvar, int B, int F, int Z, float w_reg,
+                         float w_div, float w_kld, float* vals, float* ws, void* stream);
+int hopmi_hop_losses_bwd(const float* out, const float* target, const float* out_rand, const float* mu, const float* logvar,
+                         const float* ws, const float* g, int B, int F, int Z, float w_reg, float w_kld, float* d_out,
+                         float* d_mu, float* d_logvar, void* stream);
+
 /* ---- fp32 GEMM against frozen weights on the bf16 matrix cores (the frozen BERT's linears, HOP.py:90-91,204 ->
  *      transformers BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput nn.Linear calls)
  *   C[M][N] = A[M][K] . Bt[N][K]^T (+ bias[N]);  A, C fp32 row-major.

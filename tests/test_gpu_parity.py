@@ -592,6 +592,62 @@ def test_train_llm_vs_reference_golden(golden, V, epoch, monkeypatch):
             assert checksum_close(checksum(sd[str(n)]), want, RTOL, atol), (n, checksum(sd[str(n)]), want)
 
 
+@pytest.mark.parametrize("B,F_,Z,speaker,div", [(2, 918, 32, True, True), (128, 918, 32, True, True), (64, 4284, 32, False, True),
+                                                (5, 77, 16, False, False), (130, 918, 32, True, True)])
+def test_hop_losses_vs_reference_formulas(B, F_, Z, speaker, div):
+    """ops.hop_losses (hopmi_hop_losses_fwd / _bwd) vs the loss recipe of train_llm.py:46-79 written with torch ops in float64
+    on the host (steps._regularisers is the same recipe): the four scalars and the gradients w.r.t. out, mu, logvar."""
+    from hopmi import ops
+    from oracle import fill
+    dev = _dev()
+    out = fill.uniform("loss.out", (B, 34, F_ // 34 if F_ % 34 == 0 else 1) if F_ % 34 == 0 else (B, F_)) * 0.4
+    tgt = fill.uniform("loss.tgt", tuple(out.shape)) * 0.4
+    rnd = out + fill.uniform("loss.rnd", tuple(out.shape)) * 0.12          # both branches of smooth_l1 at beta = 0.05
+    zc, zr = fill.uniform("loss.zc", (B, Z)), fill.uniform("loss.zr", (B, Z))
+    if B > 2:
+        zr[1] = zc[1] + 1e-7                                                # one clip on the clamp (-1000) side
+    mu, lv = fill.uniform("loss.mu", (B, Z)), fill.uniform("loss.lv", (B, Z))
+    w = (500.0, 0.05, 0.1)
+    # reference recipe, float64
+    o64, m64, l64 = out.double().requires_grad_(), mu.double().requires_grad_(), lv.double().requires_grad_()
+    huber = torch.nn.functional.smooth_l1_loss(o64 / 0.1, tgt.double() / 0.1) * 0.1
+    total = huber * w[0]
+    div_reg = kld = None
+    if div:
+        pose = torch.nn.functional.smooth_l1_loss(o64 / 0.05, rnd.double() / 0.05, reduction="none") * 0.05
+        pose = pose.reshape(B, -1).sum(1)
+        zl = (zc.double() - zr.double()).abs().reshape(B, -1).mean(1)
+        div_reg = torch.clamp(-(pose / (zl + 1.0e-5)), min=-1000).mean()
+        total = total + div_reg * w[1]
+        if speaker:
+            kld = -0.5 * torch.mean(1 + l64 - m64.pow(2) - l64.exp())
+            total = total + kld * w[2]
+    (total * 1.7).backward()
+    # HIP
+    og, mg, lg = out.to(dev).requires_grad_(), mu.to(dev).requires_grad_(), lv.to(dev).requires_grad_()
+    if div:
+        tot, vals = ops.hop_losses(og, tgt.to(dev), rnd.to(dev), zc.to(dev), zr.to(dev), mg if speaker else None,
+                                   lg if speaker else None, *w)
+    else:
+        tot, vals = ops.hop_losses(og, tgt.to(dev), w_reg=w[0])
+    (tot * 1.7).backward()
+    torch.cuda.synchronize()
+    v = vals.cpu().double()
+    assert abs(v[0] - huber.item()) <= 1e-5 * abs(huber.item())
+    assert abs(tot.item() - total.item()) <= 1e-5 * abs(total.item()) and abs(v[3] - total.item()) <= 1e-5 * abs(total.item())
+    assert_close(og.grad, o64.grad, rtol=1e-5, what="d out")
+    if div:
+        assert abs(v[1] - div_reg.item()) <= 1e-5 * abs(div_reg.item())
+        if speaker:
+            assert abs(v[2] - kld.item()) <= 1e-5 * abs(kld.item())
+            assert_close(mg.grad, m64.grad, rtol=1e-5, what="d mu")
+            assert_close(lg.grad, l64.grad, rtol=1e-5, what="d logvar")
+    # reproducible bit for bit
+    tot2, vals2 = ops.hop_losses(out.to(dev), tgt.to(dev), w_reg=w[0]) if not div else ops.hop_losses(
+        out.to(dev), tgt.to(dev), rnd.to(dev), zc.to(dev), zr.to(dev), mu.to(dev) if speaker else None, lv.to(dev) if speaker else None, *w)
+    assert torch.equal(vals2, vals)
+
+
 def test_train_llm_unused_score_elision(monkeypatch):
     """epoch <= 10: train_llm.py:43-44 scores the generated poses and :81 never uses the score.  steps.train_llm keeps only
     the lasting effect of that call (pre_conv's BatchNorm statistics): the returned losses and every parameter / buffer of
