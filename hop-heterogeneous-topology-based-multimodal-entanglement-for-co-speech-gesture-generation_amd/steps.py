@@ -161,6 +161,8 @@ class _LossFetch:
 # epoch <= 10: do not compute the discriminator score that train_llm.py:43-44 computes and never uses (same parameters, buffers
 # and returned losses; tests/test_gpu_parity.py::test_train_llm_unused_score_elision)
 ELIDE_UNUSED_SCORE = True
+# the loss recipe of train_llm.py:46-79 as one fused op (ops.hop_losses) instead of ~75 tensor operations
+FUSED_LOSSES = True
 
 
 def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,
@@ -200,14 +202,25 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
                 with torch.no_grad():                                          # only used detached (:60,65)
                     out_rand, z_rand, _, _ = model(in_audio, log_melspec, text_token_padded, pre_seq, rand_vids)
                 speaker = args.z_type == "speaker"
-                # train_llm.py:46-79: huber, diversity regulariser, KLD and their weighted sum, fused (ops.hop_losses)
-                loss, vals = _ops.hop_losses(outputs, target_dir_vec, out_rand.float(), z_context.float(), z_rand.float(),
-                                             z_mu.float() if speaker else None, z_logvar.float() if speaker else None,
-                                             args.loss_regression_weight, args.loss_reg_weight, args.loss_kld_weight)
-                huber_loss, div_reg, kld = vals[0], vals[1], (vals[2] if speaker else None)
-            else:
+                if FUSED_LOSSES:
+                    # train_llm.py:46-79: huber, diversity regulariser, KLD and their weighted sum, fused (ops.hop_losses)
+                    loss, vals = _ops.hop_losses(outputs, target_dir_vec, out_rand.float(), z_context.float(), z_rand.float(),
+                                                 z_mu.float() if speaker else None, z_logvar.float() if speaker else None,
+                                                 args.loss_regression_weight, args.loss_reg_weight, args.loss_kld_weight)
+                    huber_loss, div_reg, kld = vals[0], vals[1], (vals[2] if speaker else None)
+                else:
+                    huber_loss = F.smooth_l1_loss(outputs / 0.1, target_dir_vec / 0.1) * 0.1
+                    div_reg, kld = _regularisers(args, outputs, z_context.float(), z_mu.float(), z_logvar.float(),
+                                                 out_rand.float(), z_rand.float())
+                    loss = huber_loss * args.loss_regression_weight + div_reg * args.loss_reg_weight
+                    if kld is not None:
+                        loss = loss + kld * args.loss_kld_weight
+            elif FUSED_LOSSES:
                 loss, vals = _ops.hop_losses(outputs, target_dir_vec, w_reg=args.loss_regression_weight)
                 huber_loss = vals[0]
+            else:
+                huber_loss = F.smooth_l1_loss(outputs / 0.1, target_dir_vec / 0.1) * 0.1
+                loss = huber_loss * args.loss_regression_weight
             if epoch > 10:                                                     # literal gate, train_llm.py:81
                 loss = loss + gen_error * args.loss_gan_weight
         fetch = _LossFetch(args, gan, huber_loss, kld, div_reg, gen_error, dis_error)
