@@ -200,7 +200,8 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch):
            "--master-port", str(29600 + epoch), os.path.join(root, "tests", "graph_rank_worker.py"), str(epoch)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    rows = [json.loads(l.split("RANKJSON ", 1)[1]) for l in r.stdout.splitlines() if "RANKJSON " in l]
+    dec = json.JSONDecoder()          # (the two ranks' lines can arrive glued together)
+    rows = [dec.raw_decode(chunk)[0] for chunk in r.stdout.split("RANKJSON ")[1:]]
     assert len(rows) == 2, r.stdout[-2000:]
     for row in rows:
         assert row["sharded"] and row["own"] in ([0, 750], [750, 1500]), row
@@ -210,8 +211,9 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch):
             assert sorted(a) == sorted(b)
             for k in a:
                 assert abs(a[k] - b[k]) <= 2e-4 * max(abs(a[k]), 1e-6), (k, a[k], b[k])
-        # elements whose gradient is at rounding level may take a +-lr Adam step the other way (4 steps of 1e-3)
-        assert row["worst_max"] <= 8.5e-3 and row["worst_mean"] <= 5e-5, row
+        # (parameters with analytically zero gradients are frozen in the worker; single elements of the others whose gradient
+        # is at rounding level may still take a +-lr Adam step the other way)
+        assert row["worst_max"] <= 4.5e-3 and row["worst_mean"] <= 2e-5, {k: row[k] for k in ("worst_max", "worst_mean", "worst_mean_name", "worst_name", "top_mean")}
         assert row["replica_spread"] <= 1e-6, row
 
 
