@@ -132,7 +132,10 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
     asm volatile("" : "+v"(tid));
     const int ln = tid & 63, qq = ln >> 4, nn = ln & 15;
     const bool more = kt + 1 < nk;
-    if (more) issue((kt + 1) * GK);
+    // DB: the loop body is branch-free (the last step re-stages its own tile into the idle buffer), so that the splits and
+    // LDS stores of the next tile can be scheduled between this tile's MFMAs instead of behind them
+    if (DB) issue(min(kt + 1, nk - 1) * GK);
+    else if (more) issue((kt + 1) * GK);
     const __bf16* la = lds + (DB ? (kt & 1) : 0) * BUF + ((BM / 2) * wr + nn) * GLD + 8 * qq;
     const __bf16* lb = lds + (DB ? (kt & 1) : 0) * BUF + OPER + (32 * wc + nn) * GLD + 8 * qq;
     u32x4 af[MI][NP];
@@ -156,8 +159,29 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
         acc[mi][ni] = c;
       }
     }
-    if (!DB) __syncthreads();                      // one buffer: every wave has read this step's fragments
-    if (more) commit(DB ? ((kt + 1) & 1) : 0);
+    if (DB) {
+      commit((kt + 1) & 1);
+#ifndef HOPMI_GEMM_NO_SCHED
+      // order for the scheduler: next tile's global loads first, this tile's fragment reads, a run of MFMAs (the loads
+      // land meanwhile), then the splits (2 VALU per MFMA) and the LDS stores (1 per 2 MFMAs) between the remaining MFMAs
+      constexpr int NMFMA = MI * 2 * (NP * (NP + 1) / 2), NVALU_SLOTS = 16, NLEAD = NMFMA - NVALU_SLOTS - 4 * NP;
+      __builtin_amdgcn_sched_group_barrier(0x020, AF4 + NP, 0);
+      if (NLEAD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NLEAD, 0);
+#pragma unroll
+      for (int g = 0; g < NVALU_SLOTS; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 2 * NP; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+#endif
+    } else {
+      __syncthreads();                               // one buffer: every wave has read this step's fragments
+      if (more) commit(0);
+    }
     __syncthreads();
   }
 
