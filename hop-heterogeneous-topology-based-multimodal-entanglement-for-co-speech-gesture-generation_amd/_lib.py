@@ -51,6 +51,7 @@ SIGNATURES = {
     "hopmi_gemm_split_image_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_gemm_split_prepare": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hopmi_gemm_split": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "hopmi_gemm_split_ab": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gru_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_gru_fwd": (_I, [_VP] * 6 + [_I, _I, _I, _VP]),
     "hopmi_gru_bwd_ws_floats": (ctypes.c_size_t, [_I, _I]),

@@ -22,6 +22,21 @@
 
 namespace hopmi {
 
+#ifdef HOPMI_STAMPS
+static __device__ long long* g_gemm_stamps = nullptr;
+// stamps of wave 0 of every workgroup at k-step nk / 2: [block][8]
+#define GEMM_STAMP(slot)                                                                           \
+  do {                                                                                             \
+    if (kt == nk / 2 && wv == 0) {                                                                 \
+      unsigned long long t_;                                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+      if (g_gemm_stamps && (threadIdx.x & 63) == 0) g_gemm_stamps[blockIdx.x * 8 + (slot)] = (long long)t_; \
+    }                                                                                              \
+  } while (0)
+#else
+#define GEMM_STAMP(slot) do { } while (0)
+#endif
+
 constexpr int GN = 128, GK = 32;                   // (the tile's M extent BM is a template parameter: 128 or 64)
 constexpr int GLD = 48;                            // LDS row stride in bf16 units (96 bytes)
 
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
     // (the lane index is hidden from the optimiser per iteration: keeps loop-invariant LDS addresses from being hoisted into
     // dozens of registers held across the whole loop)
     asm volatile("" : "+v"(tid));
+    GEMM_STAMP(0);
     const int ln = tid & 63, qq = ln >> 4, nn = ln & 15;
     const bool more = kt + 1 < nk;
     // DB: the loop body is branch-free (the last step re-stages its own tile into the idle buffer), so that the splits and
@@ -159,6 +175,7 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
         acc[mi][ni] = c;
       }
     }
+    GEMM_STAMP(1);
     if (DB) {
       commit((kt + 1) & 1);
 #ifndef HOPMI_GEMM_NO_SCHED
@@ -180,9 +197,12 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
 #endif
     } else {
       __syncthreads();                               // one buffer: every wave has read this step's fragments
+      GEMM_STAMP(2);
       if (more) commit(0);
     }
+    GEMM_STAMP(3);
     __syncthreads();
+    GEMM_STAMP(4);
   }
 
   // epilogue: lane (q, n) holds rows 4q + r, column n of every 16 x 16 tile
@@ -217,10 +237,135 @@ static void launch_gemm_variant(const float* A, const void* Bimg, const float* b
                      K, tiles_m, tiles_n);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Both operands as prepared part images (A: hopmi_gemm_split_prepare on the activations, or a producer kernel that writes
+// the image itself): nothing is split in the kernel and nothing passes through registers on its way to LDS -- every tile is
+// staged by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, 16 rows x 64 B of one part image).  The split
+// kernel above spends 36 % of a k-step committing the next tile (tools/probes/gemm_stamps.py: 1 900 cycles MFMA phase,
+// 1 280 commit, 320 barrier); here the commit is six DMA instructions per wave.  LDS rows are 64 B, unpadded (the DMA
+// writes lane-linearly), with the 16-byte slots XOR-swizzled through the SOURCE address and the fragment reads
+// (slot ^ f((row >> 2) & 3), f = 0, 3, 2, 1: conflict-free ds_read_b128).  NBUF tile buffers: the DMA of tile kt + NBUF - 1
+// is issued while tile kt is multiplied; a counted s_waitcnt leaves the youngest tiles in flight across the raw barrier.
+__device__ __forceinline__ int gswz(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }
+
+template <int NP, int NBUF>
+__global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Bimg,
+                                                             const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                             int K, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int IMG = 128 * 64;                    // bytes of one part image of one operand tile
+  constexpr int BUFB = 2 * NP * IMG;               // [A parts | B parts]
+  int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wv >> 2, wc = wv & 3;
+  const int lane = tid & 63, q = lane >> 4, n = lane & 15;
+  const int ntiles = tiles_m * tiles_n;
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+  const int per = ntiles >> 3, rem = ntiles & 7;
+  const int tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+  if (idx >= per + (xcd < rem ? 1 : 0)) return;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * 128, n0 = tn * GN;
+
+  // staging: wave wv moves rows 16 wv .. +15 of every (operand, part) image; lane -> (row, LDS slot); source slot swizzled
+  const int srow = 16 * wv + (lane >> 2), sslot = (lane & 3) ^ gswz(lane >> 2);
+  const __bf16* a_src = Aimg + (size_t)min(m0 + srow, M - 1) * K + 8 * sslot;
+  const __bf16* b_src = Bimg + (size_t)(n0 + srow) * K + 8 * sslot;
+  const size_t a_part = (size_t)M * K, b_part = (size_t)N * K;
+  auto stage = [&](int kt) {
+    unsigned char* dst = smem_raw + (kt % NBUF) * BUFB + wv * 1024;
+    const int k0 = kt * GK;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + p * a_part + k0),
+                                       (__attribute__((address_space(3))) void*)(dst + p * IMG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + p * b_part + k0),
+                                       (__attribute__((address_space(3))) void*)(dst + (NP + p) * IMG), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / GK;
+#pragma unroll
+  for (int pre = 0; pre < NBUF - 1; ++pre)
+    if (pre < nk) stage(pre);
+  if (nk > NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * (NBUF - 2)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int fa_off = (64 * wr + n) * 64 + ((q ^ gswz(n)) << 4);          // (the swizzle only depends on n: row = 16 k + n)
+  const int fb_off = NP * IMG + (32 * wc + n) * 64 + ((q ^ gswz(n)) << 4);
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool ahead = kt + NBUF - 1 < nk;
+    if (ahead) stage(kt + NBUF - 1);
+    const unsigned char* buf = smem_raw + (kt % NBUF) * BUFB;
+    u32x4 af[4][NP];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) af[mi][p] = *reinterpret_cast<const u32x4*>(buf + fa_off + p * IMG + mi * 16 * 64);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      u32x4 bf[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const u32x4*>(buf + fb_off + p * IMG + ni * 16 * 64);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        f32x4 c = acc[mi][ni];
+#pragma unroll
+        for (int s = NP - 1; s >= 0; --s)
+#pragma unroll
+          for (int i = 0; i <= s; ++i) c = mfma_bf16(af[mi][i], bf[s - i], c);
+        acc[mi][ni] = c;
+      }
+    }
+    // tile kt + 1 must have landed (the NBUF - 2 youngest tiles may stay in flight); every wave is done reading tile kt
+    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * (NBUF - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + 32 * wc + 16 * ni + n;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 64 * wr + 16 * mi + 4 * q + r;
+        if (row < M) C[(size_t)row * N + col] = acc[mi][ni][r] + bv;
+      }
+  }
+}
+
+template <int NP, int NBUF>
+static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
+  const int tiles_m = (M + 127) / 128, tiles_n = N / GN;
+  const size_t lds = (size_t)NBUF * 2 * NP * 128 * 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<NP, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+  const int ntiles = tiles_m * tiles_n;
+  const int grid = ((ntiles + 7) / 8) * 8;
+  hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
+                     static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n);
+}
+
 // Tile choice, measured at the frozen BERT's shapes (tools/bench_gemm.py, HOPMI_GEMM_TILE forces a form): 128-row tiles,
 // double-buffered with one workgroup per CU when the tiles cover the chip about once (N = 768: 204 tiles), single-buffered
 // with two workgroups per CU for the larger grids (N = 2304 / 3072: 612 / 816 tiles).  64-row tiles (form 3) fill idle CUs
 // and quantise better on paper but lost 5-15 % everywhere (more weight traffic and barriers per MFMA): kept for experiments.
+// Also measured and dropped: 4 waves of 64 x 64 with two workgroups per CU (-8...-30 %), a second fragment register set read
+// one step ahead (-12...-30 %).
 template <int NP>
 static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
   const int t128 = ((M + 127) / 128) * (N / GN);
@@ -235,6 +380,12 @@ static int launch_gemm_split(const float* A, const void* Bimg, const float* bias
 }  // namespace hopmi
 
 using namespace hopmi;
+
+#ifdef HOPMI_STAMPS
+extern "C" int hopmi_debug_set_stamps_gemm(long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t hopmi_gemm_split_image_bytes(int N, int K, int parts) {
   return (N > 0 && K > 0 && (parts == 2 || parts == 3)) ? (size_t)parts * N * K * sizeof(__bf16) : 0;
@@ -251,6 +402,20 @@ extern "C" int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts,
   if (parts == 2) hipLaunchKernelGGL(gemm_split_prepare_kernel<2>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
   else hipLaunchKernelGGL(gemm_split_prepare_kernel<3>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
   return check_launch("hopmi_gemm_split_prepare");
+}
+
+extern "C" int hopmi_gemm_split_ab(const void* Aimage, const void* Bimage, const float* bias, float* C, int M, int N, int K, int parts,
+                                   void* stream) {
+  if (!Aimage || !Bimage || !C) { set_error("hopmi_gemm_split_ab: null pointer argument"); return HOPMI_EINVAL; }
+  if (M <= 0 || N <= 0 || K <= 0 || N % GN || K % GK || (parts != 2 && parts != 3)) {
+    set_error("hopmi_gemm_split_ab: need N %% 128 == 0, K %% 32 == 0, parts in {2, 3} (M=%d N=%d K=%d parts=%d)", M, N, K, parts);
+    return HOPMI_EINVAL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nbuf = env_int("HOPMI_GEMM_NBUF", 3);
+  if (parts == 2) { if (nbuf == 2) launch_gemm_ab<2, 2>(Aimage, Bimage, bias, C, M, N, K, st); else launch_gemm_ab<2, 3>(Aimage, Bimage, bias, C, M, N, K, st); }
+  else { if (nbuf == 2) launch_gemm_ab<3, 2>(Aimage, Bimage, bias, C, M, N, K, st); else launch_gemm_ab<3, 3>(Aimage, Bimage, bias, C, M, N, K, st); }
+  return check_launch("hopmi_gemm_split_ab");
 }
 
 extern "C" int hopmi_gemm_split(const float* A, const void* Bimage, const float* bias, float* C, int M, int N, int K, int parts,

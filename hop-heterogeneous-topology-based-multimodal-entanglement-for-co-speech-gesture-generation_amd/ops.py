@@ -244,6 +244,25 @@ def _split_gemm(a2d, img, bias, N, K, parts):
     return out
 
 
+def split_rows_image(a2d, parts):
+    """The part images [parts][M][K] (bf16) of a row-major fp32 matrix (hopmi_gemm_split_prepare): the A operand of
+    hopmi_gemm_split_ab."""
+    M, K = a2d.shape
+    L = _lib.lib()
+    img = torch.empty(L.hopmi_gemm_split_image_bytes(M, K, parts), dtype=torch.uint8, device=a2d.device)
+    _lib.check(L.hopmi_gemm_split_prepare(a2d.data_ptr(), M, K, parts, img.data_ptr(), _stream()), "hopmi_gemm_split_prepare")
+    return img
+
+
+def _split_gemm_ab(a_img, M, img, bias, N, K, parts):
+    out = torch.empty(M, N, dtype=torch.float32, device=img.device)
+    L = _lib.lib()
+    _lib.check(_timed("gemm_split", 2 * parts * (M + N) * K + 4 * M * N, 2 * M * N * K,
+                      lambda: L.hopmi_gemm_split_ab(a_img.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, parts, _stream())),
+               "hopmi_gemm_split_ab")
+    return out
+
+
 class _SplitLinearFn(torch.autograd.Function):
     """y = x W^T (+ b) against a FROZEN weight: forward and activation gradient on hopmi_gemm_split; no weight gradient."""
 

@@ -270,6 +270,12 @@ int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts, void* imag
 int hopmi_gemm_split(const float* A, const void* Bimage, const float* bias, float* C, int M, int N, int K, int parts,
                      void* stream);
 
+/* The same product with BOTH operands as part images (Aimage = hopmi_gemm_split_prepare(A, M, K, parts, ...), i.e.
+ * [parts][M][K] bf16; a producer may also write that layout itself): nothing is split inside the kernel, every tile is staged
+ * by LDS-DMA.  Same arithmetic (the same MFMA terms in the same order) as hopmi_gemm_split: results are bit-identical. */
+int hopmi_gemm_split_ab(const void* Aimage, const void* Bimage, const float* bias, float* C, int M, int N, int K, int parts,
+                        void* stream);
+
 /* ---- log-mel spectrogram of the audio clips: data_loader/lmdb_data_loader.py:216-218
  *      melspec = librosa.feature.melspectrogram(y, sr=16000, n_fft=1024, hop_length=hop, power=2)   (librosa 0.8.1:
  *      periodic Hann window, center=True with reflect padding, Slaney mel filters);  out = power_to_db(melspec, ref=np.max).T

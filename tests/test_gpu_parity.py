@@ -1128,6 +1128,9 @@ def test_gemm_split_vs_float64(M, N, K, parts, tol):
     assert rel_err(x.grad.double(), wdx) <= tol
     if parts == 3:
         assert err <= 3 * err_lib + 1e-7, (err, err_lib)          # fp32-equivalent: on a par with the library's fp32 GEMM
+    # both operands as part images, tiles staged by LDS-DMA (hopmi_gemm_split_ab): the same terms in the same order
+    y_ab = ops._split_gemm_ab(ops.split_rows_image(x.detach(), parts), M, ops.split_weight_image(w, parts), b, N, K, parts)
+    assert torch.equal(y_ab, y.detach())
 
 
 def test_bert_fast_path_split_gemm_vs_reference_golden(golden):

@@ -32,4 +32,10 @@ for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 2304)):
         t = timed(lambda: ops._split_gemm(x, img, b, N, K, parts))
         err = ((ops._split_gemm(x, img, b, N, K, parts).double() - ref).abs().max() / ref.abs().max()).item()
         line += f" | parts={parts}: {t:7.1f} us ({2*M*N*K/t/1e6:6.1f} TF-equiv) err {err:.1e}"
+        if "--ab" in sys.argv:
+            t_pre = timed(lambda: ops.split_rows_image(x, parts))
+            a_img = ops.split_rows_image(x, parts)
+            t_ab = timed(lambda: ops._split_gemm_ab(a_img, M, img, b, N, K, parts))
+            err = ((ops._split_gemm_ab(a_img, M, img, b, N, K, parts).double() - ref).abs().max() / ref.abs().max()).item()
+            line += f" [ab: split {t_pre:5.1f} + gemm {t_ab:6.1f} us, err {err:.1e}]"
     print(line, flush=True)
