@@ -275,8 +275,22 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
   if (GCN) {
     // the mix image -> LDS (plain copy loop: a register array staged across the loads ended up in scratch).  Its loads are
     // the youngest in flight, so the wait also covers the tile's activation loads -- which the commit below needs anyway.
+    // Eight loads in flight per thread and round trip: one load per iteration made the V = 42 image (20 KB+) 23 us of a
+    // 39 us launch (tools/probes/wn_stamps.py).
     const int at_n4 = (g.KP * g.ldA) >> 2;
-    for (int idx = tid; idx < at_n4; idx += WN_THREADS) reinterpret_cast<float4*>(AT)[idx] = reinterpret_cast<const float4*>(prep)[idx];
+    for (int idx0 = tid; idx0 < at_n4; idx0 += 8 * WN_THREADS) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + u * WN_THREADS;
+        v[u] = reinterpret_cast<const float4*>(prep)[min(idx, at_n4 - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + u * WN_THREADS;
+        if (idx < at_n4) reinterpret_cast<float4*>(AT)[idx] = v[u];
+      }
+    }
   }
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
