@@ -20,6 +20,10 @@ import torch.nn.functional as F
 from . import ops
 
 
+# under bf16 autocast: the bf16-storage operators between the GEMMs (False: the fp32-storage operators + autocast's casts)
+BF16_STORAGE = True
+
+
 def supports(llm) -> bool:
     try:
         cfg = llm.config
@@ -42,6 +46,7 @@ class FrozenBertEncoder:
         self.llm = llm
         self._qkv = {}
         self._img = {}
+        self._w16 = {}
 
     def _fused_qkv(self, i, att):
         ver = (att.query.weight._version, att.key.weight._version, att.value.weight._version, att.query.weight.data_ptr())
@@ -69,6 +74,48 @@ class FrozenBertEncoder:
             self._img[key] = hit
         return ops.split_linear(x, hit[1], hit[2], bias, N, K, parts)
 
+    def _bf16(self, key, weight, bias=None):
+        """bf16 copies of a frozen weight (and bias), made once per weight version: under autocast the library would
+        otherwise re-cast every weight in every step."""
+        ver = (weight._version, weight.data_ptr(), None if bias is None else bias._version)
+        hit = self._w16.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, weight.detach().to(torch.bfloat16).contiguous(), None if bias is None else bias.detach().to(torch.bfloat16).contiguous())
+            self._w16[key] = hit
+        return hit[1], hit[2]
+
+    def _call_bf16(self, inputs_embeds):
+        """The bf16-autocast form: bf16 library GEMMs against cached bf16 weights, and the bf16-storage forms of the HIP
+        operators in between (ops.*_bf16: fp32 arithmetic, bf16 in / out), the residual stream in fp32 -- the values of the
+        fp32-storage operators under autocast, without the cast kernels around every operator."""
+        llm, cfg = self.llm, self.llm.config
+        B, L, D = inputs_embeds.shape
+        H = cfg.num_attention_heads
+        train = llm.training
+        p_h = cfg.hidden_dropout_prob if train else 0.0
+        p_a = cfg.attention_probs_dropout_prob if train else 0.0
+        emb = llm.embeddings
+        h = F.layer_norm(inputs_embeds.float() + (emb.token_type_embeddings.weight[0] + emb.position_embeddings.weight[:L]),
+                         (D,), emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps).float()
+        if p_h > 0:
+            h = F.dropout(h, p_h, True)
+        h16 = h.to(torch.bfloat16)
+        for i, lay in enumerate(llm.encoder.layer):
+            att = lay.attention
+            wqkv, bqkv = self._fused_qkv(i, att.self)
+            w16, b16 = self._bf16((i, "qkv"), wqkv, bqkv)
+            qkv = F.linear(h16, w16, b16).view(B, L, 3, H, D // H)
+            a16 = ops.bert_attention_bf16(qkv, p_a, self._seed())
+            o16 = F.linear(a16, self._bf16((i, "ao"), att.output.dense.weight)[0])
+            h, h16 = ops.bias_dropout_residual_layernorm_bf16(o16, att.output.dense.bias, h, att.output.LayerNorm.weight,
+                                                              att.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
+            f16 = ops.bias_gelu_bf16(F.linear(h16, self._bf16((i, "f1"), lay.intermediate.dense.weight)[0]), lay.intermediate.dense.bias)
+            o16 = F.linear(f16, self._bf16((i, "f2"), lay.output.dense.weight)[0])
+            h, h16 = ops.bias_dropout_residual_layernorm_bf16(o16, lay.output.dense.bias, h, lay.output.LayerNorm.weight,
+                                                              lay.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
+        return h
+
     def _seed(self):
         FrozenBertEncoder._calls += 1
         return (ops.base_seed() * 2246822519 + FrozenBertEncoder._calls * 3266489917) & 0xFFFFFFFF
@@ -77,6 +124,9 @@ class FrozenBertEncoder:
         llm, cfg = self.llm, self.llm.config
         B, L, D = inputs_embeds.shape
         H = cfg.num_attention_heads
+        if (BF16_STORAGE and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and D // H == 64 and L <= 64):
+            return self._call_bf16(inputs_embeds)
         train = llm.training
         p_h = cfg.hidden_dropout_prob if train else 0.0
         p_a = cfg.attention_probs_dropout_prob if train else 0.0

@@ -13,6 +13,7 @@
 // (16x16x4, outputs transposed so that every global store is 16 bytes per lane); dropout is the stateless
 // (seed,row,head,key) hash of attn.hip.
 #include "attn_dev.h"
+#include "io_dev.h"
 
 namespace hopmi {
 
@@ -21,11 +22,11 @@ constexpr int BLD = BD + 4;        // LDS row stride of the Q / K / V / dO image
 constexpr int BMAXL = 64;
 
 // rows [0, LP) x 64 floats of one of q/k/v (or d_o) of (b, h) -> LDS image [LP][BLD], rows >= L zeroed
-template <int NT>
-__device__ __forceinline__ void stage_head(float* dst, const float* __restrict__ src, size_t row_stride, int L, int LP, int tid) {
+template <int NT, typename T>
+__device__ __forceinline__ void stage_head(float* dst, const T* __restrict__ src, size_t row_stride, int L, int LP, int tid) {
   for (int idx = tid; idx < LP * 16; idx += NT) {
     const int row = idx >> 4, c4 = idx & 15;
-    const float4 v = reinterpret_cast<const float4*>(src + (size_t)min(row, L - 1) * row_stride)[c4];
+    const float4 v = ld4(src + (size_t)min(row, L - 1) * row_stride + 4 * c4);
     *reinterpret_cast<float4*>(dst + row * BLD + 4 * c4) = (row < L) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
@@ -61,8 +62,8 @@ __device__ __forceinline__ void xt_product(f32x4 (&o)[4], const float* X, const 
 // Forward.  Workgroup = (b, h), MT = ceil(L / 16) waves; wave w owns query rows [16w, 16w + 16) end to end:
 // its score strip stays in accumulator registers, the softmax reduces over the 16 lanes of a DPP row, the
 // dropped-out probabilities pass through a wave-private LDS tile to become an MFMA operand.  One barrier.
-template <int MT>
-__global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int H,
+template <int MT, typename T>
+__global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H,
                                                                 unsigned thresh, float dscale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   constexpr int LP = 16 * MT, PLD = LP + 4, NT = 64 * MT;
@@ -73,14 +74,14 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const float* __r
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
   const size_t rs = (size_t)3 * H * BD;
-  const float* base = qkv + (size_t)b * L * rs + (size_t)h * BD;
+  const T* base = qkv + (size_t)b * L * rs + (size_t)h * BD;
   stage_head<NT>(Ks, base + (size_t)H * BD, rs, L, LP, tid);
   stage_head<NT>(Vs, base + (size_t)2 * H * BD, rs, L, LP, tid);
   float4 qf[4];
   {
-    const float4* qp = reinterpret_cast<const float4*>(base + (size_t)min(16 * w + j, L - 1) * rs + 4 * q);
+    const T* qp = base + (size_t)min(16 * w + j, L - 1) * rs + 4 * q;
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) qf[ii] = qp[4 * ii];
+    for (int ii = 0; ii < 4; ++ii) qf[ii] = ld4(qp + 16 * ii);
   }
   __syncthreads();
   f32x4 s[MT];
@@ -121,9 +122,9 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const float* __r
   xt_product<MT>(o, Vs, Pw, PLD, q, j);
   const int row = 16 * w + j;
   if (row < L) {
-    float* op = out + ((size_t)(b * L + row) * H + h) * BD + 4 * q;
+    T* op = out + ((size_t)(b * L + row) * H + h) * BD + 4 * q;
 #pragma unroll
-    for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
+    for (int di = 0; di < 4; ++di) st4(op + 16 * di, make_float4(o[di][0], o[di][1], o[di][2], o[di][3]));
   }
 }
 
@@ -133,9 +134,9 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const float* __r
 //   pass 2, wave = 16 keys: recomputes its columns of P and dPd (as transposed strips, from the statistics),
 //           dV = Pd^T dO, dK = dS^T Q / 8.
 // Every output element has one owner wave and a fixed summation order: no atomics, bitwise reproducible.
-template <int MT>
-__global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                                float* __restrict__ dqkv, int L, int H, unsigned thresh,
+template <int MT, typename T>
+__global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                T* __restrict__ dqkv, int L, int H, unsigned thresh,
                                                                 float dscale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   constexpr int LP = 16 * MT, PLD = LP + 4, NT = 64 * MT;
@@ -151,13 +152,13 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const float* __r
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
   const size_t rs = (size_t)3 * H * BD;
-  const float* base = qkv + (size_t)b * L * rs + (size_t)h * BD;
+  const T* base = qkv + (size_t)b * L * rs + (size_t)h * BD;
   stage_head<NT>(Qs, base, rs, L, LP, tid);
   stage_head<NT>(Ks, base + (size_t)H * BD, rs, L, LP, tid);
   stage_head<NT>(Vs, base + (size_t)2 * H * BD, rs, L, LP, tid);
   stage_head<NT>(Gs, dout + (size_t)b * L * H * BD + (size_t)h * BD, (size_t)H * BD, L, LP, tid);
   __syncthreads();
-  float* dst = dqkv + (size_t)b * L * rs + (size_t)h * BD;
+  T* dst = dqkv + (size_t)b * L * rs + (size_t)h * BD;
 
   // ---------------- pass 1: rows 16w .. 16w + 15 ----------------------------------------------------------
   {
@@ -211,9 +212,9 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const float* __r
     xt_product<MT>(o, Ks, Tw, PLD, q, j);                            // dQ^T = K^T dS^T
     const int row = 16 * w + j;
     if (row < L) {
-      float* op = dst + (size_t)row * rs + 4 * q;
+      T* op = dst + (size_t)row * rs + 4 * q;
 #pragma unroll
-      for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
+      for (int di = 0; di < 4; ++di) st4(op + 16 * di, make_float4(o[di][0], o[di][1], o[di][2], o[di][3]));
     }
   }
   __syncthreads();                                                   // statistics of every row visible
@@ -256,9 +257,9 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const float* __r
     f32x4 o[4];
     xt_product<MT>(o, Gs, Tw, PLD, q, j);                            // dV^T = dO^T Pd
     if (key < L) {
-      float* op = dst + (size_t)key * rs + 2 * H * BD + 4 * q;
+      T* op = dst + (size_t)key * rs + 2 * H * BD + 4 * q;
 #pragma unroll
-      for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
+      for (int di = 0; di < 4; ++di) st4(op + 16 * di, make_float4(o[di][0], o[di][1], o[di][2], o[di][3]));
     }
 #pragma unroll
     for (int nt = 0; nt < MT; ++nt)
@@ -266,9 +267,9 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_bwd_kernel(const float* __r
       for (int r = 0; r < 4; ++r) Tw[(4 * q + r) * PLD + 16 * nt + j] = ds[nt][r];
     xt_product<MT>(o, Qs, Tw, PLD, q, j);                            // dK^T = Q^T dS / 8
     if (key < L) {
-      float* op = dst + (size_t)key * rs + H * BD + 4 * q;
+      T* op = dst + (size_t)key * rs + H * BD + 4 * q;
 #pragma unroll
-      for (int di = 0; di < 4; ++di) *reinterpret_cast<float4*>(op + 16 * di) = make_float4(o[di][0], o[di][1], o[di][2], o[di][3]);
+      for (int di = 0; di < 4; ++di) st4(op + 16 * di, make_float4(o[di][0], o[di][1], o[di][2], o[di][3]));
     }
   }
 }
@@ -289,37 +290,73 @@ static int bert_attn_validate(const char* what, int B, int L, int H, float p_dro
 
 using namespace hopmi;
 
-extern "C" int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
-  if (int e = bert_attn_validate("hopmi_bert_attn_fwd", B, L, H, p_drop)) return e;
-  if (!qkv || !out) { set_error("hopmi_bert_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
+template <typename T>
+static void launch_bert_attn_fwd(const void* qkv, void* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                 hipStream_t st) {
   const int MT = (L + 15) / 16, LP = 16 * MT;
   const size_t lds = ((size_t)2 * LP * BLD + (size_t)LP * (LP + 4)) * sizeof(float);
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const float dscale = 1.f / (1.f - p_drop);
-  hipStream_t st = static_cast<hipStream_t>(stream);
+  const T* x = static_cast<const T*>(qkv);
+  T* o = static_cast<T*>(out);
   switch (MT) {
-    case 1: hipLaunchKernelGGL(bert_attn_fwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
-    case 2: hipLaunchKernelGGL(bert_attn_fwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
-    case 3: hipLaunchKernelGGL(bert_attn_fwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
-    default: hipLaunchKernelGGL(bert_attn_fwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, out, L, H, thresh, dscale, seed, seed_dev); break;
+    case 1: hipLaunchKernelGGL((bert_attn_fwd_kernel<1, T>), dim3(B * H), dim3(64), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
+    case 2: hipLaunchKernelGGL((bert_attn_fwd_kernel<2, T>), dim3(B * H), dim3(128), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
+    case 3: hipLaunchKernelGGL((bert_attn_fwd_kernel<3, T>), dim3(B * H), dim3(192), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
+    default: hipLaunchKernelGGL((bert_attn_fwd_kernel<4, T>), dim3(B * H), dim3(256), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
   }
-  return check_launch("hopmi_bert_attn_fwd");
 }
 
-extern "C" int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* dqkv, int B, int L, int H, float p_drop,
-                                   unsigned seed, const unsigned* seed_dev, void* stream) {
-  if (int e = bert_attn_validate("hopmi_bert_attn_bwd", B, L, H, p_drop)) return e;
-  if (!qkv || !d_out || !dqkv) { set_error("hopmi_bert_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
+template <typename T>
+static void launch_bert_attn_bwd(const void* qkv, const void* d_out, void* dqkv, int B, int L, int H, float p_drop, unsigned seed,
+                                 const unsigned* seed_dev, hipStream_t st) {
   const int MT = (L + 15) / 16, LP = 16 * MT;
   const size_t lds = ((size_t)4 * LP * BLD + 3 * (size_t)LP + (size_t)LP * (LP + 4)) * sizeof(float);
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const float dscale = 1.f / (1.f - p_drop);
-  hipStream_t st = static_cast<hipStream_t>(stream);
+  const T* x = static_cast<const T*>(qkv);
+  const T* g = static_cast<const T*>(d_out);
+  T* d = static_cast<T*>(dqkv);
   switch (MT) {
-    case 1: hipLaunchKernelGGL(bert_attn_bwd_kernel<1>, dim3(B * H), dim3(64), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
-    case 2: hipLaunchKernelGGL(bert_attn_bwd_kernel<2>, dim3(B * H), dim3(128), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
-    case 3: hipLaunchKernelGGL(bert_attn_bwd_kernel<3>, dim3(B * H), dim3(192), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
-    default: hipLaunchKernelGGL(bert_attn_bwd_kernel<4>, dim3(B * H), dim3(256), lds, st, qkv, d_out, dqkv, L, H, thresh, dscale, seed, seed_dev); break;
+    case 1: hipLaunchKernelGGL((bert_attn_bwd_kernel<1, T>), dim3(B * H), dim3(64), lds, st, x, g, d, L, H, thresh, dscale, seed, seed_dev); break;
+    case 2: hipLaunchKernelGGL((bert_attn_bwd_kernel<2, T>), dim3(B * H), dim3(128), lds, st, x, g, d, L, H, thresh, dscale, seed, seed_dev); break;
+    case 3: hipLaunchKernelGGL((bert_attn_bwd_kernel<3, T>), dim3(B * H), dim3(192), lds, st, x, g, d, L, H, thresh, dscale, seed, seed_dev); break;
+    default: hipLaunchKernelGGL((bert_attn_bwd_kernel<4, T>), dim3(B * H), dim3(256), lds, st, x, g, d, L, H, thresh, dscale, seed, seed_dev); break;
   }
+}
+
+static int bert_dtype_ok(const char* what, int dtype) {
+  if (dtype != HOPMI_F32 && dtype != HOPMI_BF16) { set_error("%s: dtype %d (0 = fp32, 1 = bf16)", what, dtype); return HOPMI_EINVAL; }
+  return HOPMI_OK;
+}
+
+extern "C" int hopmi_bert_attn_fwd_dt(const void* qkv, void* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                      int dtype, void* stream) {
+  if (int e = bert_attn_validate("hopmi_bert_attn_fwd", B, L, H, p_drop)) return e;
+  if (int e = bert_dtype_ok("hopmi_bert_attn_fwd_dt", dtype)) return e;
+  if (!qkv || !out) { set_error("hopmi_bert_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HOPMI_BF16) launch_bert_attn_fwd<__bf16>(qkv, out, B, L, H, p_drop, seed, seed_dev, st);
+  else launch_bert_attn_fwd<float>(qkv, out, B, L, H, p_drop, seed, seed_dev, st);
+  return check_launch("hopmi_bert_attn_fwd");
+}
+
+extern "C" int hopmi_bert_attn_bwd_dt(const void* qkv, const void* d_out, void* dqkv, int B, int L, int H, float p_drop, unsigned seed,
+                                      const unsigned* seed_dev, int dtype, void* stream) {
+  if (int e = bert_attn_validate("hopmi_bert_attn_bwd", B, L, H, p_drop)) return e;
+  if (int e = bert_dtype_ok("hopmi_bert_attn_bwd_dt", dtype)) return e;
+  if (!qkv || !d_out || !dqkv) { set_error("hopmi_bert_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HOPMI_BF16) launch_bert_attn_bwd<__bf16>(qkv, d_out, dqkv, B, L, H, p_drop, seed, seed_dev, st);
+  else launch_bert_attn_bwd<float>(qkv, d_out, dqkv, B, L, H, p_drop, seed, seed_dev, st);
   return check_launch("hopmi_bert_attn_bwd");
+}
+
+extern "C" int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+  return hopmi_bert_attn_fwd_dt(qkv, out, B, L, H, p_drop, seed, seed_dev, HOPMI_F32, stream);
+}
+
+extern "C" int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* dqkv, int B, int L, int H, float p_drop,
+                                   unsigned seed, const unsigned* seed_dev, void* stream) {
+  return hopmi_bert_attn_bwd_dt(qkv, d_out, dqkv, B, L, H, p_drop, seed, seed_dev, HOPMI_F32, stream);
 }

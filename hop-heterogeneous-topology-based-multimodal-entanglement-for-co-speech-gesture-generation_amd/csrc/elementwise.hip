@@ -9,7 +9,7 @@
 // LayerNorm rows (D <= 1024, D % 4 == 0; 768 for BERT-base) are one wave each: the row lives in registers,
 // mean/variance by DPP + cross-row shuffles, so x is read once and out written once.  Dropout uses the same
 // stateless hash as the attention kernel (seed, row, column) so the backward regenerates the mask.
-#include "common.h"
+#include "io_dev.h"
 
 namespace hopmi {
 
@@ -27,24 +27,25 @@ __device__ __forceinline__ float gelu_erf_grad_(float v) {
 }
 
 // x [M][N] (N % 4 == 0), bias [N]
-__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                                            float* __restrict__ out, size_t n4, int N4) {
+template <typename T>
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                            T* __restrict__ out, size_t n4, int N4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 v = ld4(x + 4 * i);
     const float4 b = reinterpret_cast<const float4*>(bias)[i % N4];
-    reinterpret_cast<float4*>(out)[i] = make_float4(gelu_erf_(v.x + b.x), gelu_erf_(v.y + b.y), gelu_erf_(v.z + b.z), gelu_erf_(v.w + b.w));
+    st4(out + 4 * i, make_float4(gelu_erf_(v.x + b.x), gelu_erf_(v.y + b.y), gelu_erf_(v.z + b.z), gelu_erf_(v.w + b.w)));
   }
 }
 
-__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                                            const float* __restrict__ dy, float* __restrict__ dx, size_t n4,
-                                                            int N4) {
+template <typename T>
+__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                            const T* __restrict__ dy, T* __restrict__ dx, size_t n4, int N4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 v = ld4(x + 4 * i);
     const float4 b = reinterpret_cast<const float4*>(bias)[i % N4];
-    const float4 g = reinterpret_cast<const float4*>(dy)[i];
-    reinterpret_cast<float4*>(dx)[i] = make_float4(g.x * gelu_erf_grad_(v.x + b.x), g.y * gelu_erf_grad_(v.y + b.y),
-                                                   g.z * gelu_erf_grad_(v.z + b.z), g.w * gelu_erf_grad_(v.w + b.w));
+    const float4 g = ld4(dy + 4 * i);
+    st4(dx + 4 * i, make_float4(g.x * gelu_erf_grad_(v.x + b.x), g.y * gelu_erf_grad_(v.y + b.y),
+                                g.z * gelu_erf_grad_(v.z + b.z), g.w * gelu_erf_grad_(v.w + b.w)));
   }
 }
 
@@ -58,9 +59,13 @@ constexpr int LN_MAX4 = 4;            // float4 per lane: D <= 64 * 4 * 4 = 1024
 
 // one wave per row: z = dropout(x + bias) + res[row % res_rows] ; out = (z - mean) * rstd * gamma + beta
 // saves z's normalised form xhat and rstd for the backward.
-__global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+// `x` is typed (the GEMM output); `out` stays fp32 (it is the next block's residual) and `out_t` (nullable) receives the same
+// values in x's type: the next GEMM's input.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                                    const float* __restrict__ res, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float* __restrict__ out,
+                                                                   T* __restrict__ out_t,
                                                                    float* __restrict__ xhat, float* __restrict__ rstd_out, int M,
                                                                    int D, int res_rows, float eps, unsigned drop_thresh,
                                                                    float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const float* 
     const int c4 = lane + 64 * k;
     z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < D4) {
-      float4 v = reinterpret_cast<const float4*>(x)[(size_t)row * D4 + c4];
+      float4 v = ld4(x + ((size_t)row * D4 + c4) * 4);
       const float4 b = reinterpret_cast<const float4*>(bias)[c4];
       const float4 r = reinterpret_cast<const float4*>(res)[(size_t)(row % res_rows) * D4 + c4];
       v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
@@ -106,7 +111,9 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const float* 
     if (c4 < D4) {
       const float4 g = reinterpret_cast<const float4*>(gamma)[c4], be = reinterpret_cast<const float4*>(beta)[c4];
       const float4 h = make_float4((z[k].x - mean) * rstd, (z[k].y - mean) * rstd, (z[k].z - mean) * rstd, (z[k].w - mean) * rstd);
-      reinterpret_cast<float4*>(out)[(size_t)row * D4 + c4] = make_float4(h.x * g.x + be.x, h.y * g.y + be.y, h.z * g.z + be.z, h.w * g.w + be.w);
+      const float4 o = make_float4(h.x * g.x + be.x, h.y * g.y + be.y, h.z * g.z + be.z, h.w * g.w + be.w);
+      reinterpret_cast<float4*>(out)[(size_t)row * D4 + c4] = o;
+      if (out_t != nullptr) st4(out_t + ((size_t)row * D4 + c4) * 4, o);
       if (xhat != nullptr) reinterpret_cast<float4*>(xhat)[(size_t)row * D4 + c4] = h;
     }
   }
@@ -114,9 +121,12 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const float* 
 }
 
 // dz = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)), dxh = dout * gamma ; dres = dz ; dx = dz o dropout mask
-__global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
+// `dout_t` (nullable): the gradient that arrived through the typed copy of the output, added to `dout`; `dx` is typed.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ dout_t,
+                                                                   const float* __restrict__ xhat,
                                                                    const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-                                                                   float* __restrict__ dx, float* __restrict__ dres, int M, int D,
+                                                                   T* __restrict__ dx, float* __restrict__ dres, int M, int D,
                                                                    unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -131,7 +141,11 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
     xh[k] = dh[k];
     if (c4 < D4) {
       const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
-      const float4 d = reinterpret_cast<const float4*>(dout)[(size_t)row * D4 + c4];
+      float4 d = reinterpret_cast<const float4*>(dout)[(size_t)row * D4 + c4];
+      if (dout_t != nullptr) {
+        const float4 e = ld4(dout_t + ((size_t)row * D4 + c4) * 4);
+        d = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+      }
       xh[k] = reinterpret_cast<const float4*>(xhat)[(size_t)row * D4 + c4];
       dh[k] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
       s1 += dh[k].x + dh[k].y + dh[k].z + dh[k].w;
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
         dz.z = ew_hash(seed, row, col + 2) >= drop_thresh ? dz.z * drop_scale : 0.f;
         dz.w = ew_hash(seed, row, col + 3) >= drop_thresh ? dz.w * drop_scale : 0.f;
       }
-      reinterpret_cast<float4*>(dx)[(size_t)row * D4 + c4] = dz;
+      st4(dx + ((size_t)row * D4 + c4) * 4, dz);
     }
   }
 }
@@ -167,28 +181,55 @@ static int ew_check(int M, int N, const char* what) {
 
 using namespace hopmi;
 
-extern "C" int hopmi_bias_gelu_fwd(const float* x, const float* bias, float* out, int M, int N, void* stream) {
+static int ew_dtype_ok(const char* what, int dtype) {
+  if (dtype != HOPMI_F32 && dtype != HOPMI_BF16) { set_error("%s: dtype %d (0 = fp32, 1 = bf16)", what, dtype); return HOPMI_EINVAL; }
+  return HOPMI_OK;
+}
+
+extern "C" int hopmi_bias_gelu_fwd_dt(const void* x, const float* bias, void* out, int M, int N, int dtype, void* stream) {
   if (int e = ew_check(M, N, "hopmi_bias_gelu_fwd")) return e;
+  if (int e = ew_dtype_ok("hopmi_bias_gelu_fwd_dt", dtype)) return e;
   if (!x || !bias || !out) { set_error("hopmi_bias_gelu_fwd: null pointer argument"); return HOPMI_EINVAL; }
   const size_t n4 = (size_t)M * N / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(bias_gelu_fwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, out, n4, N / 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HOPMI_BF16)
+    hipLaunchKernelGGL(bias_gelu_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x), bias, static_cast<__bf16*>(out), n4, N / 4);
+  else
+    hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x), bias, static_cast<float*>(out), n4, N / 4);
   return check_launch("hopmi_bias_gelu_fwd");
 }
 
-extern "C" int hopmi_bias_gelu_bwd(const float* x, const float* bias, const float* dy, float* dx, int M, int N, void* stream) {
+extern "C" int hopmi_bias_gelu_bwd_dt(const void* x, const float* bias, const void* dy, void* dx, int M, int N, int dtype, void* stream) {
   if (int e = ew_check(M, N, "hopmi_bias_gelu_bwd")) return e;
+  if (int e = ew_dtype_ok("hopmi_bias_gelu_bwd_dt", dtype)) return e;
   if (!x || !bias || !dy || !dx) { set_error("hopmi_bias_gelu_bwd: null pointer argument"); return HOPMI_EINVAL; }
   const size_t n4 = (size_t)M * N / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, dy, dx, n4, N / 4);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HOPMI_BF16)
+    hipLaunchKernelGGL(bias_gelu_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x), bias,
+                       static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), n4, N / 4);
+  else
+    hipLaunchKernelGGL(bias_gelu_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x), bias,
+                       static_cast<const float*>(dy), static_cast<float*>(dx), n4, N / 4);
   return check_launch("hopmi_bias_gelu_bwd");
 }
 
-extern "C" int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const float* bias, const float* res, int res_rows,
-                                                         const float* gamma, const float* beta, float* out, float* xhat,
-                                                         float* rstd, int M, int D, float eps, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+extern "C" int hopmi_bias_gelu_fwd(const float* x, const float* bias, float* out, int M, int N, void* stream) {
+  return hopmi_bias_gelu_fwd_dt(x, bias, out, M, N, HOPMI_F32, stream);
+}
+
+extern "C" int hopmi_bias_gelu_bwd(const float* x, const float* bias, const float* dy, float* dx, int M, int N, void* stream) {
+  return hopmi_bias_gelu_bwd_dt(x, bias, dy, dx, M, N, HOPMI_F32, stream);
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const float* bias, const float* res, int res_rows,
+                                                            const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
+                                                            float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
+                                                            const unsigned* seed_dev, int dtype, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_fwd")) return e;
+  if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_fwd_dt", dtype)) return e;
   if (!x || !bias || !res || !gamma || !beta || !out) { set_error("hopmi_bias_dropout_residual_layernorm_fwd: null pointer argument"); return HOPMI_EINVAL; }
   if (D > 256 * LN_MAX4 || res_rows <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
     set_error("hopmi_bias_dropout_residual_layernorm_fwd: D=%d (max %d), res_rows=%d, p_drop=%f", D, 256 * LN_MAX4, res_rows, p_drop);
@@ -196,20 +237,44 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const f
   }
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, res,
-                     gamma, beta, out, xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HOPMI_BF16)
+    hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const __bf16*>(x), bias, res,
+                       gamma, beta, out, static_cast<__bf16*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev);
+  else
+    hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const float*>(x), bias, res,
+                       gamma, beta, out, static_cast<float*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_bias_dropout_residual_layernorm_fwd");
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                            const float* gamma, void* dx, float* dres, int M, int D, float p_drop,
+                                                            unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
+  if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
+  if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_bwd_dt", dtype)) return e;
+  if (!dout || !xhat || !rstd || !gamma || !dx || !dres) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (D > 256 * LN_MAX4 || !(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: D=%d p_drop=%f", D, p_drop); return HOPMI_EINVAL; }
+  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HOPMI_BF16)
+    hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const __bf16*>(dout_t), xhat,
+                       rstd, gamma, static_cast<__bf16*>(dx), dres, M, D, thresh, dscale, seed, seed_dev);
+  else
+    hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const float*>(dout_t), xhat,
+                       rstd, gamma, static_cast<float*>(dx), dres, M, D, thresh, dscale, seed, seed_dev);
+  return check_launch("hopmi_bias_dropout_residual_layernorm_bwd");
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const float* bias, const float* res, int res_rows,
+                                                         const float* gamma, const float* beta, float* out, float* xhat,
+                                                         float* rstd, int M, int D, float eps, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+  return hopmi_bias_dropout_residual_layernorm_fwd_dt(x, bias, res, res_rows, gamma, beta, out, nullptr, xhat, rstd, M, D, eps, p_drop, seed,
+                                                      seed_dev, HOPMI_F32, stream);
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xhat, const float* rstd,
                                                          const float* gamma, float* dx, float* dres, int M, int D,
                                                          float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
-  if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
-  if (!dout || !xhat || !rstd || !gamma || !dx || !dres) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: null pointer argument"); return HOPMI_EINVAL; }
-  if (D > 256 * LN_MAX4 || !(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: D=%d p_drop=%f", D, p_drop); return HOPMI_EINVAL; }
-  const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
-  const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dout, xhat, rstd,
-                     gamma, dx, dres, M, D, thresh, dscale, seed, seed_dev);
-  return check_launch("hopmi_bias_dropout_residual_layernorm_bwd");
+  return hopmi_bias_dropout_residual_layernorm_bwd_dt(dout, nullptr, xhat, rstd, gamma, dx, dres, M, D, p_drop, seed, seed_dev, HOPMI_F32, stream);
 }

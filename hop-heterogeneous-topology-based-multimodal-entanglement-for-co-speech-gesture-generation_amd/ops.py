@@ -365,6 +365,145 @@ class _BiasDropResLnFn(torch.autograd.Function):
         return dx, None, dres, None, None, None, None, None
 
 
+# ---- bf16-storage forms of the frozen BERT's epilogue / attention operators (dtype argument of the `_dt` entry points) ------
+# Under bf16 autocast the library GEMMs produce and consume bf16; these operators read the GEMM output and write the next
+# GEMM's input in bf16 themselves (fp32 arithmetic inside), so no cast kernel sits on either side of them.  The values are
+# the ones the fp32-storage operators + autocast's casts produce: the rounding to bf16 just moves into the store.
+_BF16 = 1
+
+
+def _dev_bf16(t, name):
+    if not t.is_cuda:
+        raise _lib.HopmiError(f"hopmi: `{name}` is on {t.device}; the hot path only runs on a ROCm device (no CPU fallback)")
+    if t.dtype != torch.bfloat16:
+        raise _lib.HopmiError(f"hopmi: `{name}` must be bfloat16, got {t.dtype}")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+class _BiasGeluBf16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        x, bias = _dev_bf16(x, "x"), _dev_f32(bias.detach().float(), "bias")
+        N = x.shape[-1]
+        M = x.numel() // N
+        out = torch.empty_like(x)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_gelu_fwd", 4 * x.numel(), 0,
+                          lambda: L.hopmi_bias_gelu_fwd_dt(x.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, _BF16, st)),
+                   "hopmi_bias_gelu_fwd_dt")
+        ctx.save_for_backward(x, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bias = ctx.saved_tensors
+        dy = _dev_bf16(dy, "dy")
+        N = x.shape[-1]
+        M = x.numel() // N
+        dx = torch.empty_like(x)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_gelu_bwd", 6 * x.numel(), 0,
+                          lambda: L.hopmi_bias_gelu_bwd_dt(x.data_ptr(), bias.data_ptr(), dy.data_ptr(), dx.data_ptr(), M, N, _BF16, st)),
+                   "hopmi_bias_gelu_bwd_dt")
+        return dx, None
+
+
+def bias_gelu_bf16(x, bias):
+    """gelu_erf(x + bias) with bf16 storage on both sides (x: a bf16 GEMM output; result: the next GEMM's bf16 input)."""
+    return _BiasGeluBf16Fn.apply(x, bias)
+
+
+class _BiasDropResLnBf16Fn(torch.autograd.Function):
+    """(out fp32, out16 bf16) = LayerNorm(dropout(x + bias) + res): x is a bf16 GEMM output, res / out the fp32 residual
+    stream, out16 the same values in bf16 for the next GEMM.  Backward takes both incoming gradients."""
+
+    @staticmethod
+    def forward(ctx, x, bias, res, gamma, beta, eps, p_drop, seed):
+        x, res = _dev_bf16(x, "x"), _dev_f32(res, "res")
+        bias, gamma, beta = (_dev_f32(t.detach().float(), n) for t, n in ((bias, "bias"), (gamma, "gamma"), (beta, "beta")))
+        D = x.shape[-1]
+        M = x.numel() // D
+        res_rows = res.numel() // D
+        need = x.requires_grad or res.requires_grad
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        out16 = torch.empty_like(x)
+        xhat = torch.empty_like(out) if need else None
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device) if need else None
+        L, st, sp = _lib.lib(), _stream(), _seed_ptr()
+        _lib.check(_timed("bias_drop_res_ln_fwd", x.numel() * (2 + 4 + 4 + 2 + (4 if need else 0)), 0,
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_fwd_dt(
+                              x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
+                              out.data_ptr(), out16.data_ptr(), _ptr(xhat), _ptr(rstd), M, D, float(eps), float(p_drop),
+                              int(seed) & _M32, sp, _BF16, st)),
+                   "hopmi_bias_dropout_residual_layernorm_fwd_dt")
+        if need:
+            ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.p_drop, ctx.seed, ctx.res_shape, ctx.x_rows, ctx.sp = float(p_drop), int(seed) & _M32, res.shape, M, sp
+        return out, out16
+
+    @staticmethod
+    def backward(ctx, dout, dout16):
+        xhat, rstd, gamma = ctx.saved_tensors
+        D = xhat.shape[-1]
+        M = ctx.x_rows
+        if dout is None:
+            dout = torch.zeros_like(xhat)
+        dout = _dev_f32(dout, "dout")
+        d16 = None if dout16 is None else _dev_bf16(dout16, "dout16")
+        dx = torch.empty(xhat.shape, dtype=torch.bfloat16, device=xhat.device)
+        dres = torch.empty_like(xhat)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_drop_res_ln_bwd", 14 * xhat.numel(), 0,
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_dt(
+                              dout.data_ptr(), _ptr(d16), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                              dres.data_ptr(), M, D, ctx.p_drop, ctx.seed, ctx.sp, _BF16, st)),
+                   "hopmi_bias_dropout_residual_layernorm_bwd_dt")
+        if tuple(ctx.res_shape) != tuple(dres.shape):
+            dres = dres.view(-1, *ctx.res_shape).sum(0)
+        return dx, None, dres, None, None, None, None, None
+
+
+def bias_dropout_residual_layernorm_bf16(x, bias, res, gamma, beta, eps, p_drop=0.0, seed=0):
+    return _BiasDropResLnBf16Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
+
+
+class _BertAttnBf16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, p_drop, seed):
+        qkv = _dev_bf16(qkv, "qkv")
+        B, L, three, H, dh = qkv.shape
+        if three != 3 or dh != 64 or L > 64:
+            raise _lib.HopmiError(f"hopmi bert_attn: unsupported qkv shape {tuple(qkv.shape)} (need (B, L<=64, 3, H, 64))")
+        out = torch.empty(B, L, H * dh, dtype=torch.bfloat16, device=qkv.device)
+        Lb, st, sp = _lib.lib(), _stream(), _seed_ptr()
+        _lib.check(_timed("bert_attn_fwd", 2 * 4 * B * L * H * dh, 4 * B * H * L * L * dh,
+                          lambda: Lb.hopmi_bert_attn_fwd_dt(qkv.data_ptr(), out.data_ptr(), B, L, H, float(p_drop), int(seed), sp, _BF16, st)),
+                   "hopmi_bert_attn_fwd_dt")
+        ctx.save_for_backward(qkv)
+        ctx.p_drop, ctx.seed, ctx.sp = float(p_drop), int(seed), sp
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        dout = _dev_bf16(dout, "dout")
+        B, L, _, H, dh = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        Lb, st = _lib.lib(), _stream()
+        _lib.check(_timed("bert_attn_bwd", 2 * 7 * B * L * H * dh, 10 * B * H * L * L * dh,
+                          lambda: Lb.hopmi_bert_attn_bwd_dt(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, L, H,
+                                                            ctx.p_drop, ctx.seed, ctx.sp, _BF16, st)), "hopmi_bert_attn_bwd_dt")
+        return dqkv, None, None
+
+
+def bert_attention_bf16(qkv, p_drop=0.0, seed=0):
+    """bert_attention on a bf16 fused-QKV GEMM output, bf16 result."""
+    return _BertAttnBf16Fn.apply(qkv, p_drop, seed)
+
+
 def bias_dropout_residual_layernorm(x, bias, res, gamma, beta, eps, p_drop=0.0, seed=0):
     """LayerNorm(dropout(x + bias) + res) * gamma + beta; gradients w.r.t. x and res only."""
     return _BiasDropResLnFn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)

@@ -207,6 +207,26 @@ int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, const float* xh
                                               const float* gamma, float* dx, float* dres, int M, int D,
                                               float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
+/* ---- storage-typed forms of the frozen BERT's operators (g1: bf16 configurations).  `dtype` = 0 (fp32) or 1 (bf16) is the
+ *      storage type of the tensors that sit between two GEMMs -- x / out / dy / dx of bias + GELU, qkv / out / d_out / dqkv of the
+ *      self-attention, x (GEMM output) / out_t (next GEMM's input) / dout_t / dx of bias + dropout + residual + LayerNorm, whose
+ *      residual stream (res, out, dout, dres) and saved xhat / rstd stay fp32.  All arithmetic is fp32; with dtype 1 the values are
+ *      those of the fp32 forms under torch autocast, rounded to bf16 at the store instead of by a cast kernel.  The untyped entry
+ *      points above are these with dtype 0 (and out_t / dout_t NULL). */
+int hopmi_bias_gelu_fwd_dt(const void* x, const float* bias, void* out, int M, int N, int dtype, void* stream);
+int hopmi_bias_gelu_bwd_dt(const void* x, const float* bias, const void* dy, void* dx, int M, int N, int dtype, void* stream);
+int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const float* bias, const float* res, int res_rows,
+                                                 const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
+                                                 float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
+                                                 const unsigned* seed_dev, int dtype, void* stream);
+int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                 const float* gamma, void* dx, float* dres, int M, int D, float p_drop,
+                                                 unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
+int hopmi_bert_attn_fwd_dt(const void* qkv, void* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev,
+                           int dtype, void* stream);
+int hopmi_bert_attn_bwd_dt(const void* qkv, const void* d_out, void* dqkv, int B, int L, int H, float p_drop, unsigned seed,
+                           const unsigned* seed_dev, int dtype, void* stream);
+
 /* ---- bidirectional GRU layer recurrence: model/HOP.py:166-167,248 (decoder nn.GRU, hidden 350) and
  *      model/multimodal_context_net.py:236-237,257 (discriminator nn.GRU, hidden 64); torch.nn.GRU
  *      semantics, gate order r,z,n, h0 = 0.

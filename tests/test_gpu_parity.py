@@ -1161,3 +1161,46 @@ def test_bert_fast_path_split_gemm_vs_reference_golden(golden):
             assert_close(xi.grad, g["dx"], tol, what=f"bert dx parts={parts}")
     finally:
         ops.gemm_parts(prev)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_bert_fast_path_bf16_storage_equals_autocast_casts(golden, p_drop, monkeypatch):
+    """g1: under bf16 autocast the frozen BERT runs bf16 library GEMMs with the bf16-STORAGE forms of the HIP operators in
+    between (hopmi_*_dt, dtype 1: bf16 GEMM outputs read and bf16 GEMM inputs written directly, fp32 arithmetic, fp32
+    residual stream).  They must reproduce the fp32-storage operators wrapped in autocast's cast kernels -- the rounding to
+    bf16 only moves into the store -- and stay within the bf16 bar of the fp32 reference golden."""
+    from transformers import BertConfig, BertModel
+    from hopmi import bert_fast
+    from oracle import fill
+    dev = _dev()
+    g = golden("bert_base2")
+    cfg = BertConfig(num_hidden_layers=2, hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop)
+    m = BertModel(cfg)
+    fill.fill_state_(m)
+    for p in m.parameters():
+        p.requires_grad = False
+    m.to(dev).train()
+    x = fill.uniform("bert.inputs_embeds", (3, 34, cfg.hidden_size)).to(dev)
+    gout = fill.uniform("bert.gout3", (3, 34, cfg.hidden_size)).to(dev)
+    res = {}
+    for storage in (True, False):
+        monkeypatch.setattr(bert_fast, "BF16_STORAGE", storage)
+        monkeypatch.setattr(bert_fast.FrozenBertEncoder, "_calls", 0)          # same dropout masks in both runs
+        torch.manual_seed(5)                                                    # (the embedding dropout draws from torch's generator)
+        enc = bert_fast.FrozenBertEncoder(m)
+        xi = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = enc(xi)
+        assert out.dtype == torch.float32
+        assert bool(enc._w16) == storage, "the bf16-storage path was not the one that ran"
+        (out * gout).sum().backward()
+        res[storage] = (out.detach(), xi.grad.detach())
+    # identical roundings up to summation order inside the bf16 GEMMs (the fused QKV bias enters as a bf16 GEMM bias in one
+    # path and ... also in the other): a few bf16 ulps at most
+    assert rel_err(res[True][0], res[False][0]) <= 4e-3 and rel_err(res[True][1], res[False][1]) <= 8e-3
+    if p_drop == 0.0:
+        x1 = x[:1].clone().requires_grad_()
+        monkeypatch.setattr(bert_fast, "BF16_STORAGE", True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            o1 = bert_fast.FrozenBertEncoder(m)(x1)
+        assert rel_err(o1, g["out"]) <= 2e-2                                    # bf16 bar against the fp32 HF reference
