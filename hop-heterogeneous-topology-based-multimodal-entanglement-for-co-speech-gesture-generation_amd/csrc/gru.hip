@@ -139,8 +139,8 @@ __device__ __forceinline__ void panel_mfma_1(f32x4 (&acc)[NG], const float* As, 
 
 // one time step `s` of both directions (dir 0 walks t = s, dir 1 walks t = T-1-s).
 // MAXK2 = ceil(KP / 128) float2 slots per lane per row (KP = H padded to a multiple of 64).
-template <int MAXK2>
-__global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+template <int MAXK2, typename TG>
+__global__ __launch_bounds__(256) void gru_fwd_step_kernel(const TG* __restrict__ gi, const float* __restrict__ whh,
                                                            const float* __restrict__ bhh, float* __restrict__ y,
                                                            float* __restrict__ gates, int B, int T, int H, int KP, int s) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -163,9 +163,9 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int bc = min(b0 + (tid >> 4) + 16 * pass, B - 1);
-    const float* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
+    const TG* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) e_gi[pass][g] = gip[g * H];
+    for (int g = 0; g < 3; ++g) e_gi[pass][g] = (float)gip[g * H];
   }
 
   if (s > 0) {
@@ -228,10 +228,10 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
 // The workgroup owns units [16 jb, +16) of rows [32 bb, +32): the contraction over the 3H gates of step
 // p+1 is done gate block by gate block (K = H each): dgh rows and rows of W_hh^T (whhT[dir][unit][3H],
 // transposed by the caller) are both contiguous.
-template <int MAXK2>
+template <int MAXK2, typename TG>
 __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ gates, const float* __restrict__ whhT,
-                                                           float* __restrict__ dgi, float* __restrict__ dgh,
+                                                           TG* __restrict__ dgi, float* __restrict__ dgh,
                                                            float* __restrict__ dhz, int B, int T, int H, int KP, int s) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GruWork wk = gru_decode((H + GRU_NU - 1) / GRU_NU, (B + GRU_BM - 1) / GRU_BM);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
       const float dz = D * (hp - n) * z * (1.f - z);
       const float dr = dn * hn * r * (1.f - r);
       const size_t o = (((size_t)b * T + t) * 2 + d) * K + j;
-      dgi[o] = dr; dgi[o + H] = dz; dgi[o + 2 * H] = dn;
+      dgi[o] = (TG)dr; dgi[o + H] = (TG)dz; dgi[o + 2 * H] = (TG)dn;
       dgh[o] = dr; dgh[o + H] = dz; dgh[o + 2 * H] = dn * r;
       dhz_out[(size_t)b * H + j] = D * z;
     }
@@ -449,8 +449,8 @@ __device__ __forceinline__ Split8 load_w_frag(const float* row, int k0, int K) {
 
 // KP = 128 MAXK2 >= H: K padded so that each of the 4 K quarters is MAXK2 MFMA steps of 32.
 // 8 waves: wave w owns K quarter (w & 3) of unit half (w >> 2); the gate epilogue is one element per thread.
-template <int MAXK2>
-__global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+template <int MAXK2, typename TG>
+__global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __restrict__ gi, const float* __restrict__ whh,
                                                                  const float* __restrict__ bhh, float* y,
                                                                  float* __restrict__ gates, int* status, int B, int T,
                                                                  int H, int nJ, int nbb) {
@@ -493,9 +493,9 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __
     GRU_STAMP(0);
     float e_gi[3];
     {
-      const float* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
+      const TG* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
 #pragma unroll
-      for (int g = 0; g < 3; ++g) e_gi[g] = gip[g * H];
+      for (int g = 0; g < 3; ++g) e_gi[g] = (float)gip[g * H];
     }
     if (s > 0) {
       float2 v[2][MAXK2];                                              // wave w stages rows w and w + 8
@@ -555,10 +555,10 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const float* __
 
 // Persistent BPTT: same structure.  The workgroup's W_hh^T fragments (K = 3 gate blocks of H) stay in registers, the
 // dgh rows of all three gate blocks are staged at once (83 KB of LDS at H = 350), dgi and the D z carry stay private.
-template <int MAXK2>
+template <int MAXK2, typename TG>
 __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ gates, const float* __restrict__ whhT,
-                                                                 float* __restrict__ dgi, float* dgh, int* status, int B, int T,
+                                                                 TG* __restrict__ dgi, float* dgh, int* status, int B, int T,
                                                                  int H, int nJ, int nbb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KP = 128 * MAXK2, WS2 = (KP + 48) / 2;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
       const float dr = dn * hn * r * (1.f - r);
       const size_t o = (((size_t)b * T + t) * 2 + d) * K + j;
       st_sc1_f(dgh + o, dr); st_sc1_f(dgh + o + H, dz); st_sc1_f(dgh + o + 2 * H, dn * r);   // handed off
-      dgi[o] = dr; dgi[o + H] = dz; dgi[o + 2 * H] = dn;
+      dgi[o] = (TG)dr; dgi[o + H] = (TG)dz; dgi[o + 2 * H] = (TG)dn;
       dhz_own = D * z;
     }
     GRU_STAMP(5);
@@ -680,18 +680,18 @@ static int gru_validate(const void* const* ptrs, int n, int B, int T, int H) {
   return HOPMI_OK;
 }
 
-template <int MAXK2>
-static void launch_gru_fwd(dim3 grid, size_t lds, hipStream_t st, const float* gi, const float* whh, const float* bhh,
+template <int MAXK2, typename TG>
+static void launch_gru_fwd(dim3 grid, size_t lds, hipStream_t st, const TG* gi, const float* whh, const float* bhh,
                            float* y, float* gates, int B, int T, int H, int KP) {
   for (int s = 0; s < T; ++s)
-    hipLaunchKernelGGL(gru_fwd_step_kernel<MAXK2>, grid, dim3(256), lds, st, gi, whh, bhh, y, gates, B, T, H, KP, s);
+    hipLaunchKernelGGL((gru_fwd_step_kernel<MAXK2, TG>), grid, dim3(256), lds, st, gi, whh, bhh, y, gates, B, T, H, KP, s);
 }
 
-template <int MAXK2>
+template <int MAXK2, typename TG>
 static void launch_gru_bwd(dim3 grid, size_t lds, hipStream_t st, const float* dy, const float* y, const float* gates,
-                           const float* whhT, float* dgi, float* dgh, float* ws, int B, int T, int H, int KP) {
+                           const float* whhT, TG* dgi, float* dgh, float* ws, int B, int T, int H, int KP) {
   for (int s = 0; s < T; ++s)
-    hipLaunchKernelGGL(gru_bwd_step_kernel<MAXK2>, grid, dim3(256), lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP, s);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<MAXK2, TG>), grid, dim3(256), lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP, s);
 }
 
 }  // namespace hopmi
@@ -727,17 +727,18 @@ static int* gru_status_word(void* ws, int B, int T, int H) {
   return static_cast<int*>(ws) + hopmi_gru_ws_bytes(B, T, H) / sizeof(int) - 16;
 }
 
-template <int MAXK2>
-static void launch_gru_fwd_persistent(int grid, hipStream_t st, const float* gi, const float* whh, const float* bhh, float* y,
+template <int MAXK2, typename TG>
+static void launch_gru_fwd_persistent(int grid, hipStream_t st, const TG* gi, const float* whh, const float* bhh, float* y,
                                       float* gates, int* status, int B, int T, int H, int nJ, int nbb) {
   constexpr int WS2 = (128 * MAXK2 + 48) / 2;
   const size_t lds = (size_t)2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_F * sizeof(float);
-  hipLaunchKernelGGL(gru_fwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, status, B, T, H,
+  hipLaunchKernelGGL((gru_fwd_persistent_kernel<MAXK2, TG>), dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, status, B, T, H,
                      nJ, nbb);
 }
 
-extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws,
-                             int B, int T, int H, void* stream) {
+template <typename TG>
+static int gru_fwd_impl(const TG* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws, int B, int T, int H,
+                        void* stream) {
   const void* ptrs[] = {gi, whh, bhh, y, gates};
   if (int e = gru_validate(ptrs, 5, B, T, H)) return e;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -747,9 +748,9 @@ extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh
     gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), y, (size_t)B * T * 2 * H, st);
     const int grid = gp_grid(nJ, nbb);
     switch ((H + 127) / 128) {
-      case 1: launch_gru_fwd_persistent<1>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
-      case 2: launch_gru_fwd_persistent<2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
-      default: launch_gru_fwd_persistent<3>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      case 1: launch_gru_fwd_persistent<1, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      case 2: launch_gru_fwd_persistent<2, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      default: launch_gru_fwd_persistent<3, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
     }
     return check_launch("hopmi_gru_fwd(persistent)");
   }
@@ -759,30 +760,44 @@ extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh
   const int KP = ceil_to(H, 64);
   const size_t lds = ((size_t)(GRU_BM + 3 * GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD) * sizeof(float);
   switch ((KP + 127) / 128) {
-    case 1: launch_gru_fwd<1>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
-    case 2: launch_gru_fwd<2>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
-    case 3: launch_gru_fwd<3>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
-    default: launch_gru_fwd<4>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+    case 1: launch_gru_fwd<1, TG>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+    case 2: launch_gru_fwd<2, TG>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+    case 3: launch_gru_fwd<3, TG>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
+    default: launch_gru_fwd<4, TG>(grid, lds, st, gi, whh, bhh, y, gates, B, T, H, KP); break;
   }
   return check_launch("hopmi_gru_fwd");
+}
+
+extern "C" int hopmi_gru_fwd_dt(const void* gi, int gi_dtype, const float* whh, const float* bhh, float* y, float* gates, void* ws,
+                                int B, int T, int H, void* stream) {
+  if (gi_dtype == 1) return gru_fwd_impl(static_cast<const __bf16*>(gi), whh, bhh, y, gates, ws, B, T, H, stream);
+  if (gi_dtype == 0) return gru_fwd_impl(static_cast<const float*>(gi), whh, bhh, y, gates, ws, B, T, H, stream);
+  set_error("hopmi_gru_fwd_dt: gi_dtype %d (0 = fp32, 1 = bf16)", gi_dtype);
+  return HOPMI_EINVAL;
+}
+
+extern "C" int hopmi_gru_fwd(const float* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws,
+                             int B, int T, int H, void* stream) {
+  return gru_fwd_impl(gi, whh, bhh, y, gates, ws, B, T, H, stream);
 }
 
 extern "C" size_t hopmi_gru_bwd_ws_floats(int B, int H) {
   return (B > 0 && H > 0) ? (size_t)4 * B * H : 0;
 }
 
-template <int MAXK2>
+template <int MAXK2, typename TG>
 static void launch_gru_bwd_persistent(int grid, hipStream_t st, const float* dy, const float* y, const float* gates,
-                                      const float* whhT, float* dgi, float* dgh, int* status, int B, int T, int H, int nJ,
+                                      const float* whhT, TG* dgi, float* dgh, int* status, int B, int T, int H, int nJ,
                                       int nbb) {
   constexpr int WS2 = (128 * MAXK2 + 48) / 2;
   const size_t lds = (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_B * sizeof(float);
-  hipLaunchKernelGGL(gru_bwd_persistent_kernel<MAXK2>, dim3(grid), dim3(512), lds, st, dy, y, gates, whhT, dgi, dgh, status, B,
+  hipLaunchKernelGGL((gru_bwd_persistent_kernel<MAXK2, TG>), dim3(grid), dim3(512), lds, st, dy, y, gates, whhT, dgi, dgh, status, B,
                      T, H, nJ, nbb);
 }
 
-extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
-                             float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream) {
+template <typename TG>
+static int gru_bwd_impl(const float* dy, const float* y, const float* gates, const float* whhT, TG* dgi, float* dgh, float* ws,
+                        void* ws2, int B, int T, int H, void* stream) {
   const void* ptrs[] = {dy, y, gates, whhT, dgi, dgh, ws};
   if (int e = gru_validate(ptrs, 7, B, T, H)) return e;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -792,9 +807,9 @@ extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates
     gru_prepare(ws2, hopmi_gru_ws_bytes(B, T, H), dgh, (size_t)B * T * 2 * 3 * H, st);
     const int grid = gp_grid(nJ, nbb);
     switch ((H + 127) / 128) {
-      case 1: launch_gru_bwd_persistent<1>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
-      case 2: launch_gru_bwd_persistent<2>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
-      default: launch_gru_bwd_persistent<3>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
+      case 1: launch_gru_bwd_persistent<1, TG>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
+      case 2: launch_gru_bwd_persistent<2, TG>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
+      default: launch_gru_bwd_persistent<3, TG>(grid, st, dy, y, gates, whhT, dgi, dgh, status, B, T, H, nJ, nbb); break;
     }
     return check_launch("hopmi_gru_bwd(persistent)");
   }
@@ -804,10 +819,23 @@ extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates
   const int KP = ceil_to(H, 64);
   const size_t lds = ((size_t)(GRU_BM + GRU_NU) * (KP + 4) + 4 * GRU_BM * RED_LD) * sizeof(float);
   switch ((KP + 127) / 128) {
-    case 1: launch_gru_bwd<1>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
-    case 2: launch_gru_bwd<2>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
-    case 3: launch_gru_bwd<3>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
-    default: launch_gru_bwd<4>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+    case 1: launch_gru_bwd<1, TG>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+    case 2: launch_gru_bwd<2, TG>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+    case 3: launch_gru_bwd<3, TG>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
+    default: launch_gru_bwd<4, TG>(grid, lds, st, dy, y, gates, whhT, dgi, dgh, ws, B, T, H, KP); break;
   }
   return check_launch("hopmi_gru_bwd");
+}
+
+extern "C" int hopmi_gru_bwd_dt(const float* dy, const float* y, const float* gates, const float* whhT, void* dgi, int dgi_dtype,
+                                float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream) {
+  if (dgi_dtype == 1) return gru_bwd_impl(dy, y, gates, whhT, static_cast<__bf16*>(dgi), dgh, ws, ws2, B, T, H, stream);
+  if (dgi_dtype == 0) return gru_bwd_impl(dy, y, gates, whhT, static_cast<float*>(dgi), dgh, ws, ws2, B, T, H, stream);
+  set_error("hopmi_gru_bwd_dt: dgi_dtype %d (0 = fp32, 1 = bf16)", dgi_dtype);
+  return HOPMI_EINVAL;
+}
+
+extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,
+                             float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream) {
+  return gru_bwd_impl(dy, y, gates, whhT, dgi, dgh, ws, ws2, B, T, H, stream);
 }

@@ -897,14 +897,17 @@ def _track_status(ws):
 
 
 class _GruLayerFn(torch.autograd.Function):
-    """Recurrence of one bidirectional GRU layer (hopmi_gru_fwd / hopmi_gru_bwd).
+    """Recurrence of one bidirectional GRU layer (hopmi_gru_fwd_dt / hopmi_gru_bwd_dt).
 
-    gi (B,T,2,3H) = input projections of both directions; whh (2,3H,H); bhh (2,3H) -> y (B,T,2H)."""
+    gi (B,T,2,3H) = input projections of both directions, fp32 or -- under bf16 autocast, straight from the library GEMM --
+    bf16 (read as is: the `gi_dtype` ABI argument; its gradient goes back in the same type); whh (2,3H,H); bhh (2,3H) ->
+    y (B,T,2H) fp32.  Everything inside runs with autocast off (fp32 weight-gradient GEMMs)."""
 
     @staticmethod
-    @_fwd32
     def forward(ctx, gi, whh, bhh):
-        gi, whh, bhh = _dev_f32(gi, "gi"), _dev_f32(whh, "whh"), _dev_f32(bhh, "bhh")
+        typed = gi.dtype == torch.bfloat16
+        gi = _dev_bf16(gi, "gi") if typed else _dev_f32(gi.float(), "gi")
+        whh, bhh = _dev_f32(whh.float(), "whh"), _dev_f32(bhh.float(), "bhh")
         B, T, two, H3 = gi.shape
         H = H3 // 3
         if two != 2 or whh.shape != (2, 3 * H, H) or bhh.shape != (2, 3 * H):
@@ -915,43 +918,45 @@ class _GruLayerFn(torch.autograd.Function):
         ws = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=gi.device)
               if gru_persistent_allowed() else None)
         _lib.check(_timed("gru_fwd", 0, 2 * T * B * 2 * 3 * H * H,
-                          lambda: L.hopmi_gru_fwd(gi.data_ptr(), whh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
-                                                  gates.data_ptr(), _ptr(ws), B, T, H, st)), "hopmi_gru_fwd")
+                          lambda: L.hopmi_gru_fwd_dt(gi.data_ptr(), 1 if typed else 0, whh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
+                                                     gates.data_ptr(), _ptr(ws), B, T, H, st)), "hopmi_gru_fwd")
         _track_status(ws)
         if GRU_CHECK_STATUS and ws is not None and not torch.cuda.is_current_stream_capturing() and int(ws[-16].item()) != 0:
             raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out (status word set)")
         ctx.save_for_backward(y, gates, whh)
+        ctx.typed = typed
         return y
 
     @staticmethod
-    @_bwd32
     def backward(ctx, dy):
         y, gates, whh = ctx.saved_tensors
-        dy = _dev_f32(dy, "dy")
-        B, T, H2 = y.shape
-        H = H2 // 2
-        L, st = _lib.lib(), _stream()
-        whhT = whh.transpose(1, 2).contiguous()
-        dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
-        dgh = torch.empty_like(dgi)
-        ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
-        ws2 = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=y.device)
-               if gru_persistent_allowed() else None)
-        _lib.check(_timed("gru_bwd", 0, 2 * T * B * 2 * 3 * H * H,
-                          lambda: L.hopmi_gru_bwd(dy.data_ptr(), y.data_ptr(), gates.data_ptr(), whhT.data_ptr(),
-                                                  dgi.data_ptr(), dgh.data_ptr(), ws.data_ptr(), _ptr(ws2), B, T, H, st)),
-                   "hopmi_gru_bwd")
-        _track_status(ws2)
-        if GRU_CHECK_STATUS and ws2 is not None and not torch.cuda.is_current_stream_capturing() and int(ws2[-16].item()) != 0:
-            raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
-        # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
-        # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
-        yv = y.view(B, T, 2, H)
-        hprev = torch.zeros_like(yv)
-        hprev[:, 1:, 0] = yv[:, :-1, 0]
-        hprev[:, :-1, 1] = yv[:, 1:, 1]
-        dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
-        dbhh = dgh.sum(dim=(0, 1))
+        with torch.autocast("cuda", enabled=False):
+            dy = _dev_f32(dy.float(), "dy")
+            B, T, H2 = y.shape
+            H = H2 // 2
+            L, st = _lib.lib(), _stream()
+            whhT = whh.transpose(1, 2).contiguous()
+            dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.bfloat16 if ctx.typed else torch.float32, device=y.device)
+            dgh = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
+            ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
+            ws2 = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=y.device)
+                   if gru_persistent_allowed() else None)
+            _lib.check(_timed("gru_bwd", 0, 2 * T * B * 2 * 3 * H * H,
+                              lambda: L.hopmi_gru_bwd_dt(dy.data_ptr(), y.data_ptr(), gates.data_ptr(), whhT.data_ptr(),
+                                                         dgi.data_ptr(), 1 if ctx.typed else 0, dgh.data_ptr(), ws.data_ptr(), _ptr(ws2),
+                                                         B, T, H, st)),
+                       "hopmi_gru_bwd")
+            _track_status(ws2)
+            if GRU_CHECK_STATUS and ws2 is not None and not torch.cuda.is_current_stream_capturing() and int(ws2[-16].item()) != 0:
+                raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
+            # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
+            # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
+            yv = y.view(B, T, 2, H)
+            hprev = torch.zeros_like(yv)
+            hprev[:, 1:, 0] = yv[:, :-1, 0]
+            hprev[:, :-1, 1] = yv[:, 1:, 1]
+            dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
+            dbhh = dgh.sum(dim=(0, 1))
         return dgi, dwhh, dbhh
 
 

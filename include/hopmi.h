@@ -276,6 +276,13 @@ int hopmi_hop_losses_bwd(const float* out, const float* target, const float* out
                          const float* ws, const float* g, int B, int F, int Z, float w_reg, float w_kld, float* d_out,
                          float* d_mu, float* d_logvar, void* stream);
 
+/* The same two entry points with the storage type of the input projections as an argument (0 = fp32, 1 = bf16): under bf16
+ * autocast gi comes straight from the library GEMM and dgi goes straight into its backward; everything else stays fp32. */
+int hopmi_gru_fwd_dt(const void* gi, int gi_dtype, const float* whh, const float* bhh, float* y, float* gates, void* ws,
+                     int B, int T, int H, void* stream);
+int hopmi_gru_bwd_dt(const float* dy, const float* y, const float* gates, const float* whhT, void* dgi, int dgi_dtype,
+                     float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);
+
 /* ---- fp32 GEMM against frozen weights on the bf16 matrix cores (the frozen BERT's linears, HOP.py:90-91,204 ->
  *      transformers BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput nn.Linear calls)
  *   C[M][N] = A[M][K] . Bt[N][K]^T (+ bias[N]);  A, C fp32 row-major.
