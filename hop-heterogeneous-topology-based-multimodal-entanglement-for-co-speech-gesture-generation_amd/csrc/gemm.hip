@@ -360,17 +360,18 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
                      static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n);
 }
 
-// Tile choice, measured at the frozen BERT's shapes (tools/bench_gemm.py, HOPMI_GEMM_TILE forces a form): 128-row tiles,
-// double-buffered with one workgroup per CU when the tiles cover the chip about once (N = 768: 204 tiles), single-buffered
-// with two workgroups per CU for the larger grids (N = 2304 / 3072: 612 / 816 tiles).  64-row tiles (form 3) fill idle CUs
-// and quantise better on paper but lost 5-15 % everywhere (more weight traffic and barriers per MFMA): kept for experiments.
+// Tile choice by the number of 128 x 128 tiles, measured at the frozen BERT's shapes for M = 4352 (TED, batch 128) and M = 2176
+// (TED-Expressive, batch 64) (tools/bench_gemm.py [--m M], HOPMI_GEMM_TILE forces a form): double-buffered with one workgroup
+// per CU when the tiles cover the chip about once (160..256 tiles, e.g. N = 768 at M = 4352: 204), single-buffered with two
+// workgroups per CU above that (306, 408, 612, 816 tiles), and 64-row tiles when 128-row tiles would leave most CUs idle
+// (N = 768 at M = 2176: 102 tiles -> 204; 38 -> 29.5 us, 129 -> 103 us; at 204+ tiles the 64-row form loses 5-15 %).
 // Also measured and dropped: 4 waves of 64 x 64 with two workgroups per CU (-8...-30 %), a second fragment register set read
 // one step ahead (-12...-30 %).
 template <int NP>
 static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
   const int t128 = ((M + 127) / 128) * (N / GN);
   const int forced = env_int("HOPMI_GEMM_TILE", 0);       // diagnostics: 1 = 128/DB, 2 = 128/!DB, 3 = 64/!DB
-  const int mode = (forced >= 1 && forced <= 3) ? forced : (t128 <= 320 ? 1 : 2);
+  const int mode = (forced >= 1 && forced <= 3) ? forced : (t128 < 160 ? 3 : (t128 <= 256 ? 1 : 2));
   if (mode == 1) launch_gemm_variant<NP, true, 128>(A, Bimg, bias, C, M, N, K, st);
   else if (mode == 2) launch_gemm_variant<NP, false, 128>(A, Bimg, bias, C, M, N, K, st);
   else launch_gemm_variant<NP, false, 64>(A, Bimg, bias, C, M, N, K, st);

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 if "--tuned" in sys.argv:
     hopmi.use_tuned_gemms()
 g = torch.Generator().manual_seed(0)
-M = 4352
+M = int(sys.argv[sys.argv.index('--m') + 1]) if '--m' in sys.argv else 4352
 for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 2304)):
     x = torch.randn(M, K, generator=g).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
