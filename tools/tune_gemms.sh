@@ -11,6 +11,6 @@ for cfg in "--dataset TED --batch 128 --epoch 0" "--dataset TED --batch 128 --ep
            "--dataset TED --batch 128 --epoch 0 --dtype bf16" "--dataset TED --batch 128 --epoch 11 --dtype bf16" \
            "--dataset TED_expressive --batch 64 --epoch 11 --dtype bf16"; do
   echo "== tuning: $cfg"
-  timeout -k 10 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $cfg 2>/dev/null | tail -1 | cut -c1-160
+  timeout -k 10 600 python bench.py --eager --kernel-steps 0 --steps 2 --warmup 1 --no-cpu-baseline $cfg 2>/dev/null | tail -1 | cut -c1-160
   wc -l gpurun_out/tunableop_results0.csv
 done
