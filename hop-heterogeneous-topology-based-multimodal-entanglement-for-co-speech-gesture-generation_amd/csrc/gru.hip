@@ -7,12 +7,12 @@
 //     done by the caller (hipBLASLt) -- they have no sequential dependency;
 //   * the sequential part -- gh = h_{t-1} W_hh^T + b_hh, the gates, h_t -- runs here, both directions together,
 //     in one of two schedules behind the same entry point:
-//       - persistent (whenever every workgroup of the launch can be resident at once): ONE launch per layer; a
-//         workgroup keeps its W_hh slice in LDS for all T steps and hands h_t to the workgroups of its
-//         (direction, batch group) through L2 (write-through stores, an arrival counter per step, bounded polling);
+//       - persistent (whenever every workgroup of the launch can be resident at once): ONE launch per layer; see the block
+//         comment in front of gru_fwd_persistent_kernel (recurrent weights as split-bf16 MFMA fragments in registers,
+//         16 x 32 tiles, h_t handed over through y itself: fill pattern + re-load, no counters);
 //       - per-step: one launch per time step (a dependent launch boundary costs ~1.5 us on MI355X), the T launches
-//         enqueued from C in one ABI call.
-// Decomposition of a step: workgroup (jb, bb, dir) owns hidden units [16 jb, 16 jb + 16) of batch rows
+//         enqueued from C in one ABI call, exact-fp32 MFMA.
+// Decomposition of a per-step launch: workgroup (jb, bb, dir) owns hidden units [16 jb, 16 jb + 16) of batch rows
 // [32 bb, 32 bb + 32): out[32 x (3 gates x 16)] = h_prev[32 x H] W_slice^T on exact-fp32 MFMA 16x16x4.
 // Both operand panels (32 rows of h_prev, 48 rows of W_hh) are streamed HBM/L2 -> LDS with row-contiguous
 // 8-B loads (512 B per wave instruction; per-lane fragment loads would touch 64 cache lines each), K is
