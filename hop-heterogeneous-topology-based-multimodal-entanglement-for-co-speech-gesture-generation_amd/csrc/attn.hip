@@ -4,14 +4,16 @@
 //
 // with L = 34 audio frames, S = 1500 text prototypes shared by the whole batch, H = 8 heads, E = 128.
 // The reference materialises the (B,8,34,1500) score tensor (209 MB at B = 128) three times per forward;
-// here it never leaves the chip: flash-style online softmax, exact-fp32 MFMA (16x16x4) for both contractions.
+// here it never leaves the chip: flash-style online softmax, and all five contractions (forward: Q K^T, P V; backward:
+// dO V^T, dS K, dS^T Q, P^T dO) as three-term products of split bf16 operands on v_mfma_f32_16x16x32_bf16 (bf16_dev.h:
+// ~2^-16 relative per product, fp32 accumulation, fp32 softmax).
 //
 // Rows (b, l) are flat: N = B*L query rows per head.  Workgroup = (64-row tile, head); wave w owns 16 rows
-// entirely (its softmax statistics never cross waves) and keeps their Q fragments in registers.  The 64-key
-// K and V chunks are streamed HBM/L2 -> registers -> LDS (register prefetch of the next chunk under the
-// current chunk's MFMAs).  Linear workgroup id = tile*H + head, so with H = 8 every head lives on one XCD
-// and its K/V (1.5 MB) stay in that XCD's L2 (speed only).  Dropout uses a stateless hash of
-// (seed, row, head, key) so the backward can regenerate the mask.
+// entirely (its softmax statistics never cross waves) and keeps their Q fragments in registers.  The MFMA B operands are
+// read from bf16 images of K / V (and, in the backward, Q / dO) that attn_images_kernel prepares per call (natural rows
+// and transposed rows, hi + lo), so that staging a 32-key chunk is a set of plain 16-byte copies global -> registers -> LDS.
+// Linear workgroup id = tile*H + head, so with H = 8 every head lives on one XCD and its images stay in that XCD's L2
+// (speed only).  Dropout uses a stateless hash of (seed, row, head, key pair) so the backward can regenerate the mask.
 #include "attn_dev.h"
 #include "bf16_dev.h"
 
