@@ -252,7 +252,12 @@ def main():
         timer, ops.TIMER = ops.TIMER, None
         ks = timer.summary()
 
-    # ---- 2. warm-up (includes the recording of the step's graphs), then the timed region --------------------------------
+    # ---- 2. set-up (the one-time recording of the step's graphs: like building the model, not a warm-up step), W warm-up
+    #         steps, then the timed region ------------------------------------------------------------------------------
+    setup_calls = 0
+    while not args.eager and graphed.n_replay < 1 and setup_calls < 4:
+        step()
+        setup_calls += 1
     for _ in range(args.warmup):
         step()
     fence()
