@@ -29,6 +29,8 @@ def main():
     epoch = int(sys.argv[1])
     steps._randn_like = lambda t: torch.full_like(t, 0.5)
     steps._randperm = lambda n, device: torch.arange(n - 1, -1, -1, device=device)
+    if os.environ.get("HOPMI_WORKER_DUMMY_MB"):        # diagnostic: shift every later allocation
+        _dummy = torch.empty(int(float(os.environ["HOPMI_WORKER_DUMMY_MB"]) * (1 << 20)), dtype=torch.uint8, device=dev)
     m1, d1, inp = _pair(9, dev)
     # a different batch per rank (same replicas)
     names = ("in_audio", "log_melspec", "text", "target_dir_vec", "vid_indices")
@@ -58,10 +60,34 @@ def main():
     # replay on in this two-ranks-on-one-GPU gloo rehearsal, while each path alone, in either order, reproduces the plain
     # all-reduce-every-gradient reference to 1e-8 (platform findings); a training loop never interleaves two
     # models' steps, so the comparison is made on what it does.
-    for it in range(4):
-        losses2.append(graphed(epoch, *batch))
-    for it in range(4):
-        losses1.append(hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, sync1))
+    if os.environ.get("HOPMI_WORKER_INTERLEAVE"):         # diagnostic: the order that showed the fault described above
+        for it in range(4):
+            losses1.append(hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, sync1))
+            if os.environ.get("HOPMI_WORKER_SYNC_BEFORE"):
+                torch.cuda.synchronize()
+            losses2.append(graphed(epoch, *batch))
+            if os.environ.get("HOPMI_WORKER_SYNC_AFTER"):
+                torch.cuda.synchronize()
+    else:
+        for it in range(4):
+            losses2.append(graphed(epoch, *batch))
+        for it in range(4):
+            losses1.append(hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, sync1))
+    if os.environ.get("HOPMI_WORKER_POOLCHECK"):
+        snap = torch.cuda.memory_snapshot()
+        segs = [(sg["address"], sg["address"] + sg["total_size"], tuple(sg.get("segment_pool_id", (0, 0)))) for sg in snap]
+        def pool_of(ptr):
+            for a, b_, pid in segs:
+                if a <= ptr < b_:
+                    return pid
+            return None
+        rec = next(iter(graphed.records.values()))
+        out = {}
+        for n, p_ in list(m2.named_parameters()) + list(d2.named_parameters()):
+            if p_.grad is not None:
+                out.setdefault(str(pool_of(p_.grad.data_ptr())), []).append(n)
+        print("POOLCHECK grads by pool:", {k: (len(v), v[:6]) for k, v in out.items()}, flush=True)
+        print("POOLCHECK static:", [str(pool_of(t.data_ptr())) for t in rec["static"]], "keep:", [str(pool_of(t.data_ptr())) for t in rec["cap"].keep], flush=True)
     sharded_before = bool(graphed.sharded)
     own = (graphed.r0, graphed.r1)
     # rows this rank does not own have not moved since the recording began; unshard() fetches them from their owners
