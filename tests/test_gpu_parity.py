@@ -1148,7 +1148,8 @@ def test_bert_fast_path_split_gemm_vs_reference_golden(golden):
         p.requires_grad = False
     m.to(dev).train()
     x = fill.uniform("bert.inputs_embeds", (1, 34, cfg.hidden_size)).to(dev)
-    prev = ops.gemm_parts()
+    prev, prev_rows = ops.gemm_parts(), bert_fast.SPLIT_MIN_ROWS
+    bert_fast.SPLIT_MIN_ROWS = 1                      # (34 rows here; the product path switches over at 1 024)
     try:
         for parts, tol in ((3, RTOL), (2, RTOL)):
             ops.gemm_parts(parts)
@@ -1161,6 +1162,7 @@ def test_bert_fast_path_split_gemm_vs_reference_golden(golden):
             assert_close(xi.grad, g["dx"], tol, what=f"bert dx parts={parts}")
     finally:
         ops.gemm_parts(prev)
+        bert_fast.SPLIT_MIN_ROWS = prev_rows
 
 
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
