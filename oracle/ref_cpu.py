@@ -93,7 +93,7 @@ def gated_tcn(x, wf, bf, wg, bg, d):
     return torch.tanh(conv(wf, bf)) * torch.sigmoid(conv(wg, bg))
 
 
-def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True, relu_masks=None) -> Tuple[torch.Tensor, SD]:
+def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True, relu_masks=None, relu_probe=None) -> Tuple[torch.Tensor, SD]:
     """gwnet.py:143-249 (gcn_bool, addaptadj, supports=[]).  x: (B,173,V,16) -> (B,173,V,4).
 
     Returns (out, bn_updates) where bn_updates holds the new running_mean / running_var /
@@ -101,7 +101,9 @@ def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True, relu_masks=None) ->
 
     `relu_masks` = (mask_skip (B,256,V,4), mask_end (B,512,V,4)) of {0,1}: evaluate the two ReLUs of gwnet.py:240-242 as
     `x * mask` -- gradient checks at sizes with ~1e6 pre-activations would otherwise depend on which side of zero
-    an implementation's rounding puts the few values that lie within 1e-7 of the kink.
+    an implementation's rounding puts the few values that lie within 1e-7 of the kink.  `relu_probe` (a list) receives the
+    oracle's own two pre-activations, so that a test can check that the masks it passed in differ from the oracle's sides
+    only at the kink.
     """
     p = lambda n: sd[prefix + n]
     x = conv1x1_nchw(x, p("start_conv.weight"), p("start_conv.bias"))
@@ -127,7 +129,10 @@ def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True, relu_masks=None) ->
     relu1 = torch.relu if relu_masks is None else (lambda t: t * relu_masks[0].to(t.dtype))
     relu2 = torch.relu if relu_masks is None else (lambda t: t * relu_masks[1].to(t.dtype))
     x = relu1(skip)                                                        # gwnet.py:240
-    x = relu2(conv1x1_nchw(x, p("end_conv_1.weight"), p("end_conv_1.bias")))
+    pre2 = conv1x1_nchw(x, p("end_conv_1.weight"), p("end_conv_1.bias"))
+    if relu_probe is not None:
+        relu_probe += [skip.detach(), pre2.detach()]
+    x = relu2(pre2)
     x = conv1x1_nchw(x, p("end_conv_2.weight"), p("end_conv_2.bias"))
     return x, updates
 
@@ -135,12 +140,13 @@ def gwnet_forward(sd: SD, x, prefix="gwnet.", training=True, relu_masks=None) ->
 # ----------------------------------------------------------- reprogramming cross-attention
 def reprogramming_layer(sd: SD, target, source, value, n_heads, prefix="reprogramming_layer.",
                         drop_mask: Optional[torch.Tensor] = None, p_drop: float = 0.0,
-                        relu_mask: Optional[torch.Tensor] = None):
+                        relu_mask: Optional[torch.Tensor] = None, relu_probe: Optional[list] = None):
     """HOP.py:271-299.  target (B,L,d_model); source/value (S,d_llm) -> (B,L,d_llm).
 
     `drop_mask` (B,H,L,S) of {0,1} reproduces nn.Dropout(p_drop) on the probabilities.  `relu_mask` (B,L,H*E) of
     {0,1} evaluates the ReLU of HOP.py:284 as `x * mask` (gradient checks with millions of pre-activations must not
-    depend on which side of zero rounding puts the few values within 1e-7 of the kink).
+    depend on which side of zero rounding puts the few values within 1e-7 of the kink); `relu_probe` (a list) receives
+    the oracle's own pre-activation so that a test can check the mask against it.
     """
     p = lambda n: sd[prefix + n]
     B, L, _ = target.shape
@@ -154,6 +160,8 @@ def reprogramming_layer(sd: SD, target, source, value, n_heads, prefix="reprogra
     if drop_mask is not None:
         attn = attn * drop_mask / (1.0 - p_drop)
     out = torch.einsum("bhls,she->blhe", attn, v).reshape(B, L, -1)
+    if relu_probe is not None:
+        relu_probe.append(out.detach())
     act = torch.relu(out) if relu_mask is None else out * relu_mask.to(out.dtype)
     return linear(act, p("out_projection.weight"), p("out_projection.bias"))               # ReLU *before* out-proj
 

@@ -225,9 +225,15 @@ def test_reprogramming_layer_vs_oracle(golden, tag, B, S, d_llm, p_drop):
         v.requires_grad_(True)
     to, so = tgt.clone().requires_grad_(), src.clone().requires_grad_()
     # the oracle takes the ReLU (HOP.py:284) on the side the device path took: B*34*1024 pre-activations always hold a
-    # few values within rounding of zero, and a flipped one moves dtarget by percents
+    # few values within rounding of zero, and a flipped one moves dtarget by percents.  Unaided check of the sides the
+    # device took: they may differ from the sign of the oracle's own pre-activation only at the kink.
+    probe = []
     want = ref_cpu.reprogramming_layer(sd, to, so, so, 8, prefix="", drop_mask=mask, p_drop=p_drop,
-                                       relu_mask=relu_in[0].reshape(B, 34, -1))
+                                       relu_mask=relu_in[0].reshape(B, 34, -1), relu_probe=probe)
+    differ = relu_in[0].reshape(B, 34, -1).bool() != (probe[0] > 0)
+    if differ.any():
+        assert probe[0][differ].abs().max().item() <= 1e-4 * probe[0].abs().max().item(), "ReLU: wrong side away from the kink"
+    assert differ.float().mean().item() <= 1e-3, f"ReLU: {int(differ.sum())} sides differ"
     (want * gout).sum().backward()
     assert_close(out, want, what="out")
     if rel_err(tg.grad, to.grad) > RTOL:            # diagnostic: how many query rows carry the error?
@@ -317,7 +323,9 @@ def test_gwnet_training_vs_oracle_ragged_and_full_size(V, B, monkeypatch):
     sizes (V=9 B=128, V=42 B=64) -- output, input gradient, every parameter gradient, BatchNorm running statistics.
     The two ReLUs behind the skip sum have ~1e6 pre-activations at these sizes, a few of them within rounding of zero;
     the oracle is therefore evaluated with the ReLU masks the device path actually took (captured here), which makes
-    the gradient comparison independent of which side of the kink either implementation rounds to."""
+    the gradient comparison independent of which side of the kink either implementation rounds to.  That the device took
+    the right sides is checked unaided: its masks may differ from the sign of the oracle's own pre-activations only
+    where that pre-activation is within rounding of zero (a wrong-side ReLU anywhere else fails here)."""
     import sys
     import hopmi
     from oracle import fill, ref_cpu, spec
@@ -349,7 +357,13 @@ def test_gwnet_training_vs_oracle_ragged_and_full_size(V, B, monkeypatch):
         if v.is_floating_point():
             v.requires_grad_(True)
     xo = x0.clone().requires_grad_()
-    want, upd = ref_cpu.gwnet_forward(sd, xo, prefix="", training=True, relu_masks=relu_masks)
+    probe = []
+    want, upd = ref_cpu.gwnet_forward(sd, xo, prefix="", training=True, relu_masks=relu_masks, relu_probe=probe)
+    for which, (mk, pre) in enumerate(zip(relu_masks, probe)):
+        differ = mk.bool() != (pre > 0)
+        if differ.any():
+            assert pre[differ].abs().max().item() <= 1e-4 * pre.abs().max().item(), f"relu {which}: wrong side away from the kink"
+        assert differ.float().mean().item() <= 1e-3, f"relu {which}: {int(differ.sum())} sides differ"
     (want * gout).sum().backward()
     assert_close(out, want, what="out")
     assert_close(xg.grad, xo.grad, what="dx0")
