@@ -171,7 +171,24 @@ class GraphedTrainStep:
             self._bg = torch.zeros_like(m.mapping_layer.bias)
         for opt in (self.g_opt, self.d_opt):
             _make_capturable(opt)
+        # what a replay writes in place: the optimizers' parameters and the modules' buffers (BatchNorm statistics)
+        seen, written = set(), []
+        for t in [p for opt in (self.g_opt, self.d_opt) for g in opt.param_groups for p in g["params"]] + \
+                 list(m.buffers()) + list(self.disc.buffers()):
+            if id(t) not in seen:
+                seen.add(id(t))
+                written.append(t)
+        self._written = tuple(written)
         self._built = True
+
+    def _mark_written(self):
+        """A replay updates parameters and buffers on the device behind torch's back: advance their version counters as
+        the in-place updates of the eager step do, so that everything keyed on them (the no-grad forward's K/V prototype
+        cache, Model._kv_infer; autograd's saved-tensor checks) sees a modified tensor."""
+        bump = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+        if bump is not None:
+            bump(self._written, tuple(t._version + 1 for t in self._written))
+        self.model._kv_infer = None
 
     # -- the three places where a recording differs from the eager step -------------------------------------------
     def _prototype_segment(self, cap, amp):
@@ -279,6 +296,7 @@ class GraphedTrainStep:
                 x.replay()
             else:
                 x()
+        self._mark_written()
         self._event.synchronize()
         return _steps._LossFetch.decode(rec["terms"], self._host[:rec["n_vals"]].tolist(), True)
 

@@ -110,6 +110,41 @@ def test_graphed_step_new_batches_and_other_shapes(monkeypatch):
     assert len(graphed.records) == 1
 
 
+def test_inference_between_graphed_steps_sees_the_trained_weights(monkeypatch):
+    """A no-grad forward keeps its K/V prototypes across calls until a weight changes (Model._kv_infer, keyed on the
+    parameters' version counters).  Replays of the recorded step update the weights on the device without touching those
+    counters: an evaluation between replays must still see the current weights (= the same forward with the cache
+    dropped), not the prototypes of the evaluation before."""
+    import hopmi
+    from oracle.golden_util import step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m, d, inp = _pair(9, dev)
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-2, betas=(0.5, 0.999))
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    batch = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"], inp["vid_indices"])
+    graphed = hopmi.GraphedTrainStep(step_args(9), m, d, g_opt, d_opt, eager_calls=1)
+
+    def evaluate():
+        m.eval()
+        with torch.no_grad():
+            out = m(inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"][:, 0:16], inp["vid_indices"])
+        m.train()
+        return (out[0] if isinstance(out, (tuple, list)) else out).clone()
+
+    graphed(0, *batch)                                 # eager call
+    graphed(0, *batch)                                 # capture + first replay
+    before = evaluate()                                # fills the prototype cache
+    for _ in range(3):
+        graphed(0, *batch)                             # replays only
+    assert graphed.n_replay >= 4
+    after = evaluate()
+    m._kv_infer = None
+    fresh = evaluate()
+    assert torch.equal(after, fresh)
+    assert not torch.equal(after, before)
+
+
 def test_seed_word_advances_dropout_masks():
     """The seeded kernels add *ops.SEED_DEV to their seed: same word -> same mask, another word -> another mask, and the
     backward regenerates the forward's mask (gradient of sum(o) w.r.t. v counts the kept keys)."""
