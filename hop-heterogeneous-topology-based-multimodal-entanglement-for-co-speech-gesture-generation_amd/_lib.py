@@ -36,9 +36,11 @@ SIGNATURES = {
     "hopmi_hop_losses_bwd": (_I, [_VP] * 7 + [_I] * 3 + [ctypes.c_float] * 2 + [_VP] * 4),
     "hopmi_reprog_attn_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_reprog_attn_fwd": (_I, [_VP] * 6 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
+    "hopmi_reprog_attn_fwd_dt": (_I, [_VP] * 4 + [_I] + [_VP] * 2 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_reprog_attn_bwd_splits": (_I, []),
     "hopmi_reprog_attn_bwd_ws_bytes": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "hopmi_reprog_attn_bwd": (_I, [_VP] * 10 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
+    "hopmi_reprog_attn_bwd_dt": (_I, [_VP] * 4 + [_I] + [_VP] * 6 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_time_next_launch": (_I, [_VP, _VP]),
     "hopmi_noop_launch": (_I, [_VP]),
     "hopmi_bert_attn_fwd": (_I, [_VP] * 2 + [_I] * 3 + [ctypes.c_float, ctypes.c_uint, _VP, _VP]),

@@ -14,8 +14,14 @@
 // and transposed rows, hi + lo), so that staging a 32-key chunk is a set of plain 16-byte copies global -> registers -> LDS.
 // Linear workgroup id = tile*H + head, so with H = 8 every head lives on one XCD and its images stay in that XCD's L2
 // (speed only).  Dropout uses a stateless hash of (seed, row, head, key pair) so the backward can regenerate the mask.
+//
+// Storage type TIO of q / k / v / o / dO / dq (the `_dt` entry points): fp32, or bf16 as the tensors leave and enter the
+// bf16 GEMMs around the operator under autocast (no cast launches; loads widened, stores rounded, arithmetic unchanged).
+// A bf16 operand has no lo part, so the terms that would multiply it are not issued (mfma_split<A_LO, B_LO>): the scaled Q,
+// P and dS keep theirs.
 #include "attn_dev.h"
 #include "bf16_dev.h"
+#include "io_dev.h"
 
 namespace hopmi {
 
@@ -32,7 +38,8 @@ constexpr int KVK = 64;            // dK/dV kernel: keys per workgroup (16 per w
 // ------------------------------------------------------------------------------------------------------
 typedef unsigned short u16;
 
-__global__ __launch_bounds__(256) void attn_images_kernel(const float* __restrict__ X, int S, int Sp, int H, float mul,
+template <typename TIO>
+__global__ __launch_bounds__(256) void attn_images_kernel(const TIO* __restrict__ X, int S, int Sp, int H, float mul,
                                                           u16* __restrict__ nat, u16* __restrict__ tr) {
   __shared__ u16 th[2][32][AE + 2];                                  // [part][key][e] (+2: odd 4-byte stride for the column reads)
   const int tid = threadIdx.x, h = blockIdx.x % H, key0 = (blockIdx.x / H) * 32;
@@ -40,9 +47,9 @@ __global__ __launch_bounds__(256) void attn_images_kernel(const float* __restric
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int u = tid + 256 * it, k = u >> 5, c4 = u & 31;            // key row, float4 column
-    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-    if (key0 + k < S) x = *reinterpret_cast<const f32x4*>(X + (size_t)(key0 + k) * rs + (size_t)h * AE + 4 * c4);
-    const Split4 sp = split4(x[0] * mul, x[1] * mul, x[2] * mul, x[3] * mul);
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (key0 + k < S) x = ld4(X + (size_t)(key0 + k) * rs + (size_t)h * AE + 4 * c4);
+    const Split4 sp = split4(x.x * mul, x.y * mul, x.z * mul, x.w * mul);
     if (nat != nullptr) {
       *reinterpret_cast<u32x2*>(nat + ((size_t)(h * 2 + 0) * Sp + key0 + k) * AE + 4 * c4) = sp.hi;
       *reinterpret_cast<u32x2*>(nat + ((size_t)(h * 2 + 1) * Sp + key0 + k) * AE + 4 * c4) = sp.lo;
@@ -75,11 +82,13 @@ __device__ __forceinline__ int swz64(int row) { return (0x1230 >> (4 * ((row >> 
 // Score tile nt, column j is key 2 j + nt of the chunk (K rows are permuted in LDS accordingly), so a lane's two scores of
 // a row are adjacent keys: one packed 32-bit store per part.
 // 40 KB of LDS, <= 168 registers => 3 workgroups per CU: all 544 workgroups of the B = 128 shape are resident at once.
-__global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __restrict__ Q, const u16* __restrict__ Knat,
-                                                              const u16* __restrict__ Vtr, float* __restrict__ O,
+template <typename TIO>
+__global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const TIO* __restrict__ Q, const u16* __restrict__ Knat,
+                                                              const u16* __restrict__ Vtr, TIO* __restrict__ O,
                                                               float* __restrict__ lse, int N, int S, int Sp, int H, float scale,
                                                               unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
+  constexpr bool IN_LO = sizeof(TIO) == 4;        // fp32 inputs have a lo part, bf16 inputs do not
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Kl_ = lds;                        // [2 parts][32 rows][256 B]
   unsigned char* Vl_ = lds + 2 * 32 * 256;         // [2 parts][128 rows][64 B]
@@ -91,12 +100,12 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
 
   u32x4 qh[4], ql[4];                                               // A[i = row][k = e = 32 ks + 8 q + x], pre-scaled
   {
-    const f32x4* qp = reinterpret_cast<const f32x4*>(Q + (size_t)min(row_a, N - 1) * rs + (size_t)h * AE + 8 * q);
+    const TIO* qp = Q + (size_t)min(row_a, N - 1) * rs + (size_t)h * AE + 8 * q;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 a = qp[8 * ks], b = qp[8 * ks + 1];
-      const Split8 f = split8(make_float4(a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale),
-                              make_float4(b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale));
+      const float4 a = ld4(qp + 32 * ks), b = ld4(qp + 32 * ks + 4);
+      const Split8 f = split8(make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale),
+                              make_float4(b.x * scale, b.y * scale, b.z * scale, b.w * scale));
       qh[ks] = f.hi; ql[ks] = f.lo;
     }
   }
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
         const int off = (16 * nt + j) * 256 + (((4 * ks + q) ^ j) << 4);
         const u32x4 kh = *reinterpret_cast<const u32x4*>(Kl_ + off);
         const u32x4 kl = *reinterpret_cast<const u32x4*>(Kl_ + 32 * 256 + off);
-        acc_s[nt] = mfma_split3(qh[ks], ql[ks], kh, kl, acc_s[nt]);
+        acc_s[nt] = mfma_split<true, IN_LO>(qh[ks], ql[ks], kh, kl, acc_s[nt]);
       }
     // ---- online softmax over this chunk (lane holds rows 4q + r, keys 2j + nt) ------------------------
     const int key0 = c * 32 + 2 * j;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
         const int voff = (16 * nt + j) * 64 + ((q ^ swz64(j)) << 4);
         const u32x4 vh = *reinterpret_cast<const u32x4*>(Vl_ + voff);
         const u32x4 vl = *reinterpret_cast<const u32x4*>(Vl_ + 128 * 64 + voff);
-        acc_o[nt] = mfma_split3(ph, pl, vh, vl, acc_o[nt]);
+        acc_o[nt] = mfma_split<true, IN_LO>(ph, pl, vh, vl, acc_o[nt]);
       }
     }
   }
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
     if (row < N) {
       const float inv = 1.f / l_row;
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) O[(size_t)row * rs + (size_t)h * AE + 16 * nt + j] = acc_o[nt][r] * inv;
+      for (int nt = 0; nt < 8; ++nt) st1(O + (size_t)row * rs + (size_t)h * AE + 16 * nt + j, acc_o[nt][r] * inv);
       if (j == 0) lse[(size_t)row * H + h] = m_run[r] + __logf(l_row);
     }
   }
@@ -239,13 +248,15 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_fwd_kernel(const float* __
 // dQ kernel, per 32-key chunk: K image rows, V image rows (both 256 B, key-permuted as in the forward) and K^T image rows
 // (64 B) in LDS (48 KB => 3 workgroups per CU); S and dP = 48 MFMAs; dS -> the wave's packed tile, which reuses the V
 // region (one extra barrier per chunk); dQ += 24 MFMAs.
-__global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float* __restrict__ Q, const u16* __restrict__ Knat,
+template <typename TIO>
+__global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const TIO* __restrict__ Q, const u16* __restrict__ Knat,
                                                                  const u16* __restrict__ Vnat, const u16* __restrict__ Ktr,
-                                                                 const float* __restrict__ dO, const float* __restrict__ lse,
-                                                                 const float* __restrict__ delta, float* __restrict__ dQ, int N,
+                                                                 const TIO* __restrict__ dO, const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta, TIO* __restrict__ dQ, int N,
                                                                  int S, int Sp, int H, float scale, unsigned drop_thresh,
                                                                  float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
+  constexpr bool IN_LO = sizeof(TIO) == 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Kl_ = lds;                        // [2 parts][32 rows][256 B]
   unsigned char* Vl_ = lds + 2 * 32 * 256;         // [2 parts][32 rows][256 B]; then [4 waves][2 parts][16][64 B] dS tiles
@@ -257,16 +268,15 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
 
   u32x4 qh[4], ql[4], dh[4], dl[4];
   {
-    const f32x4* qp = reinterpret_cast<const f32x4*>(Q + (size_t)row_a * rs + (size_t)h * AE + 8 * q);
-    const f32x4* dp = reinterpret_cast<const f32x4*>(dO + (size_t)row_a * rs + (size_t)h * AE + 8 * q);
+    const TIO* qp = Q + (size_t)row_a * rs + (size_t)h * AE + 8 * q;
+    const TIO* dp = dO + (size_t)row_a * rs + (size_t)h * AE + 8 * q;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 a = qp[8 * ks], b = qp[8 * ks + 1];
-      const Split8 f = split8(make_float4(a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale),
-                              make_float4(b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale));
+      const float4 a = ld4(qp + 32 * ks), b = ld4(qp + 32 * ks + 4);
+      const Split8 f = split8(make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale),
+                              make_float4(b.x * scale, b.y * scale, b.z * scale, b.w * scale));
       qh[ks] = f.hi; ql[ks] = f.lo;
-      const f32x4 c = dp[8 * ks], d = dp[8 * ks + 1];
-      const Split8 g = split8(make_float4(c[0], c[1], c[2], c[3]), make_float4(d[0], d[1], d[2], d[3]));
+      const Split8 g = split8(ld4(dp + 32 * ks), ld4(dp + 32 * ks + 4));
       dh[ks] = g.hi; dl[ks] = g.lo;
     }
   }
@@ -336,10 +346,10 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
         const int off = (16 * nt + j) * 256 + (((4 * ks + q) ^ j) << 4);
         const u32x4 kh = *reinterpret_cast<const u32x4*>(Kl_ + off);
         const u32x4 kl = *reinterpret_cast<const u32x4*>(Kl_ + 32 * 256 + off);
-        acc_s[nt] = mfma_split3(qh[ks], ql[ks], kh, kl, acc_s[nt]);
+        acc_s[nt] = mfma_split<true, IN_LO>(qh[ks], ql[ks], kh, kl, acc_s[nt]);
         const u32x4 vh = *reinterpret_cast<const u32x4*>(Vl_ + off);
         const u32x4 vl = *reinterpret_cast<const u32x4*>(Vl_ + 32 * 256 + off);
-        acc_dp[nt] = mfma_split3(dh[ks], dl[ks], vh, vl, acc_dp[nt]);
+        acc_dp[nt] = mfma_split<IN_LO, IN_LO>(dh[ks], dl[ks], vh, vl, acc_dp[nt]);
       }
 #pragma unroll
     for (int part = 0; part < 2; ++part)
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
         const int toff = (16 * nt + j) * 64 + ((q ^ swz64(j)) << 4);
         const u32x4 th = *reinterpret_cast<const u32x4*>(Tl_ + toff);
         const u32x4 tl = *reinterpret_cast<const u32x4*>(Tl_ + 128 * 64 + toff);
-        acc_dq[nt] = mfma_split3(ph, pl, th, tl, acc_dq[nt]);
+        acc_dq[nt] = mfma_split<true, IN_LO>(ph, pl, th, tl, acc_dq[nt]);
       }
     }
   }
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
     const int row = tile * ABM + 16 * w + 4 * q + r;
     if (row < N) {
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) dQ[(size_t)row * rs + (size_t)h * AE + 16 * nt + j] = acc_dq[nt][r];
+      for (int nt = 0; nt < 8; ++nt) st1(dQ + (size_t)row * rs + (size_t)h * AE + 16 * nt + j, acc_dq[nt][r]);
     }
   }
 }
@@ -395,7 +405,8 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const float*
 // staged from the Q / dO images: natural rows for S^T = K Q^T and dP^T = V dO^T, transposed rows for dV += (P o M)^T dO
 // and dK += dS^T Q.  The partial dK / dV go to slab `split` of dKp / dVp ([nsplit][S][H][E]); the caller adds the slabs
 // in a fixed order.  80 KB of LDS => 2 workgroups per CU.
-__global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const float* __restrict__ K, const float* __restrict__ Vv,
+template <typename TIO>
+__global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const TIO* __restrict__ K, const TIO* __restrict__ Vv,
                                                                   const u16* __restrict__ Qnat, const u16* __restrict__ Qtr,
                                                                   const u16* __restrict__ Dnat, const u16* __restrict__ Dtr,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const float
                                                                   int S, int H, int nsplit, unsigned drop_thresh,
                                                                   float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
+  constexpr bool IN_LO = sizeof(TIO) == 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Ql_ = lds;                        // [2 parts][32 rows][256 B]   (scaled) Q rows
   unsigned char* Dl_ = Ql_ + 2 * 32 * 256;         //                            dO rows
@@ -417,15 +429,13 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const float
 
   u32x4 kh[4], kl[4], vh[4], vl[4];
   {
-    const f32x4* kp = reinterpret_cast<const f32x4*>(K + (size_t)key_a * rs + (size_t)h * AE + 8 * q);
-    const f32x4* vp = reinterpret_cast<const f32x4*>(Vv + (size_t)key_a * rs + (size_t)h * AE + 8 * q);
+    const TIO* kp = K + (size_t)key_a * rs + (size_t)h * AE + 8 * q;
+    const TIO* vp = Vv + (size_t)key_a * rs + (size_t)h * AE + 8 * q;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 a = kp[8 * ks], b = kp[8 * ks + 1];
-      const Split8 f = split8(make_float4(a[0], a[1], a[2], a[3]), make_float4(b[0], b[1], b[2], b[3]));
+      const Split8 f = split8(ld4(kp + 32 * ks), ld4(kp + 32 * ks + 4));
       kh[ks] = f.hi; kl[ks] = f.lo;
-      const f32x4 c = vp[8 * ks], d = vp[8 * ks + 1];
-      const Split8 g = split8(make_float4(c[0], c[1], c[2], c[3]), make_float4(d[0], d[1], d[2], d[3]));
+      const Split8 g = split8(ld4(vp + 32 * ks), ld4(vp + 32 * ks + 4));
       vh[ks] = g.hi; vl[ks] = g.lo;
     }
   }
@@ -496,10 +506,10 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const float
         const int off = (16 * nt + j) * 256 + (((4 * ks + q) ^ j) << 4);
         const u32x4 bqh = *reinterpret_cast<const u32x4*>(Ql_ + off);
         const u32x4 bql = *reinterpret_cast<const u32x4*>(Ql_ + 32 * 256 + off);
-        acc_s[nt] = mfma_split3(kh[ks], kl[ks], bqh, bql, acc_s[nt]);
+        acc_s[nt] = mfma_split<IN_LO, true>(kh[ks], kl[ks], bqh, bql, acc_s[nt]);
         const u32x4 bdh = *reinterpret_cast<const u32x4*>(Dl_ + off);
         const u32x4 bdl = *reinterpret_cast<const u32x4*>(Dl_ + 32 * 256 + off);
-        acc_dp[nt] = mfma_split3(vh[ks], vl[ks], bdh, bdl, acc_dp[nt]);
+        acc_dp[nt] = mfma_split<IN_LO, IN_LO>(vh[ks], vl[ks], bdh, bdl, acc_dp[nt]);
       }
     unsigned xk[2][2];                                              // [row nt][key pair]: keys key_c0 + 0/1 and key_c0 + 2/3
 #pragma unroll
@@ -541,10 +551,10 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const float
         const int toff = (16 * nt + j) * 64 + ((q ^ swz64(j)) << 4);
         const u32x4 dth = *reinterpret_cast<const u32x4*>(DT_ + toff);
         const u32x4 dtl = *reinterpret_cast<const u32x4*>(DT_ + 128 * 64 + toff);
-        acc_dv[nt] = mfma_split3(ph, pl, dth, dtl, acc_dv[nt]);
+        acc_dv[nt] = mfma_split<true, IN_LO>(ph, pl, dth, dtl, acc_dv[nt]);
         const u32x4 qth = *reinterpret_cast<const u32x4*>(QT_ + toff);
         const u32x4 qtl = *reinterpret_cast<const u32x4*>(QT_ + 128 * 64 + toff);
-        acc_dk[nt] = mfma_split3(sh, sl, qth, qtl, acc_dk[nt]);
+        acc_dk[nt] = mfma_split<true, true>(sh, sl, qth, qtl, acc_dk[nt]);
       }
     }
   }
@@ -574,29 +584,50 @@ extern "C" size_t hopmi_reprog_attn_ws_bytes(int S, int H, int E) {
   return (size_t)4 * 2 * H * attn_sp(S) * AE * sizeof(u16);
 }
 
-extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, void* ws,
-                                     int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
-  if (!q || !k || !v || !o || !lse || !ws) { set_error("hopmi_reprog_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
+static int attn_args_ok(const char* what, int N, int S, int H, int E, float p_drop, int dtype) {
   if (E != AE || N <= 0 || S <= 0 || H <= 0) {
-    set_error("hopmi_reprog_attn_fwd: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", N, S, H, E);
+    set_error("%s: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", what, N, S, H, E);
     return HOPMI_EINVAL;
   }
-  if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_reprog_attn_fwd: p_drop=%f outside [0,1)", p_drop); return HOPMI_EINVAL; }
+  if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("%s: p_drop=%f outside [0,1)", what, p_drop); return HOPMI_EINVAL; }
+  if (dtype != HOPMI_F32 && dtype != HOPMI_BF16) { set_error("%s: dtype %d (0 = fp32, 1 = bf16)", what, dtype); return HOPMI_EINVAL; }
+  return HOPMI_OK;
+}
+
+template <typename TIO>
+static int launch_reprog_attn_fwd(const void* q_, const void* k_, const void* v_, void* o_, float* lse, void* ws, int N, int S, int H,
+                                  float scale, float p_drop, unsigned seed, const unsigned* seed_dev, hipStream_t st) {
+  const TIO *q = static_cast<const TIO*>(q_), *k = static_cast<const TIO*>(k_), *v = static_cast<const TIO*>(v_);
+  TIO* o = static_cast<TIO*>(o_);
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 65536.0) : 0u;   // 16-bit keep fields (attn_hash_pair)
   const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const int Sp = attn_sp(S);
   const size_t img = (size_t)2 * H * Sp * AE;                       // elements per image
   u16* knat = static_cast<u16*>(ws);
   u16* vtr = knat + 3 * img;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(attn_images_kernel, dim3((Sp / 32) * H), dim3(256), 0, st, k, S, Sp, H, 1.f, knat, (u16*)nullptr);
-  hipLaunchKernelGGL(attn_images_kernel, dim3((Sp / 32) * H), dim3(256), 0, st, v, S, Sp, H, 1.f, (u16*)nullptr, vtr);
+  hipLaunchKernelGGL(attn_images_kernel<TIO>, dim3((Sp / 32) * H), dim3(256), 0, st, k, S, Sp, H, 1.f, knat, (u16*)nullptr);
+  hipLaunchKernelGGL(attn_images_kernel<TIO>, dim3((Sp / 32) * H), dim3(256), 0, st, v, S, Sp, H, 1.f, (u16*)nullptr, vtr);
   if (int e = check_launch("hopmi_reprog_attn_fwd(images)")) return e;
   const int ntile = (N + ABM - 1) / ABM;
   const size_t lds = (size_t)2 * 32 * 256 + 2 * 128 * 64 + 4 * 2 * 16 * 64;
-  hipLaunchKernelGGL(reprog_attn_fwd_kernel, dim3(ntile * H), dim3(256), lds, st, q, knat, vtr, o, lse, N, S, Sp, H, scale,
+  hipLaunchKernelGGL(reprog_attn_fwd_kernel<TIO>, dim3(ntile * H), dim3(256), lds, st, q, knat, vtr, o, lse, N, S, Sp, H, scale,
                      thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_reprog_attn_fwd");
+}
+
+extern "C" int hopmi_reprog_attn_fwd_dt(const void* q, const void* k, const void* v, void* o, int dtype, float* lse, void* ws,
+                                        int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                        void* stream) {
+  if (!q || !k || !v || !o || !lse || !ws) { set_error("hopmi_reprog_attn_fwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (int e = attn_args_ok("hopmi_reprog_attn_fwd", N, S, H, E, p_drop, dtype)) return e;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == HOPMI_BF16 ? launch_reprog_attn_fwd<__bf16>(q, k, v, o, lse, ws, N, S, H, scale, p_drop, seed, seed_dev, st)
+                             : launch_reprog_attn_fwd<float>(q, k, v, o, lse, ws, N, S, H, scale, p_drop, seed, seed_dev, st);
+}
+
+extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, void* ws,
+                                     int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+  return hopmi_reprog_attn_fwd_dt(q, k, v, o, HOPMI_F32, lse, ws, N, S, H, E, scale, p_drop, seed, seed_dev, stream);
 }
 
 // dK/dV grid = 24 key chunks x 8 heads x splits workgroups at 2 resident per CU (512 slots): 8 splits make
@@ -609,18 +640,15 @@ extern "C" size_t hopmi_reprog_attn_bwd_ws_bytes(int N, int S, int H, int E) {
   return hopmi_reprog_attn_ws_bytes(S, H, E) + (size_t)4 * 2 * H * attn_np(N) * AE * sizeof(u16);
 }
 
-extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
-                                     const float* delta, float* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
-                                     float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
-  if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv || !ws) { set_error("hopmi_reprog_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
-  if (E != AE || N <= 0 || S <= 0 || H <= 0) {
-    set_error("hopmi_reprog_attn_bwd: need head dim 128 and positive sizes (N=%d S=%d H=%d E=%d)", N, S, H, E);
-    return HOPMI_EINVAL;
-  }
-  if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_reprog_attn_bwd: p_drop=%f outside [0,1)", p_drop); return HOPMI_EINVAL; }
+template <typename TIO>
+static int launch_reprog_attn_bwd(const void* q_, const void* k_, const void* v_, const void* d_o_, const float* lse, const float* delta,
+                                  void* dq_, float* dk, float* dv, void* ws, int N, int S, int H, float scale, float p_drop,
+                                  unsigned seed, const unsigned* seed_dev, hipStream_t st) {
+  const TIO *q = static_cast<const TIO*>(q_), *k = static_cast<const TIO*>(k_), *v = static_cast<const TIO*>(v_);
+  const TIO* d_o = static_cast<const TIO*>(d_o_);
+  TIO* dq = static_cast<TIO*>(dq_);
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 65536.0) : 0u;   // 16-bit keep fields (attn_hash_pair)
   const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const int Sp = attn_sp(S), Np = attn_np(N);
   const size_t kimg = (size_t)2 * H * Sp * AE, qimg = (size_t)2 * H * Np * AE;
   u16* knat = static_cast<u16*>(ws);
@@ -630,18 +658,35 @@ extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float
   u16* qtr = qnat + qimg;
   u16* dnat = qtr + qimg;
   u16* dtr = dnat + qimg;
-  hipLaunchKernelGGL(attn_images_kernel, dim3((Sp / 32) * H), dim3(256), 0, st, k, S, Sp, H, 1.f, knat, ktr);
-  hipLaunchKernelGGL(attn_images_kernel, dim3((Sp / 32) * H), dim3(256), 0, st, v, S, Sp, H, 1.f, vnat, (u16*)nullptr);
-  hipLaunchKernelGGL(attn_images_kernel, dim3((Np / 32) * H), dim3(256), 0, st, q, N, Np, H, scale, qnat, qtr);
-  hipLaunchKernelGGL(attn_images_kernel, dim3((Np / 32) * H), dim3(256), 0, st, d_o, N, Np, H, 1.f, dnat, dtr);
+  hipLaunchKernelGGL(attn_images_kernel<TIO>, dim3((Sp / 32) * H), dim3(256), 0, st, k, S, Sp, H, 1.f, knat, ktr);
+  hipLaunchKernelGGL(attn_images_kernel<TIO>, dim3((Sp / 32) * H), dim3(256), 0, st, v, S, Sp, H, 1.f, vnat, (u16*)nullptr);
+  hipLaunchKernelGGL(attn_images_kernel<TIO>, dim3((Np / 32) * H), dim3(256), 0, st, q, N, Np, H, scale, qnat, qtr);
+  hipLaunchKernelGGL(attn_images_kernel<TIO>, dim3((Np / 32) * H), dim3(256), 0, st, d_o, N, Np, H, 1.f, dnat, dtr);
   if (int e = check_launch("hopmi_reprog_attn_bwd(images)")) return e;
   const size_t lds_q = (size_t)2 * 2 * 32 * 256 + 2 * 128 * 64;
-  hipLaunchKernelGGL(reprog_attn_bwd_dq_kernel, dim3(((N + ABM - 1) / ABM) * H), dim3(256), lds_q, st, q, knat, vnat, ktr, d_o,
+  hipLaunchKernelGGL(reprog_attn_bwd_dq_kernel<TIO>, dim3(((N + ABM - 1) / ABM) * H), dim3(256), lds_q, st, q, knat, vnat, ktr, d_o,
                      lse, delta, dq, N, S, Sp, H, scale, thresh, dscale, seed, seed_dev);
   if (int e = check_launch("hopmi_reprog_attn_bwd(dq)")) return e;
   const int nsplit = hopmi_reprog_attn_bwd_splits();
   const size_t lds_kv = (size_t)2 * 2 * 32 * 256 + 2 * 2 * 128 * 64 + 4 * 2 * 2 * 16 * 64;
-  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel, dim3(((S + KVK - 1) / KVK) * H * nsplit), dim3(256), lds_kv, st, k, v, qnat, qtr,
+  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel<TIO>, dim3(((S + KVK - 1) / KVK) * H * nsplit), dim3(256), lds_kv, st, k, v, qnat, qtr,
                      dnat, dtr, lse, delta, dk, dv, N, Np, S, H, nsplit, thresh, dscale, seed, seed_dev);
   return check_launch("hopmi_reprog_attn_bwd(dkv)");
+}
+
+extern "C" int hopmi_reprog_attn_bwd_dt(const void* q, const void* k, const void* v, const void* d_o, int dtype, const float* lse,
+                                        const float* delta, void* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
+                                        float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+  if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv || !ws) { set_error("hopmi_reprog_attn_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  if (int e = attn_args_ok("hopmi_reprog_attn_bwd", N, S, H, E, p_drop, dtype)) return e;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == HOPMI_BF16
+             ? launch_reprog_attn_bwd<__bf16>(q, k, v, d_o, lse, delta, dq, dk, dv, ws, N, S, H, scale, p_drop, seed, seed_dev, st)
+             : launch_reprog_attn_bwd<float>(q, k, v, d_o, lse, delta, dq, dk, dv, ws, N, S, H, scale, p_drop, seed, seed_dev, st);
+}
+
+extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
+                                     const float* delta, float* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
+                                     float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+  return hopmi_reprog_attn_bwd_dt(q, k, v, d_o, HOPMI_F32, lse, delta, dq, dk, dv, ws, N, S, H, E, scale, p_drop, seed, seed_dev, stream);
 }

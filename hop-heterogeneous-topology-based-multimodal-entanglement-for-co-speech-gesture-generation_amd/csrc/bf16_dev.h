@@ -26,6 +26,15 @@ __device__ __forceinline__ f32x4 mfma_split3(u32x4 a_hi, u32x4 a_lo, u32x4 b_hi,
   return mfma_bf16(a_hi, b_hi, c);
 }
 
+// the same product when a lo part is known to be zero (an operand that was bf16 to begin with): its term is not issued;
+// <true, true> issues mfma_split3's three terms in mfma_split3's order
+template <bool A_LO, bool B_LO>
+__device__ __forceinline__ f32x4 mfma_split(u32x4 a_hi, u32x4 a_lo, u32x4 b_hi, u32x4 b_lo, f32x4 c) {
+  if (A_LO) c = mfma_bf16(a_lo, b_hi, c);
+  if (B_LO) c = mfma_bf16(a_hi, b_lo, c);
+  return mfma_bf16(a_hi, b_hi, c);
+}
+
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even)
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
   const bf2 v = {(__bf16)a, (__bf16)b};

@@ -23,6 +23,9 @@ __device__ __forceinline__ void st4(__bf16* p, float4 v) {
   *reinterpret_cast<u2*>(p) = u2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
 }
 
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+
 constexpr int HOPMI_F32 = 0, HOPMI_BF16 = 1;
 
 }  // namespace hopmi

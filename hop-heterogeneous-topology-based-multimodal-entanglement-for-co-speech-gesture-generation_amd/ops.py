@@ -597,12 +597,16 @@ def bert_attention(qkv: torch.Tensor, p_drop: float = 0.0, seed: int = 0) -> tor
 
 class _ReprogAttnFn(torch.autograd.Function):
     """softmax(q k^T * scale) (dropout) v over the S prototypes without materialising the scores
-    (hopmi_reprog_attn_fwd).  q (B,L,H,E); k, v (S,H,E)."""
+    (hopmi_reprog_attn_fwd_dt / _bwd_dt).  q (B,L,H,E); k, v (S,H,E).  All three bf16 (as they leave the projections under
+    bf16 autocast): read as they are, o and dq leave in bf16 (the `dtype` ABI argument); otherwise fp32."""
 
     @staticmethod
-    @_fwd32
     def forward(ctx, q, k, v, scale, p_drop, seed):
-        q, k, v = _dev_f32(q, "q"), _dev_f32(k, "k"), _dev_f32(v, "v")
+        typed = q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16
+        if typed:
+            q, k, v = _dev_bf16(q, "q"), _dev_bf16(k, "k"), _dev_bf16(v, "v")
+        else:
+            q, k, v = _dev_f32(q.float(), "q"), _dev_f32(k.float(), "k"), _dev_f32(v.float(), "v")
         B, Lq, H, E = q.shape
         S = k.shape[0]
         if k.shape != (S, H, E) or v.shape != (S, H, E):
@@ -611,36 +615,42 @@ class _ReprogAttnFn(torch.autograd.Function):
         lse = torch.empty(B, Lq, H, dtype=torch.float32, device=q.device)
         Lb, st, sp = _lib.lib(), _stream(), _seed_ptr()
         N = B * Lq
+        eb = 2 if typed else 4
         ws = torch.empty(Lb.hopmi_reprog_attn_ws_bytes(S, H, E), dtype=torch.uint8, device=q.device)
-        _lib.check(_timed("reprog_attn_fwd", 4 * (2 * N * H * E + 2 * S * H * E), 4 * N * H * S * E,
-                          lambda: Lb.hopmi_reprog_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
-                                                           lse.data_ptr(), ws.data_ptr(), N, S, H, E, float(scale), float(p_drop),
-                                                           int(seed) & _M32, sp, st)), "hopmi_reprog_attn_fwd")
+        _lib.check(_timed("reprog_attn_fwd", eb * (2 * N * H * E + 2 * S * H * E), 4 * N * H * S * E,
+                          lambda: Lb.hopmi_reprog_attn_fwd_dt(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 1 if typed else 0,
+                                                              lse.data_ptr(), ws.data_ptr(), N, S, H, E, float(scale), float(p_drop),
+                                                              int(seed) & _M32, sp, st)), "hopmi_reprog_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale, ctx.p_drop, ctx.seed, ctx.sp = float(scale), float(p_drop), int(seed) & _M32, sp
+        ctx.scale, ctx.p_drop, ctx.seed, ctx.sp, ctx.typed = float(scale), float(p_drop), int(seed) & _M32, sp, typed
         return o
 
     @staticmethod
-    @_bwd32
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
         B, Lq, H, E = q.shape
         S = k.shape[0]
-        do = _dev_f32(do, "do")
-        delta = (do * o).sum(-1)                                    # (B,L,H): the only reduction left to torch
-        Lb, st = _lib.lib(), _stream()
-        R = Lb.hopmi_reprog_attn_bwd_splits()
-        dq = torch.empty_like(q)
-        dk = torch.empty((R,) + tuple(k.shape), dtype=torch.float32, device=q.device)
-        dv = torch.empty_like(dk)
-        N = B * Lq
-        ws = torch.empty(Lb.hopmi_reprog_attn_bwd_ws_bytes(N, S, H, E), dtype=torch.uint8, device=q.device)
-        _lib.check(_timed("reprog_attn_bwd", 4 * (4 * N * H * E + 4 * S * H * E), 14 * N * H * S * E,
-                          lambda: Lb.hopmi_reprog_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(),
-                                                           lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                                           dv.data_ptr(), ws.data_ptr(), N, S, H, E, ctx.scale, ctx.p_drop, ctx.seed, ctx.sp, st)),
-                   "hopmi_reprog_attn_bwd")
-        return dq, dk.sum(0), dv.sum(0), None, None, None
+        with torch.autocast("cuda", enabled=False):
+            do = _dev_bf16(do.to(torch.bfloat16), "do") if ctx.typed else _dev_f32(do.float(), "do")
+            delta = (do.float() * o.float()).sum(-1)                    # (B,L,H): the only reduction left to torch
+            Lb, st = _lib.lib(), _stream()
+            R = Lb.hopmi_reprog_attn_bwd_splits()
+            dq = torch.empty_like(q)
+            dk = torch.empty((R,) + tuple(k.shape), dtype=torch.float32, device=q.device)
+            dv = torch.empty_like(dk)
+            N = B * Lq
+            eb = 2 if ctx.typed else 4
+            ws = torch.empty(Lb.hopmi_reprog_attn_bwd_ws_bytes(N, S, H, E), dtype=torch.uint8, device=q.device)
+            _lib.check(_timed("reprog_attn_bwd", eb * (4 * N * H * E + 2 * S * H * E) + 8 * S * H * E, 14 * N * H * S * E,
+                              lambda: Lb.hopmi_reprog_attn_bwd_dt(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(),
+                                                                  1 if ctx.typed else 0, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
+                                                                  dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), N, S, H, E, ctx.scale,
+                                                                  ctx.p_drop, ctx.seed, ctx.sp, st)),
+                       "hopmi_reprog_attn_bwd")
+            dk, dv = dk.sum(0), dv.sum(0)
+            if ctx.typed:
+                dk, dv = dk.to(torch.bfloat16), dv.to(torch.bfloat16)
+        return dq, dk, dv, None, None, None
 
 
 class _HopLossesFn(torch.autograd.Function):

@@ -167,6 +167,13 @@ size_t hopmi_reprog_attn_ws_bytes(int S, int H, int E);
 int hopmi_reprog_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, void* ws,
                           int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
+/* The same with the storage type of q, k, v and o as an argument (dtype 0 = fp32, 1 = bf16; lse stays fp32): under bf16
+ * autocast (BASELINE.json configs 2, 4) the tensors are read as they leave the projection GEMMs and o is written as the
+ * output projection reads it -- no cast launches.  A bf16 operand has no lo part: its terms are not issued (two MFMA
+ * terms per product instead of three; the scaled q and the probabilities keep their lo parts). */
+int hopmi_reprog_attn_fwd_dt(const void* q, const void* k, const void* v, void* o, int dtype, float* lse, void* ws,
+                             int N, int S, int H, int E, float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
+
 /* Backward of the above: d_o [N][H][E] -> dq [N][H][E] and PARTIAL dk, dv [R][S][H][E] with
  * R = hopmi_reprog_attn_bwd_splits() (the query rows are split R ways over workgroups; the caller adds the
  * R slabs in order).  delta [N][H] = sum_e d_o * o (one small reduction by the caller).  ws:
@@ -178,6 +185,11 @@ size_t hopmi_reprog_attn_bwd_ws_bytes(int N, int S, int H, int E);
 int hopmi_reprog_attn_bwd(const float* q, const float* k, const float* v, const float* d_o, const float* lse,
                           const float* delta, float* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
                           float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
+
+/* ... with the storage type of q, k, v, d_o and dq as an argument (dk, dv partial slabs, lse and delta stay fp32). */
+int hopmi_reprog_attn_bwd_dt(const void* q, const void* k, const void* v, const void* d_o, int dtype, const float* lse,
+                             const float* delta, void* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
+                             float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* ---- self-attention of the frozen BERT encoder (HOP.py:204 -> transformers BertSelfAttention.forward; replaces
  *      the transpose_for_scores copies + the library scaled-dot-product attention + the output re-layout) ----

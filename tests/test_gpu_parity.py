@@ -252,6 +252,34 @@ def test_reprogramming_layer_vs_oracle(golden, tag, B, S, d_llm, p_drop):
         assert_close(out, golden(f"reprog_{tag}")["out"], what="out vs reference")
 
 
+@pytest.mark.parametrize("B,S,p_drop", [(3, 50, 0.0), (5, 1500, 0.1), (128, 1500, 0.1)])
+def test_reprog_attention_bf16_storage_vs_fp32_storage(B, S, p_drop):
+    """`dtype = 1` of hopmi_reprog_attn_fwd_dt / _bwd_dt (q, k, v, o, d_o, dq in bf16 as they sit between the bf16 GEMMs of
+    configs[2], [4]) against the fp32 entry on the same (bf16-representable) values.  The only arithmetic difference is
+    that the MFMA terms of the operands' all-zero lo parts are not issued, so the forward must equal the fp32 result
+    rounded to bf16 BIT FOR BIT; the backward reads the rounded o (delta = sum d_o o), so its gradients agree to bf16
+    rounding of the outputs (2^-9 of the largest element, bar 4e-3)."""
+    from hopmi import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randn(B, 34, 8, 128, generator=gen).bfloat16()
+    k = (0.5 * torch.randn(S, 8, 128, generator=gen)).bfloat16()
+    v = torch.randn(S, 8, 128, generator=gen).bfloat16()
+    g = torch.randn(B, 34, 8, 128, generator=gen).bfloat16()
+    scale, seed = 1.0 / 128 ** 0.5, 1234
+    res = {}
+    for name, cast in (("bf16", lambda t: t), ("f32", lambda t: t.float())):
+        qq, kk, vv = (cast(t).to(dev).requires_grad_() for t in (q, k, v))
+        o = ops.reprog_attention(qq, kk, vv, scale, p_drop, seed)
+        assert o.dtype == qq.dtype
+        (o.float() * g.to(dev).float()).sum().backward()
+        assert qq.grad.dtype == qq.dtype and kk.grad.dtype == kk.dtype
+        res[name] = (o.detach(), qq.grad, kk.grad, vv.grad)
+    assert torch.equal(res["bf16"][0], res["f32"][0].bfloat16())
+    for i, what in ((1, "dq"), (2, "dk"), (3, "dv")):
+        assert_close(res["bf16"][i].float(), res["f32"][i], 4e-3, what)
+
+
 # ------------------------------------------------------------------------------------ GRU kernels
 @pytest.mark.parametrize("persistent", ["1", "0"])
 @pytest.mark.parametrize("B,T,I,H,L", [(3, 5, 7, 6, 2), (37, 34, 20, 350, 2), (5, 28, 8, 64, 4), (130, 9, 12, 18, 1),
