@@ -34,6 +34,8 @@ SIGNATURES = {
     "hopmi_hop_losses_ws_floats": (ctypes.c_size_t, [_I]),
     "hopmi_hop_losses_fwd": (_I, [_VP] * 7 + [_I] * 3 + [ctypes.c_float] * 3 + [_VP] * 3),
     "hopmi_hop_losses_bwd": (_I, [_VP] * 7 + [_I] * 3 + [ctypes.c_float] * 2 + [_VP] * 4),
+    "hopmi_colsum_ws_floats": (ctypes.c_size_t, [_I, _I]),
+    "hopmi_colsum": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hopmi_reprog_attn_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_reprog_attn_fwd": (_I, [_VP] * 6 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_reprog_attn_fwd_dt": (_I, [_VP] * 4 + [_I] + [_VP] * 2 + [_I] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_uint, _VP, _VP]),

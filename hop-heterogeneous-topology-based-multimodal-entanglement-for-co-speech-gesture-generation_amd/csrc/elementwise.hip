@@ -177,6 +177,60 @@ static int ew_check(int M, int N, const char* what) {
   return HOPMI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Column sums of a row-major [M][N] matrix: the bias gradient db = sum over rows of dY of every trainable linear layer
+// (torch.nn.functional.linear's backward; the library's generic reduction runs these at ~1.3 TB/s: 28 us for the
+// 4352 x 2100 fp32 gradients of the GRU input projections, 25-32 of them per step).  Workgroup = 128 rows x 32 VEC columns:
+// 32 column lanes x 8 row lanes, every thread's 16 row loads are independent (all in flight), the 8 row lanes are added in
+// LDS in a fixed order, the row chunks by a second small launch in a fixed order -- bitwise reproducible.
+constexpr int CS_ROWS = 128;
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int M, int N, float* __restrict__ part) {
+  __shared__ float red[8][32 * VEC];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + tx) * VEC;
+  const int r0 = blockIdx.y * CS_ROWS;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  if (col < N) {
+#pragma unroll
+    for (int i = 0; i < CS_ROWS / 8; ++i) {
+      const int r = r0 + ty + 8 * i;
+      if (r < M) {
+        const T* p = x + (size_t)r * N + col;
+        if (VEC == 4) {
+          const float4 t = ld4(p);
+          acc[0] += t.x; acc[1 % VEC] += t.y; acc[2 % VEC] += t.z; acc[3 % VEC] += t.w;
+        } else {
+          acc[0] += (float)*p;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) red[ty][tx * VEC + v] = acc[v];
+  __syncthreads();
+  if (ty == 0 && col < N) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float s = red[0][tx * VEC + v];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s += red[k][tx * VEC + v];
+      part[(size_t)blockIdx.y * N + col + v] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nchunk, int N, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float s = part[c];
+  for (int k = 1; k < nchunk; ++k) s += part[(size_t)k * N + c];
+  out[c] = s;
+}
+
 }  // namespace hopmi
 
 using namespace hopmi;
@@ -277,4 +331,31 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_bwd(const float* dout, cons
                                                          const float* gamma, float* dx, float* dres, int M, int D,
                                                          float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   return hopmi_bias_dropout_residual_layernorm_bwd_dt(dout, nullptr, xhat, rstd, gamma, dx, dres, M, D, p_drop, seed, seed_dev, HOPMI_F32, stream);
+}
+
+extern "C" size_t hopmi_colsum_ws_floats(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  const int nchunk = (M + CS_ROWS - 1) / CS_ROWS;
+  return nchunk > 1 ? (size_t)nchunk * N : 0;
+}
+
+extern "C" int hopmi_colsum(const void* x, int dtype, int M, int N, float* out, float* ws, void* stream) {
+  if (M <= 0 || N <= 0 || (M + CS_ROWS - 1) / CS_ROWS > 65535) { set_error("hopmi_colsum: bad sizes M=%d N=%d", M, N); return HOPMI_EINVAL; }
+  if (int e = ew_dtype_ok("hopmi_colsum", dtype)) return e;
+  const int nchunk = (M + CS_ROWS - 1) / CS_ROWS;
+  if (!x || !out || (nchunk > 1 && !ws)) { set_error("hopmi_colsum: null pointer argument"); return HOPMI_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = nchunk > 1 ? ws : out;
+  const size_t esz = dtype == HOPMI_BF16 ? 2 : 4;
+  const bool vec = N % 4 == 0 && reinterpret_cast<uintptr_t>(x) % (4 * esz) == 0;
+  const dim3 grid((unsigned)((N + (vec ? 128 : 32) - 1) / (vec ? 128 : 32)), (unsigned)nchunk);
+  if (dtype == HOPMI_BF16) {
+    if (vec) hipLaunchKernelGGL((colsum_partial_kernel<__bf16, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(x), M, N, part);
+    else hipLaunchKernelGGL((colsum_partial_kernel<__bf16, 1>), grid, dim3(256), 0, st, static_cast<const __bf16*>(x), M, N, part);
+  } else {
+    if (vec) hipLaunchKernelGGL((colsum_partial_kernel<float, 4>), grid, dim3(256), 0, st, static_cast<const float*>(x), M, N, part);
+    else hipLaunchKernelGGL((colsum_partial_kernel<float, 1>), grid, dim3(256), 0, st, static_cast<const float*>(x), M, N, part);
+  }
+  if (nchunk > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, nchunk, N, out);
+  return check_launch("hopmi_colsum");
 }

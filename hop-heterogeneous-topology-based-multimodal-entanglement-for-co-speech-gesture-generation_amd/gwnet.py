@@ -285,15 +285,15 @@ class gwnet(nn.Module):
         """skip 1x1 convs summed over layers (one K=512 GEMM), relu, end convs: gwnet.py:209-220,240-246."""
         ws = torch.cat([c.weight.flatten(1) for c in self.skip_convs], 1)               # (256, 8*64)
         bs = torch.stack([c.bias for c in self.skip_convs]).sum(0)
-        s = F.relu(F.linear(tails, ws, bs))
-        s = F.relu(F.linear(s, self.end_conv_1.weight.flatten(1), self.end_conv_1.bias))
-        return F.linear(s, self.end_conv_2.weight.flatten(1), self.end_conv_2.bias)
+        s = F.relu(ops.linear(tails, ws, bs))
+        s = F.relu(ops.linear(s, self.end_conv_1.weight.flatten(1), self.end_conv_1.bias))
+        return ops.linear(s, self.end_conv_2.weight.flatten(1), self.end_conv_2.bias)
 
     def forward_cl(self, x):
         """x (B,T>=13,V,in_dim) channels-last -> (B,4,V,out_dim) channels-last."""
         if x.shape[1] < self.receptive_field:
             x = F.pad(x, (0, 0, 0, 0, self.receptive_field - x.shape[1], 0))          # gwnet.py:145-146
-        x = F.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias).float()    # gwnet.py:149
+        x = ops.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias).float()    # gwnet.py:149
         with torch.autocast("cuda", enabled=False):                                     # the kernels are fp32
             A1, A2 = self.adjacency()
             prep = ops.gcn_prepare(A1, A2)      # on-chip images of the mix matrices, shared by all layers

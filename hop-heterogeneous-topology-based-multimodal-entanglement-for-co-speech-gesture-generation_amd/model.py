@@ -99,10 +99,10 @@ class ReprogrammingLayer(nn.Module):
     def __init__(self, d_model, n_heads, d_keys=None, d_llm=None, attention_dropout=0.1):
         super().__init__()
         d_keys = d_keys or (d_model // n_heads)
-        self.query_projection = nn.Linear(d_model, d_keys * n_heads)
-        self.key_projection = nn.Linear(d_llm, d_keys * n_heads)
-        self.value_projection = nn.Linear(d_llm, d_keys * n_heads)
-        self.out_projection = nn.Linear(d_keys * n_heads, d_llm)
+        self.query_projection = ops.Linear(d_model, d_keys * n_heads)
+        self.key_projection = ops.Linear(d_llm, d_keys * n_heads)
+        self.value_projection = ops.Linear(d_llm, d_keys * n_heads)
+        self.out_projection = ops.Linear(d_keys * n_heads, d_llm)
         self.n_heads = n_heads
         self.activation = nn.ReLU()
         self.dropout = nn.Dropout(attention_dropout)
@@ -157,21 +157,21 @@ class Model(nn.Module):
         if self.z_obj:                                                          # HOP.py:96-107
             self.z_size = 16
             self.speaker_embedding = nn.Sequential(nn.Embedding(z_obj.n_words, self.z_size),
-                                                   nn.Linear(self.z_size, self.z_size))
-            self.speaker_mu = nn.Linear(self.z_size, self.z_size)
-            self.speaker_logvar = nn.Linear(self.z_size, self.z_size)
+                                                   ops.Linear(self.z_size, self.z_size))
+            self.speaker_mu = ops.Linear(self.z_size, self.z_size)
+            self.speaker_logvar = ops.Linear(self.z_size, self.z_size)
         self.word_embeddings = self.llm_model.get_input_embeddings().weight     # alias key, HOP.py:111
         self.vocab_size = self.word_embeddings.shape[0]
         if self.use_reprograme:                                                 # HOP.py:114-119
             self.num_tokens = 1500
             self.mapping_layer = nn.Linear(self.vocab_size, self.num_tokens)
-            self.align_layer = nn.Linear(2 * self.d_llm, self.d_llm)
+            self.align_layer = ops.Linear(2 * self.d_llm, self.d_llm)
             self.reprogramming_layer = ReprogrammingLayer(configs.d_model, configs.n_heads, self.d_ff, self.d_llm)
         ted = configs.datasets == "TED"
         self.pred_g_len = 27 if ted else 126
         self.hidden_size = 350
         if self.use_gwnet:                                                      # HOP.py:129-143
-            self.beat = nn.Sequential(nn.Linear(3400, 1700), nn.LeakyReLU(0.2, inplace=True), nn.Linear(1700, 170))
+            self.beat = nn.Sequential(ops.Linear(3400, 1700), nn.LeakyReLU(0.2, inplace=True), ops.Linear(1700, 170))
             self.num_nodes = 9 if ted else 42
             self.gwnet = _gwnet.gwnet(None, self.num_nodes, dropout=0, supports=None, gcn_bool=True, addaptadj=True,
                                       aptinit=None, in_dim=173, out_dim=173, residual_channels=64,
@@ -180,9 +180,9 @@ class Model(nn.Module):
         self.gru_input_size = self.d_llm + self.pred_g_len + 1 + 16 + audio_feat
         self.gru = nn.GRU(self.gru_input_size, hidden_size=self.hidden_size, num_layers=4, batch_first=True,
                           bidirectional=True, dropout=0)
-        self.out = nn.Sequential(nn.Linear(self.hidden_size, self.hidden_size // 2), nn.Dropout(0),
+        self.out = nn.Sequential(ops.Linear(self.hidden_size, self.hidden_size // 2), nn.Dropout(0),
                                  nn.LeakyReLU(True),                            # slope 1.0 == identity, HOP.py:172
-                                 nn.Linear(self.hidden_size // 2, self.pred_g_len))
+                                 ops.Linear(self.hidden_size // 2, self.pred_g_len))
         self._randn_like = torch.randn_like      # tests inject CPU-drawn noise here
         self._cache = None
         self._kv_infer = None                        # (weights key, K/V prototypes) of the last no-grad call

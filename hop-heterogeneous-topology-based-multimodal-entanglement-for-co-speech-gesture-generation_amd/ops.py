@@ -383,6 +383,69 @@ def _dev_bf16(t, name):
     return t
 
 
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """Sum over every dimension but the last: x (..., N), fp32 or bf16 -> (N,) fp32 (hopmi_colsum: the bias gradient of a
+    linear layer at HBM speed, fixed summation order)."""
+    N = x.shape[-1]
+    x2 = x.reshape(-1, N)
+    typed = x2.dtype == torch.bfloat16
+    x2 = _dev_bf16(x2, "x") if typed else _dev_f32(x2.float(), "x")
+    M = x2.shape[0]
+    L, st = _lib.lib(), _stream()
+    out = torch.empty(N, dtype=torch.float32, device=x2.device)
+    nws = L.hopmi_colsum_ws_floats(M, N)
+    ws = torch.empty(nws, dtype=torch.float32, device=x2.device) if nws else None
+    _lib.check(_timed("colsum", x2.numel() * x2.element_size(), x2.numel(),
+                      lambda: L.hopmi_colsum(x2.data_ptr(), 1 if typed else 0, M, N, out.data_ptr(), _ptr(ws), st)), "hopmi_colsum")
+    return out
+
+
+class _LinearFn(torch.autograd.Function):
+    """torch.nn.functional.linear whose backward takes the bias gradient with hopmi_colsum (the library's column reduction
+    is the slowest piece of a trainable linear layer's backward here).  Under autocast the operands are cast as
+    F.linear's autocast rule does and both gradient GEMMs run in that type; the results are handed back in the
+    parameters' types."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        amp = x.is_cuda and torch.is_autocast_enabled("cuda")
+        xc, wc, bc = x, w, b
+        if amp:
+            dt = torch.get_autocast_dtype("cuda")
+            xc, wc, bc = x.to(dt), w.to(dt), b.to(dt)
+        with torch.autocast("cuda", enabled=False):
+            y = torch.nn.functional.linear(xc.reshape(-1, xc.shape[-1]), wc, bc)
+        ctx.save_for_backward(xc, wc)
+        ctx.types = (x.dtype, w.dtype, b.dtype)
+        # (not a tracked view: an in-place activation may follow, e.g. HOP.py:131's LeakyReLU(inplace=True))
+        return torch.ops.aten._unsafe_view(y, list(x.shape[:-1]) + [w.shape[0]])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        tx, tw, tb = ctx.types
+        with torch.autocast("cuda", enabled=False):
+            dy2 = dy.reshape(-1, dy.shape[-1]).to(wc.dtype)
+            dx = (dy2 @ wc).view(xc.shape).to(tx) if ctx.needs_input_grad[0] else None
+            dw = (dy2.t() @ xc.reshape(-1, xc.shape[-1])).to(tw) if ctx.needs_input_grad[1] else None
+            db = colsum(dy2).to(tb) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """F.linear(x, w, b); with a bias that needs a gradient, through _LinearFn."""
+    if b is None or not (torch.is_grad_enabled() and b.requires_grad):
+        return torch.nn.functional.linear(x, w, b)
+    return _LinearFn.apply(x, w, b)
+
+
+class Linear(torch.nn.Linear):
+    """torch.nn.Linear (same parameters, same state_dict keys) whose forward is `linear` above."""
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)
+
+
 class _BiasGeluBf16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias):
@@ -966,7 +1029,7 @@ class _GruLayerFn(torch.autograd.Function):
             hprev[:, 1:, 0] = yv[:, :-1, 0]
             hprev[:, :-1, 1] = yv[:, 1:, 1]
             dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
-            dbhh = dgh.sum(dim=(0, 1))
+            dbhh = colsum(dgh.view(B * T, 6 * H)).view(2, 3 * H)
         return dgi, dwhh, dbhh
 
 
@@ -1040,7 +1103,7 @@ def gru_bidirectional(x: torch.Tensor, gru: torch.nn.GRU, dropout_p: float = 0.0
     for layer in range(gru.num_layers):
         al = lambda n: _PackedAlias.apply(bufs[layer][n], getattr(gru, f"{n}_l{layer}"), getattr(gru, f"{n}_l{layer}_reverse"))
         w_ih, b_ih = al("weight_ih"), al("bias_ih")
-        gi = torch.nn.functional.linear(inp, w_ih.flatten(0, 1), b_ih.flatten()).view(inp.shape[0], inp.shape[1], 2, 3 * H)
+        gi = linear(inp, w_ih.flatten(0, 1), b_ih.flatten()).view(inp.shape[0], inp.shape[1], 2, 3 * H)
         inp = gru_layer(gi, al("weight_hh"), al("bias_hh"))
         if dropout_p > 0 and training and layer < gru.num_layers - 1:
             inp = torch.nn.functional.dropout(inp, dropout_p, True)

@@ -191,6 +191,14 @@ int hopmi_reprog_attn_bwd_dt(const void* q, const void* k, const void* v, const 
                              const float* delta, void* dq, float* dk, float* dv, void* ws, int N, int S, int H, int E,
                              float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 
+/* ---- bias gradient of a trainable linear layer: out[N] = sum over the M rows of x [M][N] (what the backward of
+ *      torch.nn.functional.linear -- align_layer, the projections, the GRU input projections, the gwnet 1x1 convs,
+ *      HOP.py:118-190 -- computes with a generic reduction).  dtype of x: 0 = fp32, 1 = bf16; out fp32.
+ *      ws: hopmi_colsum_ws_floats(M, N) floats (partial sums of 128-row chunks; none for M <= 128).  Fixed summation
+ *      order: bitwise reproducible. ---- */
+size_t hopmi_colsum_ws_floats(int M, int N);
+int hopmi_colsum(const void* x, int dtype, int M, int N, float* out, float* ws, void* stream);
+
 /* ---- self-attention of the frozen BERT encoder (HOP.py:204 -> transformers BertSelfAttention.forward; replaces
  *      the transpose_for_scores copies + the library scaled-dot-product attention + the output re-layout) ----
  *   qkv   [B][L][3][H][64]  output of the fused Q|K|V projection (bias added), L <= 64, head dim 64

@@ -73,8 +73,11 @@ def test_graphed_step_equals_eager(V, epoch, monkeypatch):
         if a.is_floating_point():
             # (a bias in front of a training-mode BatchNorm has an analytically zero gradient: Adam moves it by +-lr per
             # step on rounding noise, DESIGN.md 2, and it shifts that BatchNorm's batch mean by as much)
+            # (and a few weight elements whose gradient is at rounding level step the other way -- see above: the batch
+            # variances downstream of them move by ~1e-3 relative)
             slack = 6e-3 if n.endswith("running_mean") else 0.0
-            assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1.0) + slack, n
+            rtol = 2e-3 if n.endswith("running_var") else 1e-4
+            assert (a - b).abs().max().item() <= rtol * max(a.abs().max().item(), 1.0) + slack, n
         else:
             assert torch.equal(a, b), n
 

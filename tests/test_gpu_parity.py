@@ -280,6 +280,50 @@ def test_reprog_attention_bf16_storage_vs_fp32_storage(B, S, p_drop):
         assert_close(res["bf16"][i].float(), res["f32"][i], 4e-3, what)
 
 
+@pytest.mark.parametrize("M,N", [(4352, 2100), (4352, 175), (4608, 173), (4352, 27), (8, 1536000), (1, 64), (129, 4), (2048, 1700)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum_vs_float64(M, N, dtype):
+    """hopmi_colsum (bias gradients of the trainable linears) against a float64 column sum: vector and scalar column
+    paths (N % 4), one and many row chunks, ragged last chunk, both storage types; bitwise reproducible."""
+    from hopmi import ops
+    dev = _dev()
+    x = torch.randn(M, N, generator=torch.Generator().manual_seed(M + N)).to(dtype)
+    got = ops.colsum(x.to(dev))
+    assert got.dtype == torch.float32 and got.shape == (N,)
+    want = x.double().sum(0)
+    scale = x.double().abs().sum(0).max().item()
+    assert (got.cpu().double() - want).abs().max().item() <= 2e-6 * scale
+    assert torch.equal(got, ops.colsum(x.to(dev)))
+    got3 = ops.colsum(x.to(dev).view(1, M, N))                      # leading dimensions are flattened
+    assert torch.equal(got, got3)
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_linear_with_colsum_bias_gradient_equals_functional_linear(amp):
+    """ops.linear (F.linear whose backward takes db with hopmi_colsum) against torch.nn.functional.linear's own autograd,
+    plain and under bf16 autocast: same output bits, same dx and dW bits, db to fp32 rounding (bf16 rounding of the
+    library's bf16 sum under autocast)."""
+    from hopmi import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(9)
+    x0 = torch.randn(128, 34, 700, generator=gen)
+    w0 = 0.05 * torch.randn(2100, 700, generator=gen)
+    b0 = torch.randn(2100, generator=gen)
+    g = torch.randn(128, 34, 2100, generator=gen).to(dev)
+    res = []
+    for fn in (torch.nn.functional.linear, ops.linear):
+        x, w, b = (t.to(dev).requires_grad_() for t in (x0, w0, b0))
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = fn(x, w, b)
+        (y.float() * g).sum().backward()
+        res.append((y.detach(), x.grad, w.grad, b.grad))
+    assert res[0][0].dtype == res[1][0].dtype == (torch.bfloat16 if amp else torch.float32)
+    for i in range(3):
+        assert torch.equal(res[0][i], res[1][i]), i
+    assert_close(res[1][3], res[0][3], 8e-3 if amp else 1e-5, "db")
+    assert_close(res[1][3], g.double().sum((0, 1)).float() if not amp else g.bfloat16().double().sum((0, 1)).float(), 1e-5, "db vs float64")
+
+
 # ------------------------------------------------------------------------------------ GRU kernels
 @pytest.mark.parametrize("persistent", ["1", "0"])
 @pytest.mark.parametrize("B,T,I,H,L", [(3, 5, 7, 6, 2), (37, 34, 20, 350, 2), (5, 28, 8, 64, 4), (130, 9, 12, 18, 1),
