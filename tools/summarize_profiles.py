@@ -28,8 +28,10 @@ rows = list(csv.DictReader(open(find("prof_stats", "*kernel_stats.csv"))))
 total = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (1x MI355X)\n")
-    f.write(f"# 14 train_llm steps profiled (B=128, TED V=9, fp32): 7 eager steps of the kernel region + 1 eager warm-up step + 6 replays of "
-            f"the recorded step; total kernel time {total / 1e6:.2f} ms; Name truncated to 120 chars; rows >= 0.05 %\n")
+    nsteps = sum(int(r["Calls"]) for r in rows if "hop_losses_fwd_kernel" in r["Name"])          # one launch per train_llm step
+    f.write(f"# {nsteps} train_llm steps profiled (B=128, TED V=9, fp32): the eager steps of the kernel region (7) and of the set-up, then "
+            f"the replays of the recorded step (warm-up + timed); total kernel time {total / 1e6:.2f} ms = {total / 1e6 / max(nsteps, 1):.2f} ms per step; "
+            f"Name truncated to 120 chars; rows >= 0.05 %\n")
     # launch-weighted average over all instantiations of the graded kernel (what bench.py's roofline.avg_us must agree with)
     for label, pat in (("wn_layer_fwd_kernel<MT, MULTI, GCN = true> (the graded kernel: full layer)", r"wn_layer_fwd_kernel<\d, (true|false), true>"),
                        ("wn_layer_fwd_kernel<MT, MULTI, GCN = false> (gate-only launches of the backward)", r"wn_layer_fwd_kernel<\d, (true|false), false>")):
@@ -65,7 +67,8 @@ KEYS = {"wn_layer_fwd": r"wn_layer_fwd_kernel<\d, (true|false), true>", "wn_laye
         "reprog_attn_fwd": "reprog_attn_fwd_kernel", "reprog_attn_bwd_dq": "reprog_attn_bwd_dq", "reprog_attn_bwd_dkv": "reprog_attn_bwd_dkv",
         "bert_attn_fwd": "bert_attn_fwd_kernel", "bert_attn_bwd": "bert_attn_bwd_kernel",
         "bias_drop_res_ln_fwd": "bias_drop_res_ln_fwd", "bias_gelu_fwd": "bias_gelu_fwd",
-        "gru_fwd_persistent": "gru_fwd_persistent_kernel", "gru_bwd_persistent": "gru_bwd_persistent_kernel"}
+        "gru_fwd_persistent": "gru_fwd_persistent_kernel", "gru_bwd_persistent": "gru_bwd_persistent_kernel",
+        "colsum_partial": "colsum_partial_kernel", "gemm_split": "gemm_split_kernel"}
 
 
 def counter(sub, name):
