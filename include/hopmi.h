@@ -193,7 +193,7 @@ int hopmi_reprog_attn_bwd_dt(const void* q, const void* k, const void* v, const 
 
 /* ---- bias gradient of a trainable linear layer: out[N] = sum over the M rows of x [M][N] (what the backward of
  *      torch.nn.functional.linear -- align_layer, the projections, the GRU input projections, the gwnet 1x1 convs,
- *      HOP.py:118-190 -- computes with a generic reduction).  dtype of x: 0 = fp32, 1 = bf16; out fp32.
+ *      HOP.py:104-173,262-265; gwnet.py:65,117,129-134 -- computes with a generic reduction).  dtype of x: 0 = fp32, 1 = bf16; out fp32.
  *      ws: hopmi_colsum_ws_floats(M, N) floats (partial sums of 128-row chunks; none for M <= 128).  Fixed summation
  *      order: bitwise reproducible. ---- */
 size_t hopmi_colsum_ws_floats(int M, int N);
