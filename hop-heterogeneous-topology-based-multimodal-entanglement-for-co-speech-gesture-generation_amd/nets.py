@@ -180,7 +180,9 @@ class ConvDiscriminator(nn.Module):
         """BatchNorm1d on channels-last x (B,T,C), torch semantics (batch stats over B and T)."""
         x = x.float()
         if training:
-            var, mean = torch.var_mean(x, dim=(0, 1), unbiased=False)
+            # (statistics over the rows of the transposed copy: the library's reduction over the OUTER dimensions of a
+            # (4096, 16) tensor takes 45 us, over the inner dimension of (16, 4096) a fifth of that)
+            var, mean = torch.var_mean(x.reshape(-1, x.shape[-1]).t().contiguous(), dim=1, unbiased=False)
             with torch.no_grad():
                 n = x.shape[0] * x.shape[1]
                 bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
