@@ -112,7 +112,10 @@ class _Capture:
         parts = [w.float().reshape(()) for w in self.status]
         self.status.clear()
         parts.append(self.owner._bwd_status)          # the previous replay's backward launches
-        return torch.stack(parts).sum()
+        parts.append(self.owner._peer_status)         # ... and what rode on the gradient exchanges since the last fetch
+        total = torch.stack(parts).sum()
+        self.owner._peer_status.zero_()
+        return total
 
     def fetch_into(self, fetch, dev):
         o = self.owner
@@ -160,6 +163,7 @@ class GraphedTrainStep:
         self._event = torch.cuda.Event()
         self._host = torch.zeros(16, dtype=torch.float32).pin_memory()
         self._bwd_status = torch.zeros((), dtype=torch.float32, device=dev)
+        self._peer_status = torch.zeros((), dtype=torch.float32, device=dev)   # status words of ANY rank (N > 1), see _after_backward
         self._seed_word = torch.zeros(1, dtype=torch.int64, device=dev)    # ops.SEED_DEV while recording
         self._has_proto = bool(getattr(m, "use_reprograme", False))
         if self._has_proto:
@@ -211,16 +215,23 @@ class GraphedTrainStep:
             grads = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None]
             if not is_disc and self._has_proto and self._S.grad is not None:
                 grads.append(self._S.grad)
-            flat = torch.empty(sum(g.numel() for g in grads), dtype=self.grad_dtype or torch.float32, device=grads[0].device)
+            n = sum(g.numel() for g in grads)
+            flat = torch.empty(n + 1, dtype=self.grad_dtype or torch.float32, device=grads[0].device)
             views, off = [], 0
             for g in grads:
                 views.append(flat[off:off + g.numel()].view(g.shape))
                 off += g.numel()
             torch._foreach_copy_(views, grads)
+            # one more element: this rank's persistent-GRU status words so far in the replay.  A hand-off time-out on one rank
+            # then shows up in EVERY rank's next loss fetch, so all ranks raise at the same step instead of the healthy ones
+            # waiting in the next collective for a rank that has stopped.
+            words = [w.float().reshape(()) for w in cap.status]
+            flat[n:].copy_((torch.stack(words).sum() if words else torch.zeros((), device=flat.device)).reshape(1))
             cap.keep.append(flat)
             grp = self.group
             cap.cut(lambda: all_reduce_mean(flat, grp))
             torch._foreach_copy_(grads, views)
+            self._peer_status.add_(flat[n].float())
         if not is_disc and self._has_proto:
             m = self.model
             dS = self._S.grad

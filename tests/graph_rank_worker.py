@@ -54,6 +54,16 @@ def main():
     sync1 = GradSync([m1, d1], bucket_mb=0.25)
     sync2 = GradSync([m2, d2], bucket_mb=0.25)
     graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, accelerator=sync2, eager_calls=1, group=dist.group.WORLD)
+    # a status word this worker controls, recorded as if a persistent GRU launch of the backward had produced it (there are
+    # none here: shared device): set on ONE rank at the end, it must stop EVERY rank at the same call
+    fake_status = torch.zeros((), dtype=torch.int32, device=dev)
+    plain_after_backward = graphed._after_backward
+
+    def after_backward_with_status(cap, is_disc):
+        cap.status.append(fake_status)
+        return plain_after_backward(cap, is_disc)
+
+    graphed._after_backward = after_backward_with_status
     losses1, losses2 = [], []
     # The two paths run one after the other, not step by step in turn.  Interleaved (an eager train_llm step of the OTHER
     # model copy between two replays), the GAN-phase recording's value-projection bias gradient went wrong from its third
@@ -103,11 +113,29 @@ def main():
     allcs = [torch.empty_like(cs) for _ in range(world)]
     dist.all_gather(allcs, cs)
     spread = max((c - allcs[0]).abs().max().item() for c in allcs)
+    # (after every comparison: these two calls train m2 further)
+    # a hand-off time-out on rank 1 only: its status rides on the gradient exchange of that replay, and the NEXT call's loss
+    # fetch raises on both ranks (rank 0 learns of it from the exchange alone)
+    if rank == 1:
+        fake_status.fill_(1)
+    stopped_at = None
+    for call in range(2):                  # epoch <= 10: the exchange follows the fetch, so the second call stops; GAN phase:
+        try:                               # the discriminator's exchange precedes the fetch of the same call
+            graphed(epoch, *batch)
+        except RuntimeError as e:
+            if "timed out" not in str(e):
+                raise
+            stopped_at = call
+            break
+    fake_status.zero_()
+    graphed._bwd_status.zero_()
+    graphed._peer_status.zero_()
     print("RANKJSON " + json.dumps(dict(rank=rank, losses_eager=losses1, losses_graph=losses2, sharded=sharded_before, own=own,
                                         stale_before_unshard=stale, n_plan=[k for k, _ in next(iter(graphed.records.values()))["cap"].plan],
                                         worst_max=max(v[0] for v in worst.values()), worst_mean=max(v[1] for k, v in worst.items() if not noise(k)),
                                         worst_mean_name=max((k for k in worst if not noise(k)), key=lambda k: worst[k][1]),
                                         worst_name=max(worst, key=lambda k: worst[k][0]), replica_spread=spread,
+                                        stopped_at=stopped_at,
                                         top_mean=sorted(((round(v[1], 7), k) for k, v in worst.items() if not noise(k)), reverse=True)[:6])),
           flush=True)
     dist.barrier()

@@ -253,6 +253,8 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch):
         # is at rounding level may still take a +-lr Adam step the other way)
         assert row["worst_max"] <= 4.5e-3 and row["worst_mean"] <= 2e-5, {k: row[k] for k in ("worst_max", "worst_mean", "worst_mean_name", "worst_name", "top_mean")}
         assert row["replica_spread"] <= 1e-6, row
+        # a status word set on rank 1 alone stopped BOTH ranks, at the same call (rank 0 learns of it from the exchange only)
+        assert row["stopped_at"] == (0 if epoch > 10 else 1), row["stopped_at"]
 
 
 # ------------------------------------------------------------------------------------------- input stage (feeder)
