@@ -287,7 +287,7 @@ def main():
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "median_ms_per_step": median_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 library GEMMs (autocast) + bf16 gradient exchange; f32 HIP kernels, master weights and optimizer",
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 library GEMMs (autocast), bf16 activations between them (dtype argument of the BERT / GRU / attention HIP kernels) + bf16 gradient exchange; f32 arithmetic inside the HIP kernels, f32 WaveNet stack, master weights and optimizer",
             "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{1 if V == 9 else 3}] per GPU: {args.dataset} {V + 1}-joint ({V} graph nodes), "
                                    f"34-frame clips, batch {B}/GPU, {args.dtype}, one full train_llm step = "
