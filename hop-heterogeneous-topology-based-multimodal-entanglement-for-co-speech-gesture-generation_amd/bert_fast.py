@@ -141,6 +141,7 @@ class FrozenBertEncoder:
                          (D,), emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps)
         if p_h > 0:
             h = F.dropout(h, p_h, True)
+        hr = h                                               # the residual stream's handle on h
         for i, lay in enumerate(llm.encoder.layer):
             att = lay.attention
             wqkv, bqkv = self._fused_qkv(i, att.self)
@@ -152,10 +153,12 @@ class FrozenBertEncoder:
                 a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p_a)
                 a = a.transpose(1, 2).reshape(B, L, D)
             o = self._linear((i, "ao"), a, att.output.dense.weight, None)
-            h = ops.bias_dropout_residual_layernorm(o, att.output.dense.bias, h, att.output.LayerNorm.weight,
-                                                    att.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
+            # (every LayerNorm output feeds a GEMM and the next residual add: handed out twice, so that the two gradients
+            # meet inside the backward kernel instead of in an add launch of their own)
+            h, hr = ops.bias_dropout_residual_layernorm2(o, att.output.dense.bias, hr, att.output.LayerNorm.weight,
+                                                         att.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
             f = ops.bias_gelu(self._linear((i, "f1"), h, lay.intermediate.dense.weight, None), lay.intermediate.dense.bias)
             o = self._linear((i, "f2"), f, lay.output.dense.weight, None)
-            h = ops.bias_dropout_residual_layernorm(o, lay.output.dense.bias, h, lay.output.LayerNorm.weight,
-                                                    lay.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
+            h, hr = ops.bias_dropout_residual_layernorm2(o, lay.output.dense.bias, hr, lay.output.LayerNorm.weight,
+                                                         lay.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
         return h

@@ -365,6 +365,65 @@ class _BiasDropResLnFn(torch.autograd.Function):
         return dx, None, dres, None, None, None, None, None
 
 
+class _BiasDropResLn2Fn(torch.autograd.Function):
+    """_BiasDropResLnFn handing its output out TWICE (two tensors on one storage): one for the next GEMM, one for the next
+    residual add.  Autograd then delivers the two gradients separately and the backward kernel adds them while loading
+    (`dout` + `dout_t` of hopmi_bias_dropout_residual_layernorm_bwd_dt, dtype 0) instead of a separate add launch over the
+    activation for every residual junction (12 per step in a 6-layer encoder)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, bias, res, gamma, beta, eps, p_drop, seed):
+        x, res = _dev_f32(x, "x"), _dev_f32(res, "res")
+        bias, gamma, beta = (_dev_f32(t.detach(), n) for t, n in ((bias, "bias"), (gamma, "gamma"), (beta, "beta")))
+        D = x.shape[-1]
+        M = x.numel() // D
+        res_rows = res.numel() // D
+        need = x.requires_grad or res.requires_grad
+        out = torch.empty_like(x)
+        xhat = torch.empty_like(x) if need else None
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device) if need else None
+        L, st, sp = _lib.lib(), _stream(), _seed_ptr()
+        _lib.check(_timed("bias_drop_res_ln_fwd", 4 * x.numel() * (4 if need else 3), 0,
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_fwd(
+                              x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
+                              out.data_ptr(), _ptr(xhat), _ptr(rstd), M, D, float(eps), float(p_drop), int(seed) & _M32, sp, st)),
+                   "hopmi_bias_dropout_residual_layernorm_fwd")
+        if need:
+            ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.p_drop, ctx.seed, ctx.res_shape, ctx.x_rows, ctx.sp = float(p_drop), int(seed) & _M32, res.shape, M, sp
+        ctx.set_materialize_grads(False)
+        return out, out.detach()
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, dout, dout2):
+        xhat, rstd, gamma = ctx.saved_tensors
+        if dout is None:
+            dout, dout2 = dout2, None
+        if dout is None:
+            return (None,) * 8
+        dout = _dev_f32(dout, "dout")
+        d2 = None if dout2 is None else _dev_f32(dout2, "dout2")
+        D = xhat.shape[-1]
+        M = ctx.x_rows
+        dx, dres = torch.empty_like(xhat), torch.empty_like(xhat)
+        L, st = _lib.lib(), _stream()
+        _lib.check(_timed("bias_drop_res_ln_bwd", (16 if d2 is None else 20) * xhat.numel(), 0,
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_dt(
+                              dout.data_ptr(), _ptr(d2), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                              dres.data_ptr(), M, D, ctx.p_drop, ctx.seed, ctx.sp, 0, st)),
+                   "hopmi_bias_dropout_residual_layernorm_bwd_dt")
+        if tuple(ctx.res_shape) != tuple(dres.shape):            # broadcast residual (e.g. position embeddings)
+            dres = dres.view(-1, *ctx.res_shape).sum(0)
+        return dx, None, dres, None, None, None, None, None
+
+
+def bias_dropout_residual_layernorm2(x, bias, res, gamma, beta, eps, p_drop=0.0, seed=0):
+    """(out, out again on the same storage): see _BiasDropResLn2Fn."""
+    return _BiasDropResLn2Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
+
+
 # ---- bf16-storage forms of the frozen BERT's epilogue / attention operators (dtype argument of the `_dt` entry points) ------
 # Under bf16 autocast the library GEMMs produce and consume bf16; these operators read the GEMM output and write the next
 # GEMM's input in bf16 themselves (fp32 arithmetic inside), so no cast kernel sits on either side of them.  The values are
