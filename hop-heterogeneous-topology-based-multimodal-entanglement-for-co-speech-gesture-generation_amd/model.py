@@ -245,6 +245,17 @@ class Model(nn.Module):
             self._kv_infer = (key, tuple(t.detach() for t in kv) if isinstance(kv, (tuple, list)) else kv.detach())
         return kv
 
+    def _window_selector(self, V, like):
+        key = (V, like.device, like.dtype)
+        sel = self.__dict__.setdefault("_hopmi_selectors", {}).get(key)
+        if sel is None:
+            t = torch.arange(16, device=like.device).view(16, 1)
+            j = torch.arange(V, device=like.device).view(1, V)
+            sel = torch.zeros(16 * V, 16, device=like.device, dtype=like.dtype)
+            sel[torch.arange(16 * V, device=like.device), ((t * V + j) % 16).reshape(-1)] = 1
+            self.__dict__["_hopmi_selectors"][key] = sel
+        return sel
+
     def _audio_branch(self, in_audio, pre_seq, B, V):
         """HOP.py:209-231: beat MLP on the 16 audio windows, the `.view` scramble, gwnet, and the `pre` / `beat`
         decoder inputs.  The branch has no dropout and no dependence on the speaker, so inside `step_cache()` a
@@ -260,9 +271,9 @@ class Model(nn.Module):
                 self.gwnet.replay_bn_update()
             return c["audio"]
         feat = self.beat(in_audio.unfold(1, 3400, 2191))                        # (B,16,170), once per window
-        t = torch.arange(16, device=feat.device).view(16, 1)
-        j = torch.arange(V, device=feat.device).view(1, V)
-        audio_feat = feat[:, (t * V + j) % 16]                                  # (B,16,V,170): the .view scramble
+        # the .view scramble: node j of frame t reads window (t V + j) % 16.  As a product with the 0/1 selection matrix
+        # (exact: one term per output) rather than an indexed gather, whose backward is a sort-based index_put (47 us)
+        audio_feat = torch.matmul(self._window_selector(V, feat), feat).view(B, 16, V, feat.shape[-1])   # (B,16,V,170)
         seq_audio = torch.cat([pre_seq.reshape(B, 16, V, 3), audio_feat], dim=3)
         feature = self.gwnet.forward_cl(seq_audio).permute(0, 3, 2, 1)          # (B,173,V,4) NCHW semantics
         g_seq = feature[:, :3].reshape(B, 3 * V, 4).permute(0, 2, 1)            # channel-major xyz, HOP.py:225-226
