@@ -48,6 +48,7 @@ def parse():
                     help="the frozen BERT's linears: the library's fp32 GEMM, or hopmi_gemm_split with 3 bf16 parts per operand "
                          "(six MFMA terms: fp32-equivalent, default) or 2 parts (three terms: 2^-16-class products)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
+    ap.add_argument("--tuned-table", default=None, help="another TunableOp table than the shipped one (A/B runs)")
     ap.add_argument("--rehearse-sync", action="store_true",
                     help="N=1 only: run the N>1 exchange path on a 1-rank RCCL group (overhead rehearsal)")
     ap.add_argument("--feed-host", action="store_true",
@@ -188,7 +189,7 @@ def main():
     B = args.batch
     hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
     hopmi.gemm_parts({"library": 0, "split3": 3, "split2": 2}[args.bert_gemm])      # (fp32 mode only: bf16 mode autocasts)
-    tuned = (not args.no_tuned_gemms) and args.dtype == "fp32" and hopmi.use_tuned_gemms()
+    tuned = (not args.no_tuned_gemms) and hopmi.use_tuned_gemms(args.tuned_table)      # (the table holds fp32 and bf16 shapes)
     torch.manual_seed(0)                                       # identical replicas
     model = hopmi.Model(synth.model_configs(args.dataset), synth.build_bert(6), synth.SyntheticTokenizer(),
                         synth.SpeakerVocab(1370)).float().to(dev)
