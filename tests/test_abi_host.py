@@ -64,6 +64,36 @@ def test_hot_path_refuses_cpu_tensors():
         hopmi.ops.gcn_prepare(A, A)
 
 
+def test_new_entry_points_check_their_arguments_without_a_gpu():
+    """hopmi_colsum and the dtype argument of the reprogramming attention validate sizes / pointers / dtype before any launch."""
+    L = _lib.lib()
+    assert L.hopmi_colsum_ws_floats(128, 64) == 0 and L.hopmi_colsum_ws_floats(129, 64) == 2 * 64 and L.hopmi_colsum_ws_floats(0, 64) == 0
+    assert L.hopmi_colsum(None, 0, 4, 4, None, None, None) == -1 and b"null pointer" in L.hopmi_last_error()
+    assert L.hopmi_colsum(None, 0, 0, 4, None, None, None) == -1 and b"bad sizes" in L.hopmi_last_error()
+    assert L.hopmi_colsum(None, 7, 4, 4, None, None, None) == -1 and b"dtype" in L.hopmi_last_error()
+    one = ctypes.c_void_p(16)                       # (never dereferenced: the checks come first)
+    assert L.hopmi_reprog_attn_fwd_dt(one, one, one, one, 2, one, one, 4, 4, 8, 128, 0.1, 0.0, 0, None, None) == -1
+    assert b"dtype" in L.hopmi_last_error()
+    assert L.hopmi_reprog_attn_fwd_dt(one, one, one, one, 1, one, one, 4, 4, 8, 64, 0.1, 0.0, 0, None, None) == -1
+    assert b"head dim 128" in L.hopmi_last_error()
+
+
+def test_linear_bias_gradient_has_no_host_path():
+    """ops.linear is F.linear in the forward (any device); its bias gradient is hopmi_colsum, which host tensors cannot
+    reach: the backward raises instead of summing with torch."""
+    x = torch.randn(5, 7, requires_grad=True)
+    w = torch.randn(3, 7, requires_grad=True)
+    b = torch.randn(3, requires_grad=True)
+    y = hopmi.ops.linear(x, w, b)
+    assert torch.equal(y, torch.nn.functional.linear(x, w, b))
+    with pytest.raises(_lib.HopmiError, match="no CPU fallback"):
+        y.sum().backward()
+    with torch.no_grad():                            # no gradient wanted: plain F.linear
+        assert torch.equal(hopmi.ops.linear(x, w, b), torch.nn.functional.linear(x, w, b))
+    lin = hopmi.ops.Linear(7, 3)
+    assert isinstance(lin, torch.nn.Linear) and sorted(lin.state_dict()) == ["bias", "weight"]
+
+
 def test_discriminator_and_generator_have_no_host_path():
     """ConvDiscriminator and Model run their recurrences / graph-wavenet block in libhopmi only: host tensors raise
     instead of taking a stock-torch path (the golden comparisons of both live in the -m gpu tests)."""
