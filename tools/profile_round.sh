@@ -28,3 +28,4 @@ cd $REPO
 python3 tools/summarize_profiles.py $TAG gpurun_out
 python3 tools/summarize_stats.py $TAG bf16 gpurun_out/prof_bf16 16 "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --dtype bf16  (configs[2] per GPU: TED V=9, B=128, bf16; 1x MI355X)"
 python3 tools/summarize_stats.py $TAG v42 gpurun_out/prof_v42 16 "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --dataset TED_expressive --batch 64  (configs[3]: V=42, B=64, fp32; 1x MI355X)"
+# (GAN phase: rocprofv3 --kernel-trace --stats ... -d gpurun_out/prof_gan -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --epoch 11, then summarize_stats.py $TAG gan gpurun_out/prof_gan 16 "...")
