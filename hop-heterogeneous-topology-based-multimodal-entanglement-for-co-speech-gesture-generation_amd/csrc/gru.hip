@@ -553,6 +553,98 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small hidden sizes (the discriminator's GRU: hidden 64, multimodal_context_net.py:236-237): W_hh of one direction
+// (3 x 64 x 64) fits the registers of ONE workgroup, so nothing has to cross workgroups: workgroup = (16 batch rows,
+// direction), all T steps; wave w owns units [16 w, 16 w + 16) of the three gates (24 resident split fragments);
+// h_{t-1} goes through a double-buffered fp32 LDS panel (one barrier per step), h_t of the wave's own units stays in
+// registers for the z h_{t-1} term.  A step is 18 MFMAs per wave + the gate math; measured 1.3 us per step (36 us per
+// layer at T = 28) against the 1.7-2.1 us of cross-workgroup hand-off the persistent kernel pays per step at this size.
+// The input projections of the next GS_AHEAD steps are kept in flight.  (Measured and without effect on the 1.3 us: a raw
+// s_barrier behind lgkmcnt(0) instead of __syncthreads(), and a chunked double buffer of the projections that keeps every
+// memory wait out of the loop body -- the step is not waiting on memory; where the time goes is the next thing to stamp.)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GS_H = 64, GS_LD = 68, GS_AHEAD = 4;
+
+template <typename TG>
+__global__ __launch_bounds__(256) void gru_fwd_small_kernel(const TG* __restrict__ gi, const float* __restrict__ whh,
+                                                            const float* __restrict__ bhh, float* __restrict__ y,
+                                                            float* __restrict__ gates, int B, int T) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][16][GS_LD];
+  constexpr int H = GS_H;
+  const int d = blockIdx.x & 1, b0 = (blockIdx.x >> 1) * 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
+  const int j = 16 * w + i;                                            // this lane's unit (C layout column)
+  u32x4 wh[3][2], wl[3][2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float* wrow = whh + ((size_t)(d * 3 + g) * H + j) * H;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const Split8 f = load_w_frag(wrow, 32 * ks + 8 * q, H);
+      wh[g][ks] = f.hi; wl[g][ks] = f.lo;
+    }
+  }
+  float e_bhh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) e_bhh[g] = bhh[(d * 3 + g) * H + j];
+  int brow[4];                                                         // batch rows of this lane's 4 accumulator rows (clamped)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) brow[r] = min(b0 + 4 * q + r, B - 1);
+  float h_own[4] = {0.f, 0.f, 0.f, 0.f};
+  float gbuf[GS_AHEAD][4][3];                                          // input projections of the steps in flight
+  auto fetch = [&](int slot, int s) {
+    const int t = d ? T - 1 - s : s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const TG* gip = gi + (((size_t)brow[r] * T + t) * 2 + d) * 3 * H + j;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gbuf[slot][r][g] = (float)gip[g * H];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < GS_AHEAD; ++u)
+    if (u < T) fetch(u, u);
+
+  for (int s0 = 0; s0 < T; s0 += GS_AHEAD) {
+#pragma unroll
+    for (int u = 0; u < GS_AHEAD; ++u) {
+      const int s = s0 + u;
+      if (s < T) {                                                     // (uniform over the workgroup)
+        const int t = d ? T - 1 - s : s;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = {e_bhh[g], e_bhh[g], e_bhh[g], e_bhh[g]};
+        if (s > 0) {
+          const float* hp = &hbuf[(s - 1) & 1][i][8 * q];
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const Split8 a = split8(*reinterpret_cast<const float4*>(hp + 32 * ks), *reinterpret_cast<const float4*>(hp + 32 * ks + 4));
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = mfma_split3(a.hi, a.lo, wh[g][ks], wl[g][ks], acc[g]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gr = sigmoidf_(gbuf[u][r][0] + acc[0][r]);
+          const float gz = sigmoidf_(gbuf[u][r][1] + acc[1][r]);
+          const float gn = tanhf_(gbuf[u][r][2] + gr * acc[2][r]);
+          h_own[r] = (1.f - gz) * gn + gz * h_own[r];
+          hbuf[s & 1][4 * q + r][j] = h_own[r];
+          const int b = b0 + 4 * q + r;
+          if (b < B) {
+            y[((size_t)b * T + t) * 2 * H + d * H + j] = h_own[r];
+            float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
+            gp[0] = gr; gp[H] = gz; gp[2 * H] = gn; gp[3 * H] = acc[2][r];
+          }
+        }
+        if (s + GS_AHEAD < T) fetch(u, s + GS_AHEAD);
+        __syncthreads();                                               // h_s visible; everyone is done with h_{s-1}'s buffer
+      }
+    }
+  }
+}
+
 // Persistent BPTT: same structure.  The workgroup's W_hh^T fragments (K = 3 gate blocks of H) stay in registers, the
 // dgh rows of all three gate blocks are staged at once (83 KB of LDS at H = 350), dgi and the D z carry stay private.
 template <int MAXK2, typename TG>
@@ -742,6 +834,11 @@ static int gru_fwd_impl(const TG* gi, const float* whh, const float* bhh, float*
   const void* ptrs[] = {gi, whh, bhh, y, gates};
   if (int e = gru_validate(ptrs, 5, B, T, H)) return e;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (H == GS_H && env_int("HOPMI_GRU_SMALL", 1) != 0) {               // one workgroup per (16 rows, direction): no hand-off
+    if (ws != nullptr) gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), nullptr, 0, st);                      // status = 0
+    hipLaunchKernelGGL((gru_fwd_small_kernel<TG>), dim3(2 * ((B + 15) / 16)), dim3(256), 0, st, gi, whh, bhh, y, gates, B, T);
+    return check_launch("hopmi_gru_fwd(small)");
+  }
   if (gru_persistent_ok(B, H, ws)) {
     const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
     int* status = gru_status_word(ws, B, T, H);
