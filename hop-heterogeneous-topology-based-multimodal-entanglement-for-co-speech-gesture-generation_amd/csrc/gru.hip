@@ -29,8 +29,9 @@ constexpr int RED_LD = 49;     // LDS stride of the [32][48] partial tiles
 
 // gate non-linearities on the hardware exp / rcp (v_exp_f32, v_rcp_f32): absolute error ~1e-7, far inside the 1e-3 bar;
 // the libm expf / tanhf made the gate epilogue 30 % of a recurrence step (tools/probes/gru_stamps.py)
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+// (__builtin_amdgcn_rcpf IS v_rcp_f32, 1 ulp; __frcp_rn expands to the ten-instruction IEEE division sequence)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 // XCD-aware work mapping (speed only; any placement is correct).  Workgroups are dealt round-robin over
 // the 8 XCDs by linear id, and each XCD has a private 4 MiB L2.  A "slice" = (unit block jb, direction):

@@ -29,14 +29,15 @@ namespace hopmi {
 
 constexpr int WN_FIN_G = 16;     // workgroups of the BatchNorm finalisation (wn_bn_finalize_kernel)
 
-// gate non-linearities on the hardware exp (v_exp_f32): absolute error ~1e-7, far inside the 1e-3 bar
-__device__ __forceinline__ float sigmoid_(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanh_(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+// gate non-linearities on the hardware exp and reciprocal (v_exp_f32, v_rcp_f32 through __builtin_amdgcn_rcpf: 1 ulp;
+// __frcp_rn expands to the ten-instruction IEEE division sequence): absolute error ~1e-7, far inside the 1e-3 bar
+__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 // u = tanh(a) sigmoid(g) = (1 - e^-2a) / ((1 + e^-2a)(1 + e^-g)) with ONE reciprocal; the exponents are clamped so that
 // the denominator stays finite (tanh(-22) = -1 and sigmoid(-44) = 8e-20 to fp32 precision)
 __device__ __forceinline__ float gate_(float a, float g) {
   const float ea = __expf(fminf(-2.f * a, 44.f)), eg = __expf(fminf(-g, 44.f));
-  return (1.f - ea) * __frcp_rn((1.f + ea) * (1.f + eg));
+  return (1.f - ea) * __builtin_amdgcn_rcpf((1.f + ea) * (1.f + eg));
 }
 
 // ---- weight images -----------------------------------------------------------------------------------------------
