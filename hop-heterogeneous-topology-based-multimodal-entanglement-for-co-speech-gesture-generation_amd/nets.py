@@ -164,8 +164,8 @@ class ConvDiscriminator(nn.Module):
             nn.Conv1d(16, 8, 3), nn.BatchNorm1d(8), nn.LeakyReLU(True),
             nn.Conv1d(8, 8, 3))
         self.gru = nn.GRU(8, hidden_size=self.hidden_size, num_layers=4, bidirectional=True, dropout=0.3, batch_first=True)
-        self.out = nn.Linear(self.hidden_size, 1)
-        self.out2 = nn.Linear(28, 1)
+        self.out = ops.Linear(self.hidden_size, 1)
+        self.out2 = ops.Linear(28, 1)
 
     @staticmethod
     def _conv3_cl(x, conv):
@@ -173,7 +173,7 @@ class ConvDiscriminator(nn.Module):
         (MIOpen's im2col path runs these tiny convs per sample: ~440 launches per training step)."""
         T = x.shape[1] - 2
         w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, -1)          # (O, 3*C), tap-major
-        return torch.nn.functional.linear(torch.cat([x[:, 0:T], x[:, 1:T + 1], x[:, 2:T + 2]], dim=2), w, conv.bias)
+        return ops.linear(torch.cat([x[:, 0:T], x[:, 1:T + 1], x[:, 2:T + 2]], dim=2), w, conv.bias)
 
     @staticmethod
     def _bn_cl(x, bn, training):
