@@ -94,6 +94,8 @@ class _Capture:
 
     def begin(self):
         self.graph = torch.cuda.CUDAGraph()
+        if self.owner.debug:
+            self.graph.enable_debug_mode()            # keeps the hipGraph_t behind the executable graph (dump_graphs)
         self.graph.capture_begin(pool=self.owner._pool)
 
     def end(self):
@@ -134,11 +136,12 @@ class _Capture:
 
 class GraphedTrainStep:
     def __init__(self, args, model, discriminator, model_optim, dis_optimizer, accelerator=None, group=None,
-                 eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False):
+                 eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False, debug=False):
         """`accelerator`: what the eager calls hand to train_llm (a GradSync when more than one rank trains; default a
         plain backward).  `grad_dtype=torch.bfloat16` halves the bytes of the flat gradient exchanges (the sums still
         land in fp32 gradients).  `enabled=False` makes every call the eager step (for A/B runs).  `force_exchange` runs
-        the collectives of the N > 1 recording on a 1-rank group too (rehearsal on a single-GPU box)."""
+        the collectives of the N > 1 recording on a 1-rank group too (rehearsal on a single-GPU box).  `debug=True` keeps
+        the recorded hipGraphs inspectable (`dump_graphs`)."""
         self.args, self.model, self.disc = args, _steps._unwrap(model), _steps._unwrap(discriminator)
         self.g_opt, self.d_opt = model_optim, dis_optimizer
         self.group = group
@@ -149,6 +152,7 @@ class GraphedTrainStep:
         self.eager_left = eager_calls
         self.grad_dtype = grad_dtype
         self.enabled = enabled
+        self.debug = debug
         self.records = {}
         self.n_eager = self.n_replay = 0            # calls served by steps.train_llm itself / by a replay
         self.sharded = False
@@ -237,8 +241,9 @@ class GraphedTrainStep:
             dS = self._S.grad
             with torch.no_grad():
                 if dS is not None:
-                    mapping_grad_rows(dS, m.word_embeddings, self.r0, self.r1, self._Wg, self._bg,
-                                      bf16=torch.is_autocast_enabled())
+                    # (the step's precision, not the ambient autocast state: this runs behind train_llm's autocast block)
+                    bf16 = (getattr(self.args, "mixed_precision", None) or _steps._MIXED) == "bf16"
+                    mapping_grad_rows(dS, m.word_embeddings, self.r0, self.r1, self._Wg, self._bg, bf16=bf16)
             m.mapping_layer.weight.grad, m.mapping_layer.bias.grad = self._Wg, self._bg
 
     # -- capture -----------------------------------------------------------------------------------------------------
@@ -277,7 +282,6 @@ class GraphedTrainStep:
         cur.wait_stream(self._stream)
         if cap.fetch is None:
             raise RuntimeError("hopmi GraphedTrainStep: the recorded step never fetched its losses")
-        self.sharded = self.sharded or (self.world > 1 and self._has_proto)
         return dict(cap=cap, static=static, terms=cap.fetch.terms, n_vals=len(cap.fetch.terms) + 1)
 
     # -- call --------------------------------------------------------------------------------------------------------
@@ -308,8 +312,27 @@ class GraphedTrainStep:
             else:
                 x()
         self._mark_written()
+        # every replay of an N > 1 recording updates only this rank's rows of the mapping layer (and their Adam moments): the
+        # copies are sharded again after ANY replay, also one that follows an unshard() (no new capture happens then)
+        self.sharded = self.world > 1 and self._has_proto
         self._event.synchronize()
         return _steps._LossFetch.decode(rec["terms"], self._host[:rec["n_vals"]].tolist(), True)
+
+    def dump_graphs(self, directory):
+        """Write every recorded graph segment as a DOT file (hipGraphDebugDotPrint; needs `debug=True`) and return the paths:
+        what tests/test_gpu_graph.py reads to check which node types a recording holds."""
+        import os
+        if not self.debug:
+            raise RuntimeError("hopmi GraphedTrainStep.dump_graphs: construct with debug=True")
+        os.makedirs(directory, exist_ok=True)
+        paths = []
+        for r, rec in enumerate(self.records.values()):
+            for k, (kind, x) in enumerate(rec["cap"].plan):
+                if kind == "graph":
+                    path = os.path.join(directory, f"rec{r}_seg{k:02d}.dot")
+                    x.debug_dump(path)
+                    paths.append(path)
+        return paths
 
     def _eager(self, epoch, batch):
         self.n_eager += 1
@@ -344,12 +367,31 @@ class _PlainBackward:
 
 
 def _make_capturable(opt):
-    """A captured optimizer step needs its step counters on the device (torch.optim `capturable=True`)."""
+    """A captured optimizer step needs its step counters on the device (torch.optim `capturable=True`) and -- the point
+    of doing this BEFORE anything is recorded -- its state to exist: torch creates `step`, `exp_avg` and `exp_avg_sq`
+    lazily in the first `step()` that sees a gradient (`Adam._init_group`), with `torch.zeros` / `zeros_like`.  Inside a
+    capture those zero fills would be recorded and run again on every replay (moments and step count reset every step:
+    the update degenerates to lr * sign(g)).  That is what would happen to the discriminator's optimizer, which never
+    steps before epoch 11 (train_llm.py:15-36), when the first GAN-phase call is the one that records; and to both
+    optimizers with `eager_calls=0`.  Parameters that never receive a gradient get state too; `_init_group` skips a
+    parameter whose `.grad` is None regardless of its state, so they stay untouched."""
     if not isinstance(opt, (torch.optim.Adam, torch.optim.AdamW)):
         raise TypeError("hopmi GraphedTrainStep: only torch.optim.Adam / AdamW steps are recorded "
                         f"(got {type(opt).__name__}); use train_llm for other optimizers")
     for g in opt.param_groups:
         g["capturable"] = True
-    for p, st in opt.state.items():
-        if "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
-            st["step"] = st["step"].to(p.device)
+        for p in g["params"]:
+            if not p.requires_grad:
+                continue
+            st = opt.state[p]
+            if "step" not in st:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if g.get("amsgrad", False):
+                    st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif torch.is_tensor(st["step"]):
+                if st["step"].device != p.device:
+                    st["step"] = st["step"].to(p.device)
+            else:
+                st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32, device=p.device)

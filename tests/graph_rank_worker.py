@@ -65,12 +65,12 @@ def main():
 
     graphed._after_backward = after_backward_with_status
     losses1, losses2 = [], []
-    # The two paths run one after the other, not step by step in turn.  Interleaved (an eager train_llm step of the OTHER
-    # model copy between two replays), the GAN-phase recording's value-projection bias gradient went wrong from its third
-    # replay on in this two-ranks-on-one-GPU gloo rehearsal, while each path alone, in either order, reproduces the plain
-    # all-reduce-every-gradient reference to 1e-8 (platform findings); a training loop never interleaves two
-    # models' steps, so the comparison is made on what it does.
-    if os.environ.get("HOPMI_WORKER_INTERLEAVE"):         # diagnostic: the order that showed the fault described above
+    # Two orders (argv[2]): "sequential" runs the two paths one after the other, "interleaved" queues an eager train_llm step
+    # of the OTHER model copy between two replays.  Round 2 found a wrong gradient in the interleaved order (the GAN-phase
+    # recording's value-projection bias gradient, a torch multi-block reduction behind a semaphore memset NODE, from the third
+    # replay on); the recording holds no memset node any more (tests/test_gpu_graph.py::test_recorded_step_has_no_memset_nodes)
+    # and the interleaved order is a required test.
+    if len(sys.argv) > 2 and sys.argv[2] == "interleaved" or os.environ.get("HOPMI_WORKER_INTERLEAVE"):
         for it in range(4):
             losses1.append(hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, sync1))
             if os.environ.get("HOPMI_WORKER_SYNC_BEFORE"):
@@ -113,6 +113,33 @@ def main():
     allcs = [torch.empty_like(cs) for _ in range(world)]
     dist.all_gather(allcs, cs)
     spread = max((c - allcs[0]).abs().max().item() for c in allcs)
+    # phase 2 -- replays AFTER an unshard() shard the mapping layer again (each rank only updates its rows); an eager call
+    # that follows (a short last batch) and a later unshard() must both see that.  Same steps on the GradSync pair.
+    for it in range(2):
+        graphed(epoch, *batch)
+    for it in range(2):
+        hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, sync1)
+    resharded = bool(graphed.sharded)
+    stale2 = (m2.mapping_layer.weight - m1.mapping_layer.weight).abs().max().item()
+    short = tuple(t[:1].contiguous() for t in batch)
+    n_eager_before = graphed.n_eager
+    graphed(epoch, *short)                                   # another batch shape: the eager step, which unshards first
+    hopmi.train_llm(args, epoch, *short, m1, d1, g1, o1, sync1)
+    short_was_eager = graphed.n_eager == n_eager_before + 1 and not graphed.sharded
+    graphed(epoch, *batch)                                   # ... and one more replay, then an explicit unshard()
+    hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, sync1)
+    graphed.unshard()
+    worst2 = {}
+    for (n, a), (_, b) in zip(list(m1.named_parameters()) + list(d1.named_parameters()),
+                              list(m2.named_parameters()) + list(d2.named_parameters())):
+        diff = (a - b).abs()
+        worst2[n] = (diff.max().item(), diff.mean().item())
+    cs = torch.tensor([p.double().sum().item() for p in list(m2.parameters()) + list(d2.parameters())] +
+                      [g2.state[p][k].double().sum().item() for p in (m2.mapping_layer.weight, m2.mapping_layer.bias) for k in ("exp_avg", "exp_avg_sq")],
+                      dtype=torch.float64)
+    allcs = [torch.empty_like(cs) for _ in range(world)]
+    dist.all_gather(allcs, cs)
+    spread2 = max((c - allcs[0]).abs().max().item() for c in allcs)
     # (after every comparison: these two calls train m2 further)
     # a hand-off time-out on rank 1 only: its status rides on the gradient exchange of that replay, and the NEXT call's loss
     # fetch raises on both ranks (rank 0 learns of it from the exchange alone)
@@ -135,7 +162,10 @@ def main():
                                         worst_max=max(v[0] for v in worst.values()), worst_mean=max(v[1] for k, v in worst.items() if not noise(k)),
                                         worst_mean_name=max((k for k in worst if not noise(k)), key=lambda k: worst[k][1]),
                                         worst_name=max(worst, key=lambda k: worst[k][0]), replica_spread=spread,
-                                        stopped_at=stopped_at,
+                                        stopped_at=stopped_at, resharded=resharded, stale_before_short_batch=stale2,
+                                        short_was_eager=short_was_eager, replica_spread2=spread2,
+                                        worst2_max=max(v[0] for v in worst2.values()),
+                                        worst2_mean=max(v[1] for k, v in worst2.items() if not noise(k)),
                                         top_mean=sorted(((round(v[1], 7), k) for k, v in worst.items() if not noise(k)), reverse=True)[:6])),
           flush=True)
     dist.barrier()

@@ -222,12 +222,15 @@ def test_graphed_step_dropout_advances(monkeypatch):
     assert len(set(losses[1:])) >= 4, losses
 
 
-@pytest.mark.parametrize("epoch", [0, 11])
-def test_graphed_exchange_two_ranks_one_gpu(epoch):
+@pytest.mark.parametrize("epoch,order", [(0, "sequential"), (11, "sequential"), (0, "interleaved"), (11, "interleaved")])
+def test_graphed_exchange_two_ranks_one_gpu(epoch, order):
     """The N > 1 recording (prototype rows sharded over ranks, S all-gathered, dS + the other gradients all-reduced by
     eager collectives between graph launches) with two ranks sharing cuda:0 over gloo, against the hook-driven GradSync
     exchange under steps.train_llm on copies of the same models: same losses every step, same parameters after
-    unshard(), and identical replicas across the ranks (tests/graph_rank_worker.py)."""
+    unshard(), and identical replicas across the ranks (tests/graph_rank_worker.py).  `order`: the two paths one after the
+    other, or an eager step of the other model copy queued between every two replays (the order in which round 2 saw a wrong
+    gradient).  Then the sequence replay / unshard() / replay / short batch through the eager step / replay / unshard():
+    every replay shards the mapping layer again, the eager step and unshard() must notice, the replicas stay identical."""
     import json
     import os
     import subprocess
@@ -235,7 +238,7 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + epoch), os.path.join(root, "tests", "graph_rank_worker.py"), str(epoch)]
+           "--master-port", str(29600 + epoch + (50 if order == "interleaved" else 0)), os.path.join(root, "tests", "graph_rank_worker.py"), str(epoch), order]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     dec = json.JSONDecoder()          # (the two ranks' lines can arrive glued together)
@@ -255,6 +258,261 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch):
         assert row["replica_spread"] <= 1e-6, row
         # a status word set on rank 1 alone stopped BOTH ranks, at the same call (rank 0 learns of it from the exchange only)
         assert row["stopped_at"] == (0 if epoch > 10 else 1), row["stopped_at"]
+        # phase 2: the replays after the first unshard() sharded the copies again, and both later consumers noticed
+        assert row["resharded"] and row["stale_before_short_batch"] > 1e-4 and row["short_was_eager"], row
+        assert row["replica_spread2"] <= 1e-6, row["replica_spread2"]
+        assert row["worst2_max"] <= 9e-3 and row["worst2_mean"] <= 4e-5, {k: row[k] for k in ("worst2_max", "worst2_mean")}
+
+
+# ----------------------------------------------------------------- the recorded step at the sizes bench.py times
+class _Draws:
+    """The step's random draws as STATIC device tensors: a recording reads them by address, so each call's values are put
+    there before the call, taken from torch's CPU generator in the oracle's order (ref_cpu.train_llm_step: per generator
+    forward one (B,16) `eps`; in the GAN phase two `noise` tensors for add_noise; one `perm`)."""
+
+    def __init__(self, B, V, gan, dev):
+        self.spec = ([("eps", (B, 16)), ("noise", (B, 34, 3 * V)), ("noise", (B, 34, 3 * V))] if gan else []) + \
+                    [("eps", (B, 16)), ("perm", (B,)), ("eps", (B, 16))]
+        self.slots = [torch.empty(shape, dtype=torch.int64 if kind == "perm" else torch.float32, device=dev) for kind, shape in self.spec]
+        self.i = 0
+
+    def refill(self):
+        for (kind, shape), t in zip(self.spec, self.slots):
+            t.copy_(torch.randperm(shape[0]) if kind == "perm" else torch.randn(shape))
+        self.i = 0
+
+    def take(self, kind, shape):
+        k, want = self.spec[self.i]
+        assert k == kind and tuple(shape) == tuple(want), (self.i, kind, tuple(shape), self.spec[self.i])
+        t = self.slots[self.i]
+        self.i += 1
+        return t
+
+    def install(self, model, monkeypatch):
+        from hopmi import steps
+        model._randn_like = lambda t: self.take("eps", t.shape)
+        monkeypatch.setattr(steps, "_randn_like", lambda t: self.take("noise", t.shape))
+        monkeypatch.setattr(steps, "_randperm", lambda n, device: self.take("perm", (n,)))
+
+
+@pytest.mark.parametrize("V,B,epoch", [(9, 128, 0), (42, 64, 11)])
+def test_graphed_step_baseline_size_vs_oracle(V, B, epoch, monkeypatch):
+    """What bench.py times, against the oracle: hopmi.GraphedTrainStep at BASELINE.json configs[1] (TED, B = 128, epoch 0)
+    and configs[3] in the GAN phase (TED-Expressive, V = 42, B = 64, epoch 11) with bench.py's set-up -- fused Adam (its
+    capturable form under the recording), the shipped TunableOp GEMM table, the first call recording (eager_calls = 0: the
+    optimizers' state has to exist before the capture) -- one capture + three replays.  The oracle advances the same four
+    steps on the host from the same random stream.  Compared exactly as test_train_llm_baseline_size_vs_oracle compares
+    the eager step: every step's loss dict, the last step's graded outputs, the BatchNorm running statistics after all
+    forwards of all steps, post-step checksums of generator and discriminator parameters."""
+    import hopmi
+    from oracle.golden_util import checksum, checksum_close, step_args
+    from test_gpu_parity import RTOL, _div_reg_tol, _full_size_setup, _oracle_full_step, assert_close, rel_err
+    dev = _dev()
+    n_steps = 4
+    m, d, bcfg, inp = _full_size_setup(V, B)
+    o = _oracle_full_step(V, B, epoch, bcfg, inp, n_steps=n_steps)
+    m.to(dev).train(); d.to(dev).train()
+    gan = epoch > 10
+    draws = _Draws(B, V, gan, dev)
+    draws.install(m, monkeypatch)
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999), fused=True)
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999), fused=True)
+    gin = {k: v.to(dev) for k, v in inp.items()}
+    batch = (gin["in_audio"], gin["log_melspec"], gin["text"], gin["target_dir_vec"], gin["vid_indices"])
+    graded = []          # the graded forward's output tensor: recorded once, rewritten in place by every replay
+    hook = m.register_forward_hook(lambda mod, args, out: graded.append(out[0]) if torch.is_grad_enabled() else None)
+    tuned = hopmi.use_tuned_gemms()
+    assert tuned, "the shipped TunableOp table is missing"
+    graphed = hopmi.GraphedTrainStep(step_args(V), m, d, g_opt, d_opt, eager_calls=0)
+    torch.manual_seed(777)
+    rets = []
+    try:
+        for it in range(n_steps):
+            draws.refill()
+            rets.append(graphed(epoch, *batch))
+        torch.cuda.synchronize()
+    finally:
+        hook.remove()
+        import torch.cuda.tunable as tunable
+        tunable.enable(False)
+    assert graphed.n_eager == 0 and graphed.n_replay == n_steps and len(graded) == 1
+    out = graded[0].detach().float().cpu()
+    eps_out = rel_err(out, o["out"])
+    # four Adam steps: an element whose gradient is at rounding level may step the other way on either side (DESIGN.md 2),
+    # +-2 lr on a few elements per step; the outputs of step 4 see the sum of those walks.  Bar: the north_star's 1e-3.
+    assert eps_out <= RTOL, f"outputs (step {n_steps}) rel err {eps_out:.3e}"
+    div_tol, cond = _div_reg_tol(eps_out, o)
+    for it, (ret, want) in enumerate(zip(rets, o["rets"])):
+        assert sorted(ret.keys()) == sorted(want.keys()), (it, ret, want)
+        for k in want:
+            tol = RTOL if k != "DIV_REG" else div_tol
+            assert abs(ret[k] - want[k]) <= tol * max(abs(want[k]), 1e-6), (it, k, ret[k], want[k], f"eps_out {eps_out:.2e} cond {cond:.1f}")
+    sd = m.state_dict()
+    for k, v in o["bn"].items():
+        assert_close(sd[k], v, what=k)
+    for n, v in o["params"].items():
+        a, b = checksum(sd[n]), checksum(v)
+        assert checksum_close(a, b, RTOL, n_steps * 2e-3 * 64), (n, a, b)
+    if gan:
+        dsd = d.state_dict()
+        for n, v in o["dparams"].items():
+            a, b = checksum(dsd[n]), checksum(v)
+            assert checksum_close(a, b, RTOL, n_steps * 2e-4 * 64), (n, a, b)
+        # the discriminator's optimizer state was created before the capture, not inside it: its step counters count replays
+        for p in d.parameters():
+            assert float(d_opt.state[p]["step"]) == n_steps
+    for p in m.parameters():
+        if p.requires_grad and p.grad is not None:
+            assert float(g_opt.state[p]["step"]) == n_steps
+
+
+def test_graphed_step_epoch_10_to_11_transition(monkeypatch):
+    """A training run crosses from epoch 10 to epoch 11 with the generator's recording already in use: the first GAN-phase
+    call is recorded directly (no eager call left), and it is the first time the discriminator's optimizer steps
+    (train_llm.py:15-36).  Its Adam state must come from outside the recording: step counters count the GAN-phase steps and
+    the parameters follow the eager path (a state created under capture is re-zeroed by every replay)."""
+    import hopmi
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m1, d1, inp = _pair(9, dev)
+    m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
+    m2._randn_like = m1._randn_like
+    mk = lambda m, d: (torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999)),
+                       torch.optim.Adam(d.parameters(), lr=1e-3, betas=(0.5, 0.999)))
+    g1, o1 = mk(m1, d1)
+    g2, o2 = mk(m2, d2)
+    args = step_args(9)
+    batch = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"], inp["vid_indices"])
+    graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, eager_calls=1)
+    epochs = [10, 10, 10, 11, 11, 11, 11]
+    for it, epoch in enumerate(epochs):
+        want = hopmi.train_llm(args, epoch, *batch, m1, d1, g1, o1, Accel())
+        got = graphed(epoch, *batch)
+        assert sorted(got) == sorted(want), (it, got, want)
+        for k in want:
+            assert abs(got[k] - want[k]) <= 2e-4 * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])
+    assert graphed.n_eager == 1 and len(graphed.records) == 2
+    n_gan = sum(e > 10 for e in epochs)
+    for (n, a), (_, b) in zip(d1.named_parameters(), d2.named_parameters()):
+        assert float(o2.state[b]["step"]) == n_gan == float(o1.state[a]["step"]), n
+        ea, eb = o1.state[a]["exp_avg"], o2.state[b]["exp_avg"]
+        if not n.startswith("pre_conv.") or not n.endswith(".bias"):      # (analytically zero gradients: rounding noise)
+            assert (ea - eb).abs().max().item() <= 1e-3 * ea.abs().max().item() + 1e-9, n
+        diff = (a - b).abs()
+        assert diff.max().item() <= 4.5e-3 and diff.mean().item() <= 1e-3, (n, diff.max().item(), diff.mean().item())
+
+
+def _dot_node_types(path):
+    """Node labels of a hipGraphDebugDotPrint file -> list of lower-cased label strings (one per node)."""
+    import re
+    text = open(path).read()
+    return [lab.lower() for lab in re.findall(r'\[[^\]]*label\s*=\s*"([^"]*)"', text)]
+
+
+@pytest.mark.parametrize("epoch,dtype", [(0, "fp32"), (11, "fp32"), (11, "bf16")])
+def test_recorded_step_has_no_memset_nodes(epoch, dtype, tmp_path, monkeypatch):
+    """Structural guard for the replay faults of DESIGN.md 5: in a replay, a memset NODE is not reliably ordered in front of
+    the kernel node that depends on it once other work is queued on the stream between replays (seen twice: the persistent
+    GRU's counters, and the semaphore memset of a torch multi-block reduction whose result then came out wrong).  The
+    recording therefore holds no memset node at all: hopmi's own kernels initialise their state with kernels, and every
+    torch reduction that would split over blocks (column sums of tall matrices, var_mean over a batch) goes through
+    hopmi_colsum / hopmi's own kernels.  Checked at the sizes where torch's reductions do split: configs[1], B = 128,
+    6-layer BERT-base, both phases, fp32 and bf16."""
+    import hopmi
+    from oracle.golden_util import step_args
+    from test_gpu_parity import _full_size_setup
+    dev = _dev()
+    V, B = 9, 128
+    m, d, bcfg, inp = _full_size_setup(V, B)
+    m.to(dev).train(); d.to(dev).train()
+    g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999), fused=True)
+    d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999), fused=True)
+    gin = {k: v.to(dev) for k, v in inp.items()}
+    batch = (gin["in_audio"], gin["log_melspec"], gin["text"], gin["target_dir_vec"], gin["vid_indices"])
+    prev = hopmi.mixed_precision(None if dtype == "fp32" else dtype)
+    try:
+        graphed = hopmi.GraphedTrainStep(step_args(V), m, d, g_opt, d_opt, eager_calls=1, debug=True)
+        for _ in range(3):
+            graphed(epoch, *batch)
+        torch.cuda.synchronize()
+    finally:
+        hopmi.mixed_precision(prev)
+    paths = graphed.dump_graphs(str(tmp_path))
+    assert paths
+    n_nodes, memsets = 0, []
+    for path in paths:
+        labels = _dot_node_types(path)
+        n_nodes += len(labels)
+        memsets += [(path.rsplit("/", 1)[-1], lab[:120]) for lab in labels if "memset" in lab]
+    assert n_nodes > 500, n_nodes                    # the dump really lists the step's launches
+    assert not memsets, memsets[:20]
+
+
+@pytest.mark.parametrize("epoch", [0, 11])
+def test_graphed_step_soak_interleaved_with_eager_work(epoch, monkeypatch):
+    """50 replays of the recorded step at configs[1] size (B = 128, 6-layer BERT-base: the size at which torch's reductions
+    split over blocks), with an eager evaluation forward of the SAME model and an eager training step of ANOTHER model copy
+    queued between replays and no synchronisation in between -- what a training loop does around validation, short last
+    batches and unshard().  Learning rate 0 and constant draws keep the weights fixed, so that every gradient tensor of every
+    replay can be compared with an all-eager twin's on the same batch: bit for bit (same deterministic kernels, same
+    inputs), except the mapping layer's weight gradient, which the recording forms with its own GEMM call (1e-6)."""
+    import hopmi
+    from oracle.golden_util import Accel, step_args
+    from test_gpu_parity import _full_size_setup
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    V, B = 9, 128
+    m, d, bcfg, inp = _full_size_setup(V, B)
+    const = lambda t: torch.full_like(t, 0.25)
+    m._randn_like = const
+    m.to(dev).train(); d.to(dev).train()
+    twin_m, twin_d = copy.deepcopy(m), copy.deepcopy(d)
+    other_m, other_d = copy.deepcopy(m), copy.deepcopy(d)
+    for mm in (twin_m, other_m):
+        mm._randn_like = const
+    mk = lambda mm, dd, lr: (torch.optim.Adam([p for p in mm.parameters() if p.requires_grad], lr=lr, betas=(0.5, 0.999)),
+                             torch.optim.Adam(dd.parameters(), lr=lr, betas=(0.5, 0.999)))
+    g_opt, d_opt = mk(m, d, 0.0)
+    tg, td = mk(twin_m, twin_d, 0.0)
+    og, od = mk(other_m, other_d, 1e-3)                       # the bystander really trains
+    args = step_args(V)
+    names = ("in_audio", "log_melspec", "text", "target_dir_vec", "vid_indices")
+    gen = torch.Generator().manual_seed(11)
+    batches = []
+    for k in range(3):
+        batches.append(tuple((inp[n] + 0.05 * k * torch.randn(inp[n].shape, generator=gen)).to(dev) if inp[n].is_floating_point()
+                             else inp[n].roll(k, 0).to(dev) for n in names))
+    graphed = hopmi.GraphedTrainStep(args, m, d, g_opt, d_opt, eager_calls=1)
+    pairs = [(n, a, b) for (n, a), (_, b) in zip(list(m.named_parameters()) + list(d.named_parameters()),
+                                                 list(twin_m.named_parameters()) + list(twin_d.named_parameters())) if a.requires_grad]
+    bad = []
+    n_iter = 52
+    for it in range(n_iter):
+        b = batches[it % 3]
+        got = graphed(epoch, *b)
+        # -- queued behind the replay, no synchronisation: a training step of another model copy, an evaluation of this one
+        hopmi.train_llm(args, epoch, *batches[(it + 1) % 3], other_m, other_d, og, od, Accel())
+        m.eval()
+        with torch.no_grad():
+            m(b[0], b[1], b[2], b[3][:, 0:16], b[4])
+        m.train()
+        want = hopmi.train_llm(args, epoch, *b, twin_m, twin_d, tg, td, Accel())
+        torch.cuda.synchronize()
+        for k in want:
+            assert got[k] == want[k] or abs(got[k] - want[k]) <= 1e-6 * abs(want[k]), (it, k, got[k], want[k])
+        for n, a, bb in pairs:
+            if a.grad is None and bb.grad is None:
+                continue
+            assert a.grad is not None and bb.grad is not None, (it, n)
+            if n == "mapping_layer.weight":
+                ok = (a.grad - bb.grad).abs().max().item() <= 1e-6 * bb.grad.abs().max().item() + 1e-12
+            else:
+                ok = torch.equal(a.grad, bb.grad)
+            if not ok:
+                bad.append((it, n, (a.grad - bb.grad).abs().max().item(), bb.grad.abs().max().item()))
+        assert not bad, bad[:10]
+    assert graphed.n_replay >= 50
 
 
 # ------------------------------------------------------------------------------------------- input stage (feeder)

@@ -787,11 +787,13 @@ def _full_size_setup(V, B, n_spk=11):
     return m, d, bcfg, fill.hot_path_inputs(B, V, bcfg.vocab_size, n_spk)
 
 
-def _oracle_full_step(V, B, epoch, bcfg, inp, n_spk=11):
-    """The oracle's train_llm step on the host at a BASELINE.json size (cached: the fp32 and bf16 tests share it)."""
+def _oracle_full_step(V, B, epoch, bcfg, inp, n_spk=11, n_steps=1):
+    """The oracle's train_llm step(s) on the host at a BASELINE.json size (cached: the fp32, bf16 and recorded-step tests
+    share it).  `n_steps` > 1 advances the same functional state that many steps on the same batch (one CPU random
+    stream, seeded once); the returned dict describes the LAST step and carries every step's loss dict in `rets`."""
     from oracle import ref_cpu, spec
     from oracle.golden_util import hop_cfg, step_args
-    key = (V, B, epoch)
+    key = (V, B, epoch, n_steps)
     if key in _FULL:
         return _FULL[key]
     g_sd = spec.build_sd(spec.model_spec(V, bcfg, n_spk))
@@ -806,10 +808,13 @@ def _oracle_full_step(V, B, epoch, bcfg, inp, n_spk=11):
     od = torch.optim.Adam([v for v in d_sd.values() if v.requires_grad], lr=1e-4, betas=(0.5, 0.999))
     torch.manual_seed(777)
     rng = lambda kind, shape: torch.randperm(shape[0]) if kind == "perm" else torch.randn(shape)
-    want, out, _, _, out_rand = ref_cpu.train_llm_step(step_args(V), hop_cfg(V, bcfg.hidden_size), epoch, inp, g_sd, d_sd, og, od, rng,
-                                                       bert_heads=bcfg.num_attention_heads)
+    rets = []
+    for _ in range(n_steps):
+        want, out, _, _, out_rand = ref_cpu.train_llm_step(step_args(V), hop_cfg(V, bcfg.hidden_size), epoch, inp, g_sd, d_sd, og, od, rng,
+                                                           bert_heads=bcfg.num_attention_heads)
+        rets.append(want)
     keep = ("mapping_layer.weight", "gru.weight_hh_l0", "beat.0.weight", "reprogramming_layer.out_projection.weight")
-    _FULL[key] = dict(ret=want, out=out, out_rand=out_rand,
+    _FULL[key] = dict(ret=want, rets=rets, out=out, out_rand=out_rand,
                       bn={k: v.detach().clone() for k, v in g_sd.items() if ".bn." in k and "running_" in k},
                       params={k: g_sd[k].detach().clone() for k in keep},
                       dparams={k: v.detach().clone() for k, v in d_sd.items() if k in ("out.weight", "gru.weight_hh_l0")})
