@@ -553,6 +553,14 @@ static size_t wn_fwd_lds_bytes(const GcnGeom& g) {
 
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;    // hopmi_time_next_launch
 
+// the pending measurement events of this host thread (null unless hopmi_time_next_launch armed them), handed to ONE launch
+hipEvent_t wn_take_timing_events(hipEvent_t* stop) {
+  const hipEvent_t e0 = t_ev_start;
+  *stop = t_ev_stop;
+  t_ev_start = t_ev_stop = nullptr;
+  return e0;
+}
+
 template <int MT>
 static int launch_wn_fwd(const float* xin, const float* scsh, const u32x4* wimg, const float* bf, const float* bg,
                          const float* prep, const float* bm, float* y, float* fs, float* utail, int utail_ld, float* part,

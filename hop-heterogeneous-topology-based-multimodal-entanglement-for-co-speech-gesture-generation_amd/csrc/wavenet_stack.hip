@@ -1,0 +1,682 @@
+// The whole WaveNet stack of the HOP graph-wavenet block (reference: model/gwnet.py:181-237, 8 layers) as ONE persistent launch,
+// training mode (BatchNorm batch statistics):
+//
+//   for layer i:   r^ = BN_{i-1}(y_{i-1}) on load;  u = tanh(.) sigmoid(.) (gated TCN);  skip tail;  y_i = gcn(u) + r^[t+d];
+//                  per-channel sum / sum of squares of y_i  ->  EXCHANGED ACROSS ALL WORKGROUPS  ->  scale / shift of BN_i
+//
+// Training-mode BatchNorm makes every layer a chip-wide dependency: layer i + 1 of ANY clip needs the statistics of layer i over
+// ALL clips.  As eight launches that seam was a kernel boundary plus a finalisation launch per layer (8 x (10.9 + 9.8) us at
+// TED / B = 128); here it is an in-launch exchange.  Per layer every workgroup
+//   1. runs its tile(s) of the layer exactly as wn_layer_fwd_kernel does (same phases, same arithmetic), reading its rows of
+//      y_{i-1} with sc1 loads and writing y_i with sc1 (write-through) stores;
+//   2. publishes its 128 partial sums (one 512-byte row, one store instruction of one wave), drains its stores, and adds 1 to
+//      the counter of its group (group = workgroup index mod 8: the workgroups of one XCD under round-robin placement -- for
+//      speed only, nothing depends on it);
+//   3. the workgroup whose add came LAST in its group (told by the value the add returned) sums the group's rows in index order
+//      (double), publishes the group sum and adds 1 to the layer's top counter;
+//   4. every workgroup polls the top counter (one lane, sc1 loads, s_sleep), then adds the <= 8 group sums in index order and
+//      computes mean / rstd / scale / shift itself: the same numbers in every workgroup, bitwise reproducible from run to run
+//      (fixed summation order everywhere, no floating-point atomics).
+// Hand-off form (MI355X_MICROARCH.md, visibility, valid forms: sc1 payload stores, every storing wave drains, workgroup barrier,
+// ONE lane's agent-scope atomic add; consumers: sc1 poll / returned add, workgroup barrier, sc1 loads of every handed-off byte).
+// Counters are per layer (no reuse inside a launch); the workgroup that finalises the LAST layer's statistics -- by then every
+// workgroup has made all its adds and finished all its polls -- zeroes them for the next launch.  Requirements: the grid is
+// resident at once (host: grid <= occupancy x CUs).  Every spin is bounded: on time-out the workgroup raises the status word and
+// leaves the kernel, so the launch always drains (results are then garbage, the host raises on the status word).
+#include <hip/hip_ext.h>
+
+#include "bf16_dev.h"
+#include "wn_dev.h"
+
+namespace hopmi {
+
+constexpr int STK_MAX_LAYERS = 8;
+constexpr int STK_GROUPS = 8;
+constexpr int STK_THREADS = 512;
+constexpr int STK_CNT_STRIDE = 32;                 // ints: every counter on a 128-byte line of its own
+// sync block (ints): [layer][group] group counters, [layer] top counters, status word
+constexpr int STK_SYNC_INTS = (STK_MAX_LAYERS * STK_GROUPS + STK_MAX_LAYERS + 1) * STK_CNT_STRIDE;
+
+struct StackLayer {
+  const float* xin;      // (B, T_in, V, 64): x0 for layer 0, y_{i-1} after
+  float* y;              // (B, T_out, V, 64) or null (last layer: its output is dead, gwnet.py:240)
+  const float* bf; const float* bg; const float* bm;
+  const float* gamma; const float* beta;
+  float* rmean; float* rvar;       // running statistics (updated in place) or null
+  int T_in, T_out, d, n_slabs, S, ntiles;
+  float invT;
+};
+
+struct StackArgs {
+  StackLayer L[STK_MAX_LAYERS];
+  const u32x4* wimg;     // n_layers weight images (hopmi_wn_prepare_weights)
+  const float* prep;     // mix-matrix images (hopmi_gcn_prepare)
+  float* utail;          // (B, 4, V, utail_ld): layer i's skip tail at channel offset 64 i
+  float* scsh_out;       // [n_layers][128]  scale | shift of BN_i
+  float* mean_rstd;      // [n_layers][192]  mean | rstd | unbiased variance
+  int* sync;             // STK_SYNC_INTS ints, zero before the first launch (left zero by every completed launch)
+  float* part;           // [n_layers][grid][128] partial sums
+  double* gsum;          // [n_layers][STK_GROUPS][128] group sums
+  int n_layers, B, V, utail_ld4;
+  int KP, ldA, MP;       // mix-matrix image geometry (GcnGeom)
+  float invV, momentum, eps;
+};
+
+#ifdef HOPMI_STAMPS
+static __device__ long long* g_stk_stamps = nullptr;
+#define STK_STAMP(layer, slot)                                                                              \
+  do {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    unsigned long long t_;                                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (g_stk_stamps && threadIdx.x == 0) g_stk_stamps[(blockIdx.x * STK_MAX_LAYERS + (layer)) * 16 + (slot)] = (long long)t_; \
+  } while (0)
+#else
+#define STK_STAMP(layer, slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ float stk_gate(float a, float g) {       // tanh(a) sigmoid(g), one reciprocal (wavenet.hip: gate_)
+  const float ea = __expf(fminf(-2.f * a, 44.f)), eg = __expf(fminf(-g, 44.f));
+  return (1.f - ea) * __builtin_amdgcn_rcpf((1.f + ea) * (1.f + eg));
+}
+
+typedef __attribute__((address_space(8))) void* rsrc_t;        // buffer resource (V#)
+__device__ __forceinline__ auto stk_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+constexpr int AUX_SC1 = 16;                                     // gfx940+: cache-policy bit 4 = sc1 (write-through / bypass L1)
+
+// One lane waits until *p >= want (sc1 loads); false on time-out (status raised).
+__device__ __forceinline__ bool stk_poll(const int* p, int want, int* status) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+  for (;;) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {            // 2 s
+      __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// Node mix of the slabs s = h, h + 2, ... of a tile (as wavenet.hip: node_mix2; see there).
+template <int KS, int MTN, bool HOLD>
+__device__ __forceinline__ void stk_node_mix(const float* U, __bf16* Hh, __bf16* Hl, const float* AT, int V, int ldA, int nsl,
+                                             int dump_row, int w, int h, int q, int j) {
+  float am[HOLD ? MTN : 1][HOLD ? KS : 1];
+  int woff[MTN];
+#pragma unroll
+  for (int mt = 0; mt < MTN; ++mt) {
+    if (HOLD) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) am[mt][ks] = AT[(4 * ks + q) * ldA + 16 * mt + j];
+    }
+    const int m = 16 * mt + j;
+    const int blk = (m >= V) ? 1 : 0;
+    woff[mt] = (m < 2 * V) ? ((m - blk * V) * HS + C * (1 + blk) + 16 * w + 4 * q) : -1;
+  }
+  const int dump = dump_row * HS + C + 16 * w + 4 * q;
+  constexpr int SGN = HOLD ? 2 : 1;
+  int s = h;
+  for (; s + 2 * (SGN - 1) < nsl; s += 2 * SGN) {
+    float xb[SGN][KS];
+#pragma unroll
+    for (int sg = 0; sg < SGN; ++sg)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xb[sg][ks] = U[((s + 2 * sg) * V + 4 * ks + q) * LDD + 16 * w + j];
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) {
+      f32x4 acc[SGN];
+#pragma unroll
+      for (int sg = 0; sg < SGN; ++sg) acc[sg] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float b = HOLD ? am[mt][ks] : AT[(4 * ks + q) * ldA + 16 * mt + j];
+#pragma unroll
+        for (int sg = 0; sg < SGN; ++sg) acc[sg] = mfma16(xb[sg][ks], b, acc[sg]);
+      }
+#pragma unroll
+      for (int sg = 0; sg < SGN; ++sg) {
+        const int off = woff[mt] >= 0 ? (s + 2 * sg) * V * HS + woff[mt] : dump;
+        const Split4 sp = split4(acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3]);
+        *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
+        *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
+      }
+    }
+  }
+  for (; s < nsl; s += 2) {
+    float xb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[ks] = U[(s * V + 4 * ks + q) * LDD + 16 * w + j];
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma16(xb[ks], HOLD ? am[mt][ks] : AT[(4 * ks + q) * ldA + 16 * mt + j], acc);
+      const int off = woff[mt] >= 0 ? s * V * HS + woff[mt] : dump;
+      const Split4 sp = split4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
+      *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
+    }
+  }
+}
+
+__device__ __forceinline__ void stk_node_mix_generic(const float* U, __bf16* Hh, __bf16* Hl, const float* AT, int V, int ldA, int KP,
+                                                     int MP, int nsl, int w, int h, int q, int j) {
+  const int ksteps = KP >> 2, mt_n = MP >> 4;
+  for (int s = h; s < nsl; s += 2) {
+    const float* us = U + (s * V + q) * LDD + 16 * w + j;
+    for (int mt = 0; mt < mt_n; ++mt) {
+      const float* at = AT + q * ldA + 16 * mt + j;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < ksteps; ++ks) acc = mfma16(us[4 * ks * LDD], at[4 * ks * ldA], acc);
+      const int m = 16 * mt + j;
+      if (m < 2 * V) {
+        const int blk = (m >= V) ? 1 : 0;
+        const int off = (s * V + m - blk * V) * HS + C * (1 + blk) + 16 * w + 4 * q;
+        const Split4 sp = split4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
+        *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
+      }
+    }
+  }
+}
+
+// MT = the LARGEST tile (in 16-row MFMA tiles) of any layer of the launch: it fixes the LDS layout; a layer whose tiles are
+// smaller skips the MFMA tiles it does not have (wave-uniform predicates).  16-row tile mt belongs to row half mt & 1, so the
+// two halves stay balanced at every tile size.
+template <int MT>
+__global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NIT = ((16 * MT + 4) * 16 + STK_THREADS - 1) / STK_THREADS;
+  constexpr int MTH = (MT + 1) / 2;
+  constexpr int rows_lds = 16 * MT + 4;
+  __bf16* R0h = reinterpret_cast<__bf16*>(smem);
+  __bf16* R0l = R0h + rows_lds * RS;
+  __bf16* R1h = R0l + rows_lds * RS;
+  __bf16* R1l = R1h + rows_lds * RS;
+  float* U = reinterpret_cast<float*>(R1l + rows_lds * RS);
+  __bf16* Hh = reinterpret_cast<__bf16*>(U + rows_lds * LDD);
+  __bf16* Hl = Hh + rows_lds * HS;
+  float* AT = reinterpret_cast<float*>(Hl + rows_lds * HS);
+  float* SCSH = AT + A.KP * A.ldA;                                 // [128] scale | shift of the layer being read
+  int* FLAG = reinterpret_cast<int*>(SCSH + 2 * C);                // [4]
+  // exchange scratch, aliased onto the (dead between layers) operand images Hh | Hl: 2 x rows_lds x 416 B >= 16.6 KB at MT = 1
+  float* RED = reinterpret_cast<float*>(Hh);                       // [2][128] floats
+  double* COMB = reinterpret_cast<double*>(RED + 4 * C);           // [4][128] doubles
+  double* FIN = COMB + 4 * 2 * C;                                  // [8][128] doubles
+
+  int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), w = wv & 3, h = wv >> 2;
+  int lane = tid & 63, q = lane >> 4, j = lane & 15, c4 = tid & 15;
+  const int V = A.V;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int grp = bid & (STK_GROUPS - 1);
+  const int n_groups = G < STK_GROUPS ? G : STK_GROUPS;
+  const int gsz = (G - grp + STK_GROUPS - 1) / STK_GROUPS;         // workgroups b = grp + 8 m, m < gsz
+  int* status = A.sync + (STK_MAX_LAYERS * STK_GROUPS + STK_MAX_LAYERS) * STK_CNT_STRIDE;
+
+  // identity scale / shift for layer 0
+  if (tid < 2 * C) SCSH[tid] = tid < C ? 1.f : 0.f;
+  // u rows this workgroup never writes (tiles smaller than MT, the 4 padding rows) are read by the node mix's K padding times
+  // zero: they must be finite
+  for (int idx = tid; idx < rows_lds * LDD; idx += STK_THREADS) U[idx] = 0.f;
+  {
+    const int at_n4 = (A.KP * A.ldA) >> 2;
+    for (int idx0 = tid; idx0 < at_n4; idx0 += 8 * STK_THREADS) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(A.prep)[min(idx0 + u * STK_THREADS, at_n4 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (idx0 + u * STK_THREADS < at_n4) reinterpret_cast<float4*>(AT)[idx0 + u * STK_THREADS] = v[u];
+    }
+  }
+
+  // weight fragments of the layer about to run: loaded BEFORE the exchange of the previous layer completes (they depend on
+  // nothing), so that their latency hides behind it
+  u32x4 wt[2][4][2];
+  u32x4 wm[6][2];
+  auto load_wt = [&](int layer) {
+    const u32x4* tp = A.wimg + (size_t)layer * WIMG_UNITS + (size_t)(w * 2) * 4 * 2 * 64 + lane;
+#pragma unroll
+    for (int gate = 0; gate < 2; ++gate)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) wt[gate][ks][part] = tp[((gate * 4 + ks) * 2 + part) * 64];
+  };
+  auto load_wm = [&](int layer) {
+    const u32x4* mp = A.wimg + (size_t)layer * WIMG_UNITS + WIMG_TCN_UNITS + (size_t)(w * 6) * 2 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+      for (int part = 0; part < 2; ++part) wm[ks][part] = mp[(ks * 2 + part) * 64];
+  };
+  load_wt(0);
+  __syncthreads();                                   // SCSH is read at the head of the first tile
+
+  for (int layer = 0; layer < A.n_layers; ++layer) {
+    const StackLayer& L = A.L[layer];
+    STK_STAMP(layer, 0);
+    const int shift4b = L.d * V * 256;              // tap-1 row offset in bytes
+    const bool last_layer = layer == A.n_layers - 1;
+    const unsigned xin_bytes = (unsigned)A.B * L.T_in * V * 256u;
+    const auto xr = stk_rsrc(L.xin, xin_bytes);
+    const auto yr = stk_rsrc(L.y, L.y != nullptr ? (unsigned)A.B * L.T_out * V * 256u : 0u);   // (null y: zero records, stores dropped)
+    const float4 bf4 = *reinterpret_cast<const float4*>(L.bf + 16 * w + 4 * q);
+    const float4 bg4 = *reinterpret_cast<const float4*>(L.bg + 16 * w + 4 * q);
+    const float4 bias4 = *reinterpret_cast<const float4*>(L.bm + 16 * w + 4 * q);
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+    float* utail = A.utail + C * layer;
+
+    for (int tile = bid; tile < L.ntiles; tile += G) {
+      asm volatile("" : "+v"(tid));                  // keep per-lane address math from being hoisted out of the loops
+      lane = tid & 63; q = lane >> 4; j = lane & 15; c4 = tid & 15;
+      const int slab0 = tile * L.S;
+      const int nsl = min(L.S, L.n_slabs - slab0);
+      const int R = nsl * V;
+      const int nt = (R + 15) >> 4;                  // populated 16-row tiles
+      const unsigned orow0 = (unsigned)slab0 * V;
+
+      // ---- phase 0: both tap panels -> registers -> normalise -> split -> LDS ------------------------------------------
+      int in0[NIT], tail[NIT];
+      bool ok[NIT];
+      u32x4 x0r[NIT], x1r[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = (tid >> 4) + (STK_THREADS / 16) * it;
+        const int rc = min(row, R - 1);
+        const int s = (int)((rc + 0.5f) * A.invV);
+        const int v = rc - s * V;
+        const int slab = slab0 + s;
+        const int b = (int)((slab + 0.5f) * L.invT);
+        const int tp = slab - b * L.T_out;
+        ok[it] = row < R;
+        in0[it] = (((b * L.T_in + tp) * V + v) * 16 + c4) * 16;                    // byte offset
+        tail[it] = (ok[it] && tp >= L.T_out - 4) ? ((b * 4 + tp - (L.T_out - 4)) * V + v) * A.utail_ld4 + c4 : -1;
+        x0r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0[it], 0, AUX_SC1);
+        x1r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0[it] + shift4b, 0, AUX_SC1);
+      }
+      const float4 sc4 = reinterpret_cast<const float4*>(SCSH)[c4];
+      const float4 sh4 = reinterpret_cast<const float4*>(SCSH + C)[c4];
+      __syncthreads();                               // previous tile's LDS fully consumed
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = (tid >> 4) + (STK_THREADS / 16) * it;
+        if (row < rows_lds) {
+          float4 a = __builtin_bit_cast(float4, x0r[it]), b2 = __builtin_bit_cast(float4, x1r[it]);
+          a = make_float4(a.x * sc4.x + sh4.x, a.y * sc4.y + sh4.y, a.z * sc4.z + sh4.z, a.w * sc4.w + sh4.w);
+          b2 = make_float4(b2.x * sc4.x + sh4.x, b2.y * sc4.y + sh4.y, b2.z * sc4.z + sh4.z, b2.w * sc4.w + sh4.w);
+          if (!ok[it]) { a = make_float4(0.f, 0.f, 0.f, 0.f); b2 = a; }
+          const Split4 sa = split4(a.x, a.y, a.z, a.w), sb = split4(b2.x, b2.y, b2.z, b2.w);
+          const int off = row * RS + 4 * c4;
+          *reinterpret_cast<u32x2*>(R0h + off) = sa.hi;
+          *reinterpret_cast<u32x2*>(R0l + off) = sa.lo;
+          *reinterpret_cast<u32x2*>(R1h + off) = sb.hi;
+          *reinterpret_cast<u32x2*>(R1l + off) = sb.lo;
+        }
+      }
+      __syncthreads();
+      STK_STAMP(layer, 1);
+
+      // ---- phase 1: gated TCN as split products, gate, u -> LDS -------------------------------------------------------
+      {
+        f32x4 af[MTH], ag[MTH];
+#pragma unroll
+        for (int i = 0; i < MTH; ++i) { af[i] = {0.f, 0.f, 0.f, 0.f}; ag[i] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const __bf16* rh = ((ks >> 1) ? R1h : R0h) + j * RS + 32 * (ks & 1) + 8 * q;
+          const __bf16* rl = ((ks >> 1) ? R1l : R0l) + j * RS + 32 * (ks & 1) + 8 * q;
+          u32x4 bh[MTH], bl[MTH];
+#pragma unroll
+          for (int i = 0; i < MTH; ++i) {
+            const int mt = min(2 * i + h, MT - 1);
+            bh[i] = *reinterpret_cast<const u32x4*>(rh + 16 * mt * RS);
+            bl[i] = *reinterpret_cast<const u32x4*>(rl + 16 * mt * RS);
+          }
+#pragma unroll
+          for (int i = 0; i < MTH; ++i) {
+            if (2 * i + h < nt) {
+              af[i] = mfma_split3(wt[0][ks][0], wt[0][ks][1], bh[i], bl[i], af[i]);
+              ag[i] = mfma_split3(wt[1][ks][0], wt[1][ks][1], bh[i], bl[i], ag[i]);
+            }
+          }
+        }
+        STK_STAMP(layer, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_wm(layer);                              // lands behind the gate / node-mix phases
+#pragma unroll
+        for (int i = 0; i < MTH; ++i) {
+          const int mt = 2 * i + h;
+          if (mt < MT && mt < nt) {
+            const int row = 16 * mt + j;
+            const float4 u = make_float4(stk_gate(af[i][0] + bf4.x, ag[i][0] + bg4.x), stk_gate(af[i][1] + bf4.y, ag[i][1] + bg4.y),
+                                         stk_gate(af[i][2] + bf4.z, ag[i][2] + bg4.z), stk_gate(af[i][3] + bf4.w, ag[i][3] + bg4.w));
+            *reinterpret_cast<float4*>(U + row * LDD + 16 * w + 4 * q) = u;
+            const Split4 su = split4(u.x, u.y, u.z, u.w);
+            *reinterpret_cast<u32x2*>(Hh + row * HS + 16 * w + 4 * q) = su.hi;
+            *reinterpret_cast<u32x2*>(Hl + row * HS + 16 * w + 4 * q) = su.lo;
+          }
+        }
+      }
+      __syncthreads();
+      STK_STAMP(layer, 3);
+
+      // ---- skip tail: last 4 frames of u, LDS -> HBM as whole 256-B rows (read by later launches only: plain stores) --
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = (tid >> 4) + (STK_THREADS / 16) * it;
+        if (tail[it] >= 0) reinterpret_cast<float4*>(utail)[tail[it]] = *reinterpret_cast<const float4*>(U + row * LDD + 4 * c4);
+      }
+
+      // ---- phase 2: node mix (exact fp32 MFMA, K = V) -> split images ------------------------------------------------
+      if (V == 9) stk_node_mix<3, 2, true>(U, Hh, Hl, AT, V, A.ldA, nsl, rows_lds - 1, w, h, q, j);
+      else if (V == 42) stk_node_mix<11, 6, false>(U, Hh, Hl, AT, V, A.ldA, nsl, rows_lds - 1, w, h, q, j);
+      else stk_node_mix_generic(U, Hh, Hl, AT, V, A.ldA, A.KP, A.MP, nsl, w, h, q, j);
+      __syncthreads();
+      STK_STAMP(layer, 4);
+
+      // ---- phase 3: channel contraction (K = 192) + bias + residual, y store (write-through), BatchNorm sums ---------
+      f32x4 acc[MTH];
+#pragma unroll
+      for (int i = 0; i < MTH; ++i) acc[i] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        u32x4 bh[MTH], bl[MTH];
+#pragma unroll
+        for (int i = 0; i < MTH; ++i) {
+          const int mt = min(2 * i + h, MT - 1);
+          bh[i] = *reinterpret_cast<const u32x4*>(Hh + (16 * mt + j) * HS + 32 * ks + 8 * q);
+          bl[i] = *reinterpret_cast<const u32x4*>(Hl + (16 * mt + j) * HS + 32 * ks + 8 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < MTH; ++i)
+          if (2 * i + h < nt) acc[i] = mfma_split3(wm[ks][0], wm[ks][1], bh[i], bl[i], acc[i]);
+      }
+      STK_STAMP(layer, 5);
+#pragma unroll
+      for (int i = 0; i < MTH; ++i) {
+        const int mt = 2 * i + h;
+        const int row = 16 * mt + j;
+        if (mt < MT && row < R) {
+          const float4 res = join4(*reinterpret_cast<const u32x2*>(R1h + row * RS + 16 * w + 4 * q),
+                                   *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q));
+          const f32x4 yv = {acc[i][0] + bias4.x + res.x, acc[i][1] + bias4.y + res.y, acc[i][2] + bias4.z + res.z,
+                            acc[i][3] + bias4.w + res.w};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), yr, ((orow0 + row) * C + 16 * w + 4 * q) * 4, 0, AUX_SC1);
+          st1 += yv;
+          st2 += yv * yv;
+        }
+      }
+    }
+    STK_STAMP(layer, 6);
+
+    // ---- exchange -------------------------------------------------------------------------------------------------------
+    // this workgroup's partial row: 16 rows j of a DPP row (xor 1, 2, 4, 8), then the two row halves, fixed order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        st1[r] += __shfl_xor(st1[r], o);
+        st2[r] += __shfl_xor(st2[r], o);
+      }
+    }
+    __syncthreads();                                 // the images are dead: RED / COMB / FIN alias them
+    if (j == 0) {
+      *reinterpret_cast<f32x4*>(RED + h * 2 * C + 16 * w + 4 * q) = st1;
+      *reinterpret_cast<f32x4*>(RED + h * 2 * C + C + 16 * w + 4 * q) = st2;
+    }
+    __syncthreads();
+    float* my_part = A.part + ((size_t)layer * G + bid) * 2 * C;
+    if (wv == 0 && lane < 32) {
+      const float4 a = reinterpret_cast<const float4*>(RED)[lane], b = reinterpret_cast<const float4*>(RED + 2 * C)[lane];
+      const float4 s = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+      const auto pr = stk_rsrc(my_part, 2 * C * 4);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), pr, lane * 16, 0, AUX_SC1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave: its y / partial stores have left
+    if (!last_layer) load_wt(layer + 1);             // the next layer's TCN fragments: in flight across the exchange
+    __syncthreads();
+    int* gcnt = A.sync + (layer * STK_GROUPS + grp) * STK_CNT_STRIDE;
+    int* tcnt = A.sync + (STK_MAX_LAYERS * STK_GROUPS + layer) * STK_CNT_STRIDE;
+    if (tid == 0) FLAG[0] = __hip_atomic_fetch_add(gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1;
+    __syncthreads();
+    STK_STAMP(layer, 7);
+    bool top_last = false;
+    if (FLAG[0]) {
+      // last arriver of the group: add the group's rows in index order
+      const int col = tid & (2 * C - 1), slice = tid >> 7;
+      double acc = 0.0;
+      for (int m0 = slice; m0 < gsz; m0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = m0 + 4 * u;
+          v[u] = m < gsz ? __hip_atomic_load(A.part + ((size_t)layer * G + grp + STK_GROUPS * m) * 2 * C + col, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+      }
+      COMB[slice * 2 * C + col] = acc;
+      __syncthreads();
+      if (tid < 2 * C) {
+        const double t = ((COMB[tid] + COMB[2 * C + tid]) + COMB[4 * C + tid]) + COMB[6 * C + tid];
+        __hip_atomic_store(A.gsum + ((size_t)layer * STK_GROUPS + grp) * 2 * C + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) FLAG[1] = __hip_atomic_fetch_add(tcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1;
+      __syncthreads();
+      top_last = FLAG[1] != 0;
+    }
+    if (last_layer) {
+      if (!top_last) break;                          // nobody waits for the last layer's statistics: one workgroup finalises them
+    } else {
+      if (tid == 0) FLAG[2] = stk_poll(tcnt, n_groups, status) ? 1 : 0;
+      __syncthreads();
+      if (!FLAG[2]) return;                          // time-out (status raised): leave; every other workgroup times out as well
+    }
+    STK_STAMP(layer, 8);
+    {
+      // the <= 8 group sums, added in index order: every workgroup computes the same statistics
+      const int g = tid >> 6, pr = tid & 63;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (g < n_groups) {
+        const auto gr = stk_rsrc(A.gsum + (size_t)layer * STK_GROUPS * 2 * C, STK_GROUPS * 2 * C * 8);
+        v = __builtin_amdgcn_raw_buffer_load_b128(gr, (g * 2 * C + 2 * pr) * 8, 0, AUX_SC1);
+      }
+      *reinterpret_cast<u32x4*>(FIN + g * 2 * C + 2 * pr) = v;
+      __syncthreads();
+      if (tid < C) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < n_groups; ++k) { s1 += FIN[k * 2 * C + tid]; s2 += FIN[k * 2 * C + C + tid]; }
+        const double n = (double)L.n_slabs * V;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)A.eps));
+        const float sc = L.gamma[tid] * rstd;
+        const float sh = L.beta[tid] - (float)mean * sc;
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        SCSH[tid] = sc;
+        SCSH[C + tid] = sh;
+        if (last_layer || bid == 0) {               // one writer of the layer's outputs
+          float* so = A.scsh_out + layer * 2 * C;
+          float* mr = A.mean_rstd + layer * 3 * C;
+          so[tid] = sc;
+          so[C + tid] = sh;
+          mr[tid] = (float)mean;
+          mr[C + tid] = rstd;
+          mr[2 * C + tid] = (float)unbiased;
+          if (L.rmean != nullptr) {
+            L.rmean[tid] = (1.f - A.momentum) * L.rmean[tid] + A.momentum * (float)mean;
+            L.rvar[tid] = (1.f - A.momentum) * L.rvar[tid] + A.momentum * (float)unbiased;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (last_layer) {
+      // every workgroup has made all its adds and finished all its polls: leave the counters at zero for the next launch
+      for (int k = tid; k < STK_MAX_LAYERS * STK_GROUPS + STK_MAX_LAYERS; k += STK_THREADS)
+        __hip_atomic_store(A.sync + k * STK_CNT_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static size_t stk_lds_bytes(int mt, int KP, int ldA) {
+  const size_t rows_lds = 16 * mt + 4;
+  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * LDD + (size_t)KP * ldA + 2 * C) * sizeof(float) + 16;
+}
+
+struct StackPlan {
+  int mt_max, grid, n_cu;
+  size_t lds;
+  int S[STK_MAX_LAYERS], ntiles[STK_MAX_LAYERS], mt[STK_MAX_LAYERS];
+};
+
+template <int MT>
+static const void* stk_fn() { return reinterpret_cast<const void*>(&wn_stack_fwd_kernel<MT>); }
+
+static const void* stk_fn_for(int mt) {
+  switch (mt) {
+    case 1: return stk_fn<1>();
+    case 2: return stk_fn<2>();
+    case 3: return stk_fn<3>();
+    case 4: return stk_fn<4>();
+    case 5: return stk_fn<5>();
+  }
+  return nullptr;
+}
+
+// Geometry of every layer for a grid of `grid_target` workgroups (the per-layer launches' own rule, wn_dev.h), the largest tile,
+// and the resident grid: occupancy (the runtime's answer for this kernel / block / LDS size) x CUs.
+static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, StackPlan* P) {
+  if (n_layers < 1 || n_layers > STK_MAX_LAYERS || dil == nullptr) { set_error("hopmi_wn_stack: 1..%d layers", STK_MAX_LAYERS); return HOPMI_EINVAL; }
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) {
+    (void)hipGetLastError();
+    set_error("hopmi_wn_stack: no device");
+    return HOPMI_EINVAL;
+  }
+  const int target = wn_env_int("HOPMI_WN_GRID", n_cu) < n_cu ? wn_env_int("HOPMI_WN_GRID", n_cu) : n_cu;
+  int T = T_in, mt_max = 1, tiles_max = 1;
+  for (int l = 0; l < n_layers; ++l) {
+    if (int e = wn_validate(B, T, V, dil[l])) return e;
+    if ((long long)B * T * V * 256 >= (1LL << 31)) { set_error("hopmi_wn_stack: layer tensor beyond 2 GiB (32-bit buffer offsets)"); return HOPMI_EINVAL; }
+    const LayerGeom L = make_layer_geom(B, T, V, dil[l], target, WN_MAX_MT);
+    P->S[l] = L.g.S; P->ntiles[l] = L.g.ntiles; P->mt[l] = L.g.mtiles;
+    if (L.g.mtiles > mt_max) mt_max = L.g.mtiles;
+    if (L.g.ntiles > tiles_max) tiles_max = L.g.ntiles;
+    T -= dil[l];
+  }
+  const GcnGeom g = make_geom(1, V, 1);
+  P->mt_max = mt_max;
+  P->lds = stk_lds_bytes(mt_max, g.KP, g.ldA);
+  P->n_cu = n_cu;
+  if (P->lds > 160 * 1024) { set_error("hopmi_wn_stack: tile needs %zu bytes of LDS", P->lds); return HOPMI_EINVAL; }
+  const void* fn = stk_fn_for(mt_max);
+  if (fn == nullptr) { set_error("hopmi_wn_stack: internal: %d m-tiles", mt_max); return HOPMI_EINVAL; }
+  static bool attr_done[WN_MAX_MT + 1] = {};
+  if (!attr_done[mt_max]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+    attr_done[mt_max] = true;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, STK_THREADS, P->lds) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    set_error("hopmi_wn_stack: the kernel does not fit a CU (occupancy query)");
+    return HOPMI_EINVAL;
+  }
+  // one workgroup per CU even where two would fit: the per-layer tiles are sized for n_cu workgroups, and a margin of
+  // residency is worth more than the second workgroup (MI355X_MICROARCH.md: the query can read one high)
+  const int resident = n_cu;
+  P->grid = tiles_max < target ? tiles_max : target;
+  if (P->grid > resident) P->grid = resident;
+  return HOPMI_OK;
+}
+
+hipEvent_t wn_take_timing_events(hipEvent_t* stop);     // wavenet.hip (hopmi_time_next_launch)
+
+}  // namespace hopmi
+
+using namespace hopmi;
+
+#ifdef HOPMI_STAMPS
+extern "C" int hopmi_debug_set_stamps_stack(long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stk_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int hopmi_wn_stack_grid(int B, int T_in, int V, const int* dilations, int n_layers) {
+  StackPlan P;
+  if (stk_plan(B, T_in, V, dilations, n_layers, &P)) return 0;
+  return P.grid;
+}
+
+extern "C" size_t hopmi_wn_stack_ws_bytes(int B, int T_in, int V, const int* dilations, int n_layers) {
+  StackPlan P;
+  if (stk_plan(B, T_in, V, dilations, n_layers, &P)) return 0;
+  return (size_t)STK_SYNC_INTS * sizeof(int) + (size_t)n_layers * P.grid * 2 * C * sizeof(float) +
+         (size_t)n_layers * STK_GROUPS * 2 * C * sizeof(double);
+}
+
+extern "C" int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float* const* bf, const float* const* bg, const float* prep,
+                                  const float* const* bm, const float* const* gamma, const float* const* beta,
+                                  float* const* running_mean, float* const* running_var, float momentum, float eps, float* const* y,
+                                  float* utail, int utail_ld, float* scsh_out, float* mean_rstd_out, void* ws, int B, int T_in, int V,
+                                  const int* dilations, int n_layers, void* stream) {
+  StackPlan P;
+  if (int e = stk_plan(B, T_in, V, dilations, n_layers, &P)) return e;
+  if (!x0 || !wimg || !bf || !bg || !prep || !bm || !gamma || !beta || !y || !utail || !scsh_out || !mean_rstd_out || !ws) {
+    set_error("hopmi_wn_stack_fwd: null pointer argument");
+    return HOPMI_EINVAL;
+  }
+  if (utail_ld < C * n_layers || (utail_ld & 3)) { set_error("hopmi_wn_stack_fwd: utail_ld=%d must be a multiple of 4 and >= 64 * n_layers", utail_ld); return HOPMI_EINVAL; }
+  StackArgs A{};
+  int T = T_in;
+  for (int l = 0; l < n_layers; ++l) {
+    StackLayer& L = A.L[l];
+    if (!bf[l] || !bg[l] || !bm[l] || !gamma[l] || !beta[l] || (l < n_layers - 1 && !y[l])) {
+      set_error("hopmi_wn_stack_fwd: null pointer for layer %d", l);
+      return HOPMI_EINVAL;
+    }
+    L.xin = l == 0 ? x0 : y[l - 1];
+    L.y = l < n_layers - 1 ? y[l] : nullptr;
+    L.bf = bf[l]; L.bg = bg[l]; L.bm = bm[l]; L.gamma = gamma[l]; L.beta = beta[l];
+    L.rmean = running_mean ? running_mean[l] : nullptr;
+    L.rvar = running_var ? running_var[l] : nullptr;
+    if ((L.rmean == nullptr) != (L.rvar == nullptr)) { set_error("hopmi_wn_stack_fwd: running_mean / running_var of layer %d: both or none", l); return HOPMI_EINVAL; }
+    L.T_in = T; L.d = dilations[l]; L.T_out = T - dilations[l];
+    L.n_slabs = B * L.T_out; L.S = P.S[l]; L.ntiles = P.ntiles[l];
+    L.invT = 1.0f / L.T_out;
+    T = L.T_out;
+  }
+  const GcnGeom g = make_geom(1, V, 1);
+  A.wimg = static_cast<const u32x4*>(wimg);
+  A.prep = prep;
+  A.utail = utail;
+  A.scsh_out = scsh_out;
+  A.mean_rstd = mean_rstd_out;
+  A.sync = static_cast<int*>(ws);
+  A.part = reinterpret_cast<float*>(A.sync + STK_SYNC_INTS);
+  A.gsum = reinterpret_cast<double*>(A.part + (size_t)n_layers * P.grid * 2 * C);
+  A.n_layers = n_layers; A.B = B; A.V = V; A.utail_ld4 = utail_ld / 4;
+  A.KP = g.KP; A.ldA = g.ldA; A.MP = g.MP;
+  A.invV = 1.0f / V; A.momentum = momentum; A.eps = eps;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e1 = nullptr;
+  const hipEvent_t e0 = wn_take_timing_events(&e1);
+  switch (P.mt_max) {
+#define HOPMI_STK_CASE(MT_) \
+    case MT_: hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_>), dim3(P.grid), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A); break;
+    HOPMI_STK_CASE(1) HOPMI_STK_CASE(2) HOPMI_STK_CASE(3) HOPMI_STK_CASE(4) HOPMI_STK_CASE(5)
+#undef HOPMI_STK_CASE
+    default: set_error("hopmi_wn_stack_fwd: internal: %d m-tiles", P.mt_max); return HOPMI_EINVAL;
+  }
+  return check_launch("hopmi_wn_stack_fwd");
+}

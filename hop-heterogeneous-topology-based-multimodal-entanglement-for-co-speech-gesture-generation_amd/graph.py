@@ -8,9 +8,10 @@ the host needs to issue them, not by the device.  `GraphedTrainStep` records the
     step = hopmi.GraphedTrainStep(args, model, discriminator, model_optim, dis_optimizer)      # Adam optimizers
     losses = step(epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices)   # = train_llm(...)
 
-* The first `eager_calls` calls run `steps.train_llm` itself (library handles, workspaces and autograd threads come up
-  outside a capture); the next call captures and replays; later calls copy the batch into the graph's static inputs
-  and replay.  Every call is exactly one training step.  One recording per phase (`epoch <= 10` / GAN phase) and batch
+* The first `eager_calls` calls OF EACH PHASE (`epoch <= 10` / GAN phase) run `steps.train_llm` itself (library handles,
+  workspaces, lazily built operand images and autograd threads come up outside a capture -- the discriminator's backward
+  runs for the first time at epoch 11); the next call captures and replays; later calls copy the batch into the graph's
+  static inputs and replay.  Every call is exactly one training step.  One recording per phase (`epoch <= 10` / GAN phase) and batch
   shape; a batch of another shape (the last, short one of an epoch) runs the eager step.
 * The recording is cut into segments where the step talks to the outside: behind the loss copy (the replay waits for
   that event only and returns while backward + optimizer still run), and -- with more than one rank -- around every
@@ -149,7 +150,8 @@ class GraphedTrainStep:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.accel = accelerator if accelerator is not None else _PlainBackward()
-        self.eager_left = eager_calls
+        self.eager_calls = eager_calls
+        self.eager_left = {}                        # phase (gan flag) -> eager calls still to make before recording it
         self.grad_dtype = grad_dtype
         self.enabled = enabled
         self.debug = debug
@@ -289,10 +291,11 @@ class GraphedTrainStep:
         batch = (in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices)
         if not (self.enabled and in_audio.is_cuda):
             return self._eager(epoch, batch)
-        if self.eager_left > 0:
-            self.eager_left -= 1
-            return self._eager(epoch, batch)
         gan = epoch > 10 and self.args.loss_gan_weight > 0.0
+        left = self.eager_left.setdefault(gan, self.eager_calls)
+        if left > 0:
+            self.eager_left[gan] = left - 1
+            return self._eager(epoch, batch)
         key = (gan, torch.is_autocast_enabled(), _steps._MIXED, getattr(self.args, "mixed_precision", None)) + tuple(
             (tuple(t.shape), t.dtype) for t in batch)
         rec = self.records.get(key)

@@ -914,6 +914,77 @@ def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_
     return y, fs, scsh_out, mean_rstd
 
 
+_STACK_WS = {}       # (device index, stream, geometry) -> workspace of the persistent stack kernel (counters zero between launches)
+STACK_ENABLED = True  # False: the training forward runs as per-layer launches (A/B runs, HOPMI_WN_STACK=0)
+
+
+def wn_stack_supported(B: int, T_in: int, V: int, dilations) -> int:
+    """Grid of the one-launch WaveNet stack (hopmi_wn_stack_fwd) for this geometry, or 0 when it cannot be used: unsupported
+    geometry, or a context in which its workgroups are not guaranteed to be resident together (persistent kernels withheld
+    beside RCCL kernels / on a shared device, see no_persistent_gru)."""
+    import ctypes
+    import os
+    if not STACK_ENABLED or os.environ.get("HOPMI_WN_STACK", "1") == "0" or not gru_persistent_allowed():
+        return 0
+    n = len(dilations)
+    return int(_lib.lib().hopmi_wn_stack_grid(B, T_in, V, (ctypes.c_int * n)(*dilations), n))
+
+
+def wn_stack_fwd(x0, wimg, tcn_biases, prep, mlp_biases, bns, tails, dilations):
+    """All WaveNet layers of a training-mode forward as ONE persistent launch (hopmi_wn_stack_fwd): x0 (B,T,V,64) start-conv
+    output, wimg = wn_prepare_weights(...) of the n layers, tcn_biases = [(bf, bg)], mlp_biases = [bm], bns = the
+    nn.BatchNorm2d modules (affine parameters, running statistics updated in place), tails (B,4,V,64 n) receives the skip
+    tails.  Returns (ys, scsh, mean_rstd): ys[l] = layer l's pre-BatchNorm output for l < n - 1 (the last one is dead),
+    scsh (n,128) the scale | shift rows, mean_rstd (n,192) mean | rstd | unbiased variance rows."""
+    import ctypes
+    n = len(dilations)
+    B, T_in, V, _ = x0.shape
+    dev = x0.device
+    L = _lib.lib()
+    dil = (ctypes.c_int * n)(*dilations)
+    nbytes = L.hopmi_wn_stack_ws_bytes(B, T_in, V, dil, n)
+    if nbytes == 0:
+        raise _lib.HopmiError(f"hopmi wn_stack_fwd: unsupported geometry: {L.hopmi_last_error().decode()}")
+    x0 = _dev_f32(x0, "x0")
+    st = _stream()
+    key = (dev.index, st, B, T_in, V, tuple(dilations))
+    ws = _STACK_WS.get(key)
+    if ws is None:
+        ws = _STACK_WS[key] = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
+    if tails.stride(-1) != 1 or tails.stride(2) % 4 or tails.shape != (B, 4, V, 64 * n) or tails.dtype != torch.float32:
+        raise _lib.HopmiError(f"hopmi wn_stack_fwd: bad tails tensor {tuple(tails.shape)} strides {tails.stride()}")
+    if wimg.dtype != torch.uint8 or wimg.numel() != L.hopmi_wn_weight_image_bytes(n) or not wimg.is_contiguous():
+        raise _lib.HopmiError("hopmi wn_stack_fwd: `wimg` is not the wn_prepare_weights() image of these layers")
+    mom, eps = float(bns[0].momentum), float(bns[0].eps)
+    if any(float(b.momentum) != mom or float(b.eps) != eps for b in bns):
+        raise _lib.HopmiError("hopmi wn_stack_fwd: the BatchNorm layers must share momentum and eps")
+    ys, T = [], T_in
+    for l in range(n - 1):
+        T -= dilations[l]
+        ys.append(torch.empty(B, T, V, 64, dtype=torch.float32, device=dev))
+    scsh = torch.empty(n, 128, dtype=torch.float32, device=dev)
+    mean_rstd = torch.empty(n, 192, dtype=torch.float32, device=dev)
+    tab = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else _dev_f32(t, "stack parameter").data_ptr() for t in ts])
+    for t in [b for pair in tcn_biases for b in pair] + list(mlp_biases) + [p for bn in bns for p in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]:
+        if t is not None and (not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != 64):
+            raise _lib.HopmiError("hopmi wn_stack_fwd: per-layer vectors must be contiguous float32 [64]")
+    ytab = (ctypes.c_void_p * max(n - 1, 1))(*[y.data_ptr() for y in ys]) if n > 1 else (ctypes.c_void_p * 1)(None)
+    # SURVEY.md 8(d), fused layers: per layer x in + x out (not the dead last one) + the last-4-frames skip tail
+    n_rows, nbytes_alg, flops, T = 0, 0, 0, T_in
+    for l, d in enumerate(dilations):
+        nbytes_alg += 4 * 64 * V * (B * T + (B * (T - d) if l < n - 1 else 0) + 4 * B)
+        flops += B * (T - d) * V * (2 * 2 * 2 * 64 * 64 + 2 * 192 * 64 + 4 * 64 * V)
+        T -= d
+    _lib.check(_timed("wn_stack_fwd", nbytes_alg, flops,
+                      lambda: L.hopmi_wn_stack_fwd(x0.data_ptr(), wimg.data_ptr(), tab([b[0] for b in tcn_biases]), tab([b[1] for b in tcn_biases]),
+                                                   prep.data_ptr(), tab(mlp_biases), tab([bn.weight for bn in bns]), tab([bn.bias for bn in bns]),
+                                                   tab([bn.running_mean for bn in bns]), tab([bn.running_var for bn in bns]), mom, eps, ytab,
+                                                   tails.data_ptr(), tails.stride(2), scsh.data_ptr(), mean_rstd.data_ptr(), ws.data_ptr(),
+                                                   B, T_in, V, dil, n, st), exact=True), "hopmi_wn_stack_fwd")
+    _track_status(ws[:(8 * 8 + 8) * 32 + 16])           # (status word at index [-16] of this view)
+    return ys, scsh, mean_rstd
+
+
 def wn_fused_training_supported(V: int) -> bool:
     """The fused backward keeps five tile images and both mix-matrix images in LDS: that fits for V <= 42 (the
     reference's two skeletons are 9 and 42 nodes).  Larger graphs train through the composed path (gcn kernel + GEMMs)."""

@@ -126,6 +126,35 @@ int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const float* beta,
                          int B, int T_in, int V, int dilation, void* stream);
 int hopmi_wn_bn_replay(const float* mean_rstd, float* running_mean, float* running_var, float momentum, void* stream);
 
+/* ---- the whole WaveNet stack, training-mode forward, as ONE persistent launch: model/gwnet.py:181-237 for all layers
+ *      (what n_layers x (hopmi_wn_layer_fwd + hopmi_wn_bn_finalize) compute; csrc/wavenet_stack.hip).  Training-mode BatchNorm
+ *      makes every layer a chip-wide dependency (the statistics of layer i over all clips feed layer i + 1); inside this launch
+ *      the per-workgroup partial sums are exchanged through memory (sc1 stores, per-group and per-layer arrival counters,
+ *      fixed-order sums: bitwise reproducible), so the seam costs an exchange instead of a kernel boundary plus a
+ *      finalisation launch.
+ *
+ *   x0        [B][T_in][V][64]   start-conv output;  dilations[n_layers];  T shrinks by dilations[l] per layer
+ *   wimg      hopmi_wn_prepare_weights image of the n_layers layers;  bf, bg, bm, gamma, beta: n_layers pointers to [64]
+ *   running_mean / running_var: n_layers pointers (entries nullable) updated in place with torch semantics
+ *   y         n_layers - 1 pointers: y[l] [B][T_l][V][64] receives layer l's pre-BatchNorm output (the backward's and the next
+ *             layer's input); the last layer's output is dead (gwnet.py:240) and not stored
+ *   utail     [B][4][V][utail_ld]: layer l's gated activations of the last 4 frames at channel offset 64 l
+ *   scsh_out  [n_layers][128]  scale | shift of BN_l (what layer l + 1 applies on load);  mean_rstd_out [n_layers][192]
+ *             mean | rstd | unbiased variance
+ *   ws        hopmi_wn_stack_ws_bytes(...) bytes; its first 4 KiB-aligned block of counters must be ZERO before the first launch
+ *             and is left zero by every completed launch; int word [(8*8 + 8) * 32] is the status word (non-zero: a wait timed
+ *             out, results invalid, re-zero ws).
+ *   The grid (hopmi_wn_stack_grid, <= one workgroup per CU) must be resident at once: do not launch beside kernels that hold
+ *   CUs indefinitely.  hopmi_wn_stack_grid returns 0 when the configuration is not supported (use the per-layer calls).
+ *   Honours hopmi_time_next_launch. */
+int hopmi_wn_stack_grid(int B, int T_in, int V, const int* dilations, int n_layers);
+size_t hopmi_wn_stack_ws_bytes(int B, int T_in, int V, const int* dilations, int n_layers);
+int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float* const* bf, const float* const* bg, const float* prep,
+                       const float* const* bm, const float* const* gamma, const float* const* beta,
+                       float* const* running_mean, float* const* running_var, float momentum, float eps, float* const* y,
+                       float* utail, int utail_ld, float* scsh_out, float* mean_rstd_out, void* ws, int B, int T_in, int V,
+                       const int* dilations, int n_layers, void* stream);
+
 /* Backward of one fused WaveNet layer (autograd of gwnet.py:181-237), see csrc/wavenet_bwd.hip.
  *   xin, scsh_in, fs, wf, wg, prep, Wm : as in / saved by the forward
  *   P0n, P1n [B][T_out - d_next][V][64]: gradient w.r.t. this layer's BatchNorm output as written by the NEXT

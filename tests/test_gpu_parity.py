@@ -515,6 +515,58 @@ def test_gwnet_full_size_properties(V, B):
         assert torch.equal(a, b), "fused training path is not bitwise reproducible"
 
 
+@pytest.mark.parametrize("V,B", [(9, 128), (42, 64), (9, 300), (5, 1), (42, 3), (17, 40)])
+def test_wn_stack_one_launch_vs_per_layer_launches(V, B):
+    """hopmi_wn_stack_fwd (all 8 layers in one persistent launch, BatchNorm statistics exchanged between workgroups inside
+    it) against the same forward as 8 x (hopmi_wn_layer_fwd + hopmi_wn_bn_finalize): same arithmetic per row, the partial
+    sums of the statistics grouped differently (1e-5).  Outputs, every gradient (the backward consumes the stack's saved
+    activations / statistics), running statistics; B = 300 gives every workgroup several tiles per layer, (5, 1) fewer
+    tiles than workgroups.  And the one-launch form is bitwise reproducible and leaves its counters at zero (a second launch
+    on the same workspace works)."""
+    import copy
+    import hopmi
+    from hopmi import ops
+    dev = _dev()
+    torch.manual_seed(3)
+    m = hopmi.gwnet(None, V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173,
+                    out_dim=173, residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512).to(dev).train()
+    x = torch.randn(B, 173, V, 16, device=dev)
+    gout = torch.randn(B, 173, V, 4, device=dev)
+    assert ops.wn_stack_supported(B, 16, V, (1, 2, 1, 2, 1, 2, 1, 2)) > 0
+    res = {}
+    for mode in ("stack", "stack_again", "layers"):
+        ops.STACK_ENABLED = mode != "layers"
+        try:
+            mm = copy.deepcopy(m)
+            xi = x.clone().requires_grad_()
+            out = mm(xi)
+            (out * gout).sum().backward()
+            with torch.no_grad():
+                out_ng = mm(x)                        # the no-grad training forward takes the same kernel
+            torch.cuda.synchronize()
+        finally:
+            ops.STACK_ENABLED = True
+        ops.check_status_now()
+        res[mode] = dict(out=out.detach(), out_ng=out_ng, dx=xi.grad, grads={n: p.grad for n, p in mm.named_parameters() if p.grad is not None},
+                         bufs={n: b.clone() for n, b in mm.named_buffers()})
+    a, b, c = res["stack"], res["stack_again"], res["layers"]
+    assert torch.equal(a["out"], b["out"]) and torch.equal(a["dx"], b["dx"]) and torch.equal(a["out_ng"], b["out_ng"])
+    assert all(torch.equal(a["bufs"][n], b["bufs"][n]) for n in a["bufs"])
+    assert torch.equal(a["out"], a["out_ng"])         # same inputs, same weights: the second forward repeats the first
+    assert_close(a["out"], c["out"], 1e-5, "out")
+    assert_close(a["dx"], c["dx"], 1e-4, "dx")
+    assert sorted(a["grads"]) == sorted(c["grads"])
+    for n in a["grads"]:
+        if n.endswith("mlp.mlp.bias"):               # analytically zero gradients: rounding noise on both sides
+            continue
+        assert_close(a["grads"][n], c["grads"][n], 1e-4, n)
+    for n in a["bufs"]:
+        if a["bufs"][n].is_floating_point():
+            assert_close(a["bufs"][n], c["bufs"][n], 1e-5, n)
+        else:
+            assert torch.equal(a["bufs"][n], c["bufs"][n]), n
+
+
 # ---------------------------------------------------------------------------------- full model
 def _make_model(V, dev):
     import hopmi
