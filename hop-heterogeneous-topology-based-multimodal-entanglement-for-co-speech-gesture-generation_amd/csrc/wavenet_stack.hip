@@ -6,23 +6,26 @@
 //
 // Training-mode BatchNorm makes every layer a chip-wide dependency: layer i + 1 of ANY clip needs the statistics of layer i over
 // ALL clips.  As eight launches that seam was a kernel boundary plus a finalisation launch per layer (8 x (10.9 + 9.8) us at
-// TED / B = 128); here it is an in-launch exchange.  Per layer every workgroup
-//   1. runs its tile(s) of the layer exactly as wn_layer_fwd_kernel does (same phases, same arithmetic), reading its rows of
-//      y_{i-1} with sc1 loads and writing y_i with sc1 (write-through) stores;
-//   2. publishes its 128 partial sums (one 512-byte row, one store instruction of one wave), drains its stores, and adds 1 to
-//      the counter of its group (group = workgroup index mod 8: the workgroups of one XCD under round-robin placement -- for
-//      speed only, nothing depends on it);
-//   3. the workgroup whose add came LAST in its group (told by the value the add returned) sums the group's rows in index order
-//      (double), publishes the group sum and adds 1 to the layer's top counter;
-//   4. every workgroup polls the top counter (one lane, sc1 loads, s_sleep), then adds the <= 8 group sums in index order and
-//      computes mean / rstd / scale / shift itself: the same numbers in every workgroup, bitwise reproducible from run to run
-//      (fixed summation order everywhere, no floating-point atomics).
-// Hand-off form (MI355X_MICROARCH.md, visibility, valid forms: sc1 payload stores, every storing wave drains, workgroup barrier,
-// ONE lane's agent-scope atomic add; consumers: sc1 poll / returned add, workgroup barrier, sc1 loads of every handed-off byte).
-// Counters are per layer (no reuse inside a launch); the workgroup that finalises the LAST layer's statistics -- by then every
-// workgroup has made all its adds and finished all its polls -- zeroes them for the next launch.  Requirements: the grid is
-// resident at once (host: grid <= occupancy x CUs).  Every spin is bounded: on time-out the workgroup raises the status word and
-// leaves the kernel, so the launch always drains (results are then garbage, the host raises on the status word).
+// TED / B = 128); here it is an in-launch exchange whose critical path is THREE memory hops.  Per layer every workgroup
+//   1. runs its tile(s) of the layer exactly as wn_layer_fwd_kernel does (same phases, same arithmetic), writing y_i with sc1
+//      (write-through) stores;
+//   2. publishes its 128 partial sums at once as data-tagged granules (8 bytes = {tag, fp32 bits}, ONE aligned store each:
+//      the data is the flag, nothing to drain first);
+//   3. the first workgroup of each group (group = workgroup index mod 8: one XCD under round-robin placement -- for speed
+//      only, nothing depends on it) sweeps its group's granules until every tag matches, adds them in index order (double) and
+//      publishes the group sum as granules (two per value: hi and lo float of the double);
+//   4. meanwhile every workgroup drains its y stores, raises the "drained" flag of its tiles, waits for the flags of the few
+//      tiles that produced the rows ITS next tile reads (neighbours: they drained at the same time) and issues that tile's
+//      loads -- the activations of layer i + 1 arrive while the statistics are still on their way;
+//   5. every workgroup sweeps the <= 8 group sums until every tag matches, adds them in index order and computes mean / rstd /
+//      scale / shift itself: the same numbers in every workgroup, bitwise reproducible from run to run (fixed summation order
+//      everywhere, no floating-point atomics).
+// Hand-off forms (MI355X_MICROARCH.md, visibility): R2 granules for the statistics (tag = launch sequence number x 16 + layer + 1,
+// never 0; the sequence number lives in the workspace and is advanced by workgroup 0 at the very end of a launch, so a replayed
+// hipGraph sees fresh tags; no counter, nothing to reset); for y: sc1 stores, every storing wave drains, workgroup barrier,
+// ONE lane's sc1 flag store; consumers: sc1 flag poll, workgroup barrier, sc1 loads of every handed-off byte.
+// Requirements: the grid is resident at once (host: grid <= CUs).  Every spin is bounded: on time-out the workgroup raises the
+// status word and leaves the kernel, so the launch always drains (results are then garbage, the host raises on the status word).
 #include <hip/hip_ext.h>
 
 #include "bf16_dev.h"
@@ -33,9 +36,9 @@ namespace hopmi {
 constexpr int STK_MAX_LAYERS = 8;
 constexpr int STK_GROUPS = 8;
 constexpr int STK_THREADS = 512;
-constexpr int STK_CNT_STRIDE = 32;                 // ints: every counter on a 128-byte line of its own
-// sync block (ints): [layer][group] group counters, [layer] top counters, status word
-constexpr int STK_SYNC_INTS = (STK_MAX_LAYERS * STK_GROUPS + STK_MAX_LAYERS + 1) * STK_CNT_STRIDE;
+// control block (ints): [0] launch sequence number, [32] status word
+constexpr int STK_SYNC_INTS = 64, STK_STATUS_AT = 32;
+typedef unsigned long long u64;
 
 struct StackLayer {
   const float* xin;      // (B, T_in, V, 64): x0 for layer 0, y_{i-1} after
@@ -54,9 +57,11 @@ struct StackArgs {
   float* utail;          // (B, 4, V, utail_ld): layer i's skip tail at channel offset 64 i
   float* scsh_out;       // [n_layers][128]  scale | shift of BN_i
   float* mean_rstd;      // [n_layers][192]  mean | rstd | unbiased variance
-  int* sync;             // STK_SYNC_INTS ints, zero before the first launch (left zero by every completed launch)
-  float* part;           // [n_layers][grid][128] partial sums
-  double* gsum;          // [n_layers][STK_GROUPS][128] group sums
+  int* sync;             // STK_SYNC_INTS ints: launch sequence number, status word (zero before the first launch)
+  u64* pgran;            // [n_layers][grid][128]        partial sums, granules {tag, fp32 bits}
+  u64* ggran;            // [n_layers][STK_GROUPS][256]  group sums, granules (hi, lo) per value
+  unsigned* yflag;       // [n_layers][max_tiles]        "the y rows of this tile have left the workgroup" (= tag)
+  int max_tiles;
   int n_layers, B, V, utail_ld4;
   int KP, ldA, MP;       // mix-matrix image geometry (GcnGeom)
   float invV, momentum, eps;
@@ -87,16 +92,29 @@ __device__ __forceinline__ auto stk_rsrc(const void* p, unsigned bytes) {
 }
 constexpr int AUX_SC1 = 16;                                     // gfx940+: cache-policy bit 4 = sc1 (write-through / bypass L1)
 
-// One lane waits until *p >= want (sc1 loads); false on time-out (status raised).
-__device__ __forceinline__ bool stk_poll(const int* p, int want, int* status) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+__device__ __forceinline__ bool stk_expired(unsigned long long t0, int* status) {
+  if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {              // 2 s at 100 MHz
+    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  return false;
+}
+
+// N granules per lane, re-read until every tag matches (R2: the data is the flag); v[k] = the value bits.  Bounded.
+template <int N>
+__device__ __forceinline__ bool stk_sweep(const u64* const (&p)[N], unsigned tag, unsigned (&v)[N], int* status) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {            // 2 s
-      __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const u64 x = p[k] != nullptr ? __hip_atomic_load(p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)tag << 32);
+      v[k] = (unsigned)x;
+      ok &= (unsigned)(x >> 32) == tag;
     }
-    __builtin_amdgcn_s_sleep(2);
+    if (ok) return true;
+    if (stk_expired(t0, status)) return false;
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -215,27 +233,31 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
   const int grp = bid & (STK_GROUPS - 1);
   const int n_groups = G < STK_GROUPS ? G : STK_GROUPS;
   const int gsz = (G - grp + STK_GROUPS - 1) / STK_GROUPS;         // workgroups b = grp + 8 m, m < gsz
-  int* status = A.sync + (STK_MAX_LAYERS * STK_GROUPS + STK_MAX_LAYERS) * STK_CNT_STRIDE;
+  const bool combiner = bid < n_groups;                            // the first workgroup of its group adds the group's rows
+  int* status = A.sync + STK_STATUS_AT;
 
   // identity scale / shift for layer 0
   if (tid < 2 * C) SCSH[tid] = tid < C ? 1.f : 0.f;
+  if (tid == 0) { FLAG[0] = FLAG[1] = FLAG[2] = 0; FLAG[3] = *reinterpret_cast<volatile int*>(A.sync); }   // [3]: launch sequence number
   // u rows this workgroup never writes (tiles smaller than MT, the 4 padding rows) are read by the node mix's K padding times
   // zero: they must be finite
   for (int idx = tid; idx < rows_lds * LDD; idx += STK_THREADS) U[idx] = 0.f;
   {
+    // the mix image -> LDS: up to 4 independent loads per thread and round trip (V = 42: 1 232 float4 = 3 per thread)
     const int at_n4 = (A.KP * A.ldA) >> 2;
-    for (int idx0 = tid; idx0 < at_n4; idx0 += 8 * STK_THREADS) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(A.prep)[min(idx0 + u * STK_THREADS, at_n4 - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (idx0 + u * STK_THREADS < at_n4) reinterpret_cast<float4*>(AT)[idx0 + u * STK_THREADS] = v[u];
+    const float4* src = reinterpret_cast<const float4*>(A.prep);
+    for (int idx0 = tid; idx0 < at_n4; idx0 += 4 * STK_THREADS) {
+      const float4 v0 = src[min(idx0, at_n4 - 1)], v1 = src[min(idx0 + STK_THREADS, at_n4 - 1)];
+      const float4 v2 = src[min(idx0 + 2 * STK_THREADS, at_n4 - 1)], v3 = src[min(idx0 + 3 * STK_THREADS, at_n4 - 1)];
+      reinterpret_cast<float4*>(AT)[idx0] = v0;
+      if (idx0 + STK_THREADS < at_n4) reinterpret_cast<float4*>(AT)[idx0 + STK_THREADS] = v1;
+      if (idx0 + 2 * STK_THREADS < at_n4) reinterpret_cast<float4*>(AT)[idx0 + 2 * STK_THREADS] = v2;
+      if (idx0 + 3 * STK_THREADS < at_n4) reinterpret_cast<float4*>(AT)[idx0 + 3 * STK_THREADS] = v3;
     }
   }
 
-  // weight fragments of the layer about to run: loaded BEFORE the exchange of the previous layer completes (they depend on
-  // nothing), so that their latency hides behind it
+  // weight fragments: straight from the prepared image (L2-resident), the TCN set behind the tile's commit, the graph-conv set
+  // behind the TCN phase, so that neither is live with the other
   u32x4 wt[2][4][2];
   u32x4 wm[6][2];
   auto load_wt = [&](int layer) {
@@ -254,23 +276,63 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 #pragma unroll
       for (int part = 0; part < 2; ++part) wm[ks][part] = mp[(ks * 2 + part) * 64];
   };
-  load_wt(0);
-  __syncthreads();                                   // SCSH is read at the head of the first tile
+
+  // a tile's two tap panels -> registers (sc1: rows another workgroup wrote in this launch); the tile's row map stays in
+  // registers (tail[]: where the skip tail of the row goes, or -1; ok[]: row < R)
+  int tail[NIT];
+  bool ok[NIT];
+  u32x4 x0r[NIT], x1r[NIT];
+  auto issue_tile = [&](const StackLayer& L, int tile) {
+    const int slab0 = tile * L.S;
+    const int R = min(L.S, L.n_slabs - slab0) * V;
+    const auto xr = stk_rsrc(L.xin, (unsigned)A.B * L.T_in * V * 256u);
+    const int shift4b = L.d * V * 256;               // tap-1 row offset in bytes
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = (tid >> 4) + (STK_THREADS / 16) * it;
+      const int rc = min(row, R - 1);
+      const int s = (int)((rc + 0.5f) * A.invV);
+      const int v = rc - s * V;
+      const int slab = slab0 + s;
+      const int b = (int)((slab + 0.5f) * L.invT);
+      const int tp = slab - b * L.T_out;
+      ok[it] = row < R;
+      const int in0 = (((b * L.T_in + tp) * V + v) * 16 + c4) * 16;              // byte offset
+      tail[it] = (ok[it] && tp >= L.T_out - 4) ? ((b * 4 + tp - (L.T_out - 4)) * V + v) * A.utail_ld4 + c4 : -1;
+      x0r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0, 0, AUX_SC1);
+      x1r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0 + shift4b, 0, AUX_SC1);
+    }
+  };
+  // per-layer constants (this lane's 4 channels): requested with the first tile's panels, i.e. during the previous layer's
+  // exchange, so that no load is young when the layer starts (the wait in front of the weight loads would pay for it)
+  float4 bf4, bg4, bias4;
+  auto load_consts = [&](const StackLayer& L) {
+    bf4 = *reinterpret_cast<const float4*>(L.bf + 16 * w + 4 * q);
+    bg4 = *reinterpret_cast<const float4*>(L.bg + 16 * w + 4 * q);
+    bias4 = *reinterpret_cast<const float4*>(L.bm + 16 * w + 4 * q);
+  };
+  if (bid < A.L[0].ntiles) issue_tile(A.L[0], bid);
+  load_consts(A.L[0]);
+  {
+    // touch every layer's descriptor now (first, middle and last word: all its cache lines): the scalar loads of a layer's
+    // geometry then hit the scalar cache instead of paying a memory round trip at the head of every layer
+    int warm = 0;
+    for (int l = 0; l < A.n_layers; ++l) warm += (int)(size_t)A.L[l].xin + (int)(size_t)A.L[l].gamma + A.L[l].ntiles + (int)A.L[l].invT;
+    if (tid == 0) FLAG[2] = warm;
+  }
+  __syncthreads();                                   // SCSH / FLAG[3] are read below
+  const unsigned seq = (unsigned)FLAG[3];
 
   for (int layer = 0; layer < A.n_layers; ++layer) {
     const StackLayer& L = A.L[layer];
     STK_STAMP(layer, 0);
-    const int shift4b = L.d * V * 256;              // tap-1 row offset in bytes
     const bool last_layer = layer == A.n_layers - 1;
-    const unsigned xin_bytes = (unsigned)A.B * L.T_in * V * 256u;
-    const auto xr = stk_rsrc(L.xin, xin_bytes);
+    const unsigned tag = (seq << 4) | (unsigned)(layer + 1);
     const auto yr = stk_rsrc(L.y, L.y != nullptr ? (unsigned)A.B * L.T_out * V * 256u : 0u);   // (null y: zero records, stores dropped)
-    const float4 bf4 = *reinterpret_cast<const float4*>(L.bf + 16 * w + 4 * q);
-    const float4 bg4 = *reinterpret_cast<const float4*>(L.bg + 16 * w + 4 * q);
-    const float4 bias4 = *reinterpret_cast<const float4*>(L.bm + 16 * w + 4 * q);
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
     float* utail = A.utail + C * layer;
 
+    // the first tile's tap panels are in flight since the previous layer's exchange
     for (int tile = bid; tile < L.ntiles; tile += G) {
       asm volatile("" : "+v"(tid));                  // keep per-lane address math from being hoisted out of the loops
       lane = tid & 63; q = lane >> 4; j = lane & 15; c4 = tid & 15;
@@ -280,25 +342,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       const int nt = (R + 15) >> 4;                  // populated 16-row tiles
       const unsigned orow0 = (unsigned)slab0 * V;
 
-      // ---- phase 0: both tap panels -> registers -> normalise -> split -> LDS ------------------------------------------
-      int in0[NIT], tail[NIT];
-      bool ok[NIT];
-      u32x4 x0r[NIT], x1r[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int row = (tid >> 4) + (STK_THREADS / 16) * it;
-        const int rc = min(row, R - 1);
-        const int s = (int)((rc + 0.5f) * A.invV);
-        const int v = rc - s * V;
-        const int slab = slab0 + s;
-        const int b = (int)((slab + 0.5f) * L.invT);
-        const int tp = slab - b * L.T_out;
-        ok[it] = row < R;
-        in0[it] = (((b * L.T_in + tp) * V + v) * 16 + c4) * 16;                    // byte offset
-        tail[it] = (ok[it] && tp >= L.T_out - 4) ? ((b * 4 + tp - (L.T_out - 4)) * V + v) * A.utail_ld4 + c4 : -1;
-        x0r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0[it], 0, AUX_SC1);
-        x1r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0[it] + shift4b, 0, AUX_SC1);
-      }
+      // ---- phase 0: both tap panels (in flight since before the statistics arrived for the first tile) -> normalise -> split -> LDS
+      if (tile != bid) issue_tile(L, tile);          // (its producers' flags were checked with the first tile's, see the exchange)
       const float4 sc4 = reinterpret_cast<const float4*>(SCSH)[c4];
       const float4 sh4 = reinterpret_cast<const float4*>(SCSH + C)[c4];
       __syncthreads();                               // previous tile's LDS fully consumed
@@ -318,6 +363,11 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           *reinterpret_cast<u32x2*>(R1l + off) = sb.lo;
         }
       }
+      // the TCN weight fragments (L2-resident image, 128 KiB per workgroup through the CU's 64 B/clk vector-memory path: ~2 000
+      // cycles).  Requested only here: in front of the commit the waves sit in the issue of these loads instead of committing,
+      // and in front of the exchange's sweeps every sweep pass would wait for them (a load's data waits for every older one)
+      __builtin_amdgcn_sched_barrier(0);
+      load_wt(layer);
       __syncthreads();
       STK_STAMP(layer, 1);
 
@@ -346,8 +396,6 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           }
         }
         STK_STAMP(layer, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        load_wm(layer);                              // lands behind the gate / node-mix phases
 #pragma unroll
         for (int i = 0; i < MTH; ++i) {
           const int mt = 2 * i + h;
@@ -361,6 +409,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
             *reinterpret_cast<u32x2*>(Hl + row * HS + 16 * w + 4 * q) = su.lo;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        load_wm(layer);                              // (behind the gate for the same reason) lands behind the node-mix phase
       }
       __syncthreads();
       STK_STAMP(layer, 3);
@@ -430,66 +480,90 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       *reinterpret_cast<f32x4*>(RED + h * 2 * C + C + 16 * w + 4 * q) = st2;
     }
     __syncthreads();
-    float* my_part = A.part + ((size_t)layer * G + bid) * 2 * C;
-    if (wv == 0 && lane < 32) {
-      const float4 a = reinterpret_cast<const float4*>(RED)[lane], b = reinterpret_cast<const float4*>(RED + 2 * C)[lane];
-      const float4 s = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-      const auto pr = stk_rsrc(my_part, 2 * C * 4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), pr, lane * 16, 0, AUX_SC1);
+    if (tid < 2 * C) {                               // 2 waves x 64 granules: whole 512-byte lines per store instruction
+      const float sum = RED[tid] + RED[2 * C + tid];
+      __hip_atomic_store(A.pgran + ((size_t)layer * G + bid) * 2 * C + tid, ((u64)tag << 32) | __float_as_uint(sum), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave: its y / partial stores have left
-    if (!last_layer) load_wt(layer + 1);             // the next layer's TCN fragments: in flight across the exchange
-    __syncthreads();
-    int* gcnt = A.sync + (layer * STK_GROUPS + grp) * STK_CNT_STRIDE;
-    int* tcnt = A.sync + (STK_MAX_LAYERS * STK_GROUPS + layer) * STK_CNT_STRIDE;
-    if (tid == 0) FLAG[0] = __hip_atomic_fetch_add(gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1;
-    __syncthreads();
     STK_STAMP(layer, 7);
-    bool top_last = false;
-    if (FLAG[0]) {
-      // last arriver of the group: add the group's rows in index order
+    if (!last_layer) {
+      // y of this layer: drained by every storing wave, then the tiles' flags (ONE lane).  (The drain also covers the granule
+      // stores above; a combiner loses nothing by it: its members' granules need the same time to become visible.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        for (int tile = bid; tile < L.ntiles; tile += G)
+          __hip_atomic_store(A.yflag + (size_t)layer * A.max_tiles + tile, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool alive = true;
+    if (combiner) {
+      // the group's rows, added in index order (members b = grp + 8 m): slice = m mod 4 per thread, then the 4 slices
       const int col = tid & (2 * C - 1), slice = tid >> 7;
       double acc = 0.0;
-      for (int m0 = slice; m0 < gsz; m0 += 32) {
-        float v[8];
+      for (int m0 = slice; m0 < gsz && alive; m0 += 32) {
+        const u64* p[8];
+        unsigned v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int m = m0 + 4 * u;
-          v[u] = m < gsz ? __hip_atomic_load(A.part + ((size_t)layer * G + grp + STK_GROUPS * m) * 2 * C + col, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          p[u] = m < gsz ? A.pgran + ((size_t)layer * G + grp + STK_GROUPS * m) * 2 * C + col : nullptr;
         }
+        alive = stk_sweep<8>(p, tag, v, status);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        for (int u = 0; u < 8; ++u) acc += (m0 + 4 * u < gsz) ? (double)__uint_as_float(v[u]) : 0.0;
       }
       COMB[slice * 2 * C + col] = acc;
       __syncthreads();
       if (tid < 2 * C) {
         const double t = ((COMB[tid] + COMB[2 * C + tid]) + COMB[4 * C + tid]) + COMB[6 * C + tid];
-        __hip_atomic_store(A.gsum + ((size_t)layer * STK_GROUPS + grp) * 2 * C + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float hi = (float)t, lo = (float)(t - (double)hi);
+        u64* g = A.ggran + ((size_t)layer * STK_GROUPS + grp) * 4 * C + 2 * tid;
+        __hip_atomic_store(g, ((u64)tag << 32) | __float_as_uint(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, ((u64)tag << 32) | __float_as_uint(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) FLAG[1] = __hip_atomic_fetch_add(tcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1;
-      __syncthreads();
-      top_last = FLAG[1] != 0;
-    }
-    if (last_layer) {
-      if (!top_last) break;                          // nobody waits for the last layer's statistics: one workgroup finalises them
-    } else {
-      if (tid == 0) FLAG[2] = stk_poll(tcnt, n_groups, status) ? 1 : 0;
-      __syncthreads();
-      if (!FLAG[2]) return;                          // time-out (status raised): leave; every other workgroup times out as well
     }
     STK_STAMP(layer, 8);
-    {
-      // the <= 8 group sums, added in index order: every workgroup computes the same statistics
-      const int g = tid >> 6, pr = tid & 63;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (g < n_groups) {
-        const auto gr = stk_rsrc(A.gsum + (size_t)layer * STK_GROUPS * 2 * C, STK_GROUPS * 2 * C * 8);
-        v = __builtin_amdgcn_raw_buffer_load_b128(gr, (g * 2 * C + 2 * pr) * 8, 0, AUX_SC1);
+    if (last_layer && bid != 0) break;               // nobody waits for the last layer's statistics: workgroup 0 finalises them
+    if (!last_layer) {
+      // the tiles that produced the rows this workgroup reads next (all of its tiles of layer + 1): neighbours, they drained at
+      // the same time.  Then the first tile's loads go out: they arrive while the statistics are still on their way.
+      const StackLayer& N = A.L[layer + 1];
+      if (wv == 1) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool good = true;
+        for (int tile = bid; tile < N.ntiles && good; tile += G) {
+          const int s_lo = tile * N.S, s_hi = min(s_lo + N.S, N.n_slabs) - 1;
+          const int b_lo = s_lo / N.T_out, b_hi = s_hi / N.T_out;
+          const int p_lo = (b_lo * L.T_out + (s_lo - b_lo * N.T_out)) / L.S;
+          const int p_hi = min((b_hi * L.T_out + (s_hi - b_hi * N.T_out) + N.d) / L.S, L.ntiles - 1);
+          for (int p0 = p_lo; p0 <= p_hi && good; p0 += 64) {
+            const unsigned* f = A.yflag + (size_t)layer * A.max_tiles + min(p0 + lane, p_hi);
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+              if (stk_expired(t0, status)) { good = false; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            good = __all(good);
+          }
+        }
+        if (lane == 0) FLAG[0] = good ? 1 : 0;
       }
-      *reinterpret_cast<u32x4*>(FIN + g * 2 * C + 2 * pr) = v;
+      __syncthreads();
+      if (!FLAG[0]) return;                          // time-out (status raised): every other workgroup times out as well
+      if (bid < N.ntiles) issue_tile(N, bid);
+      load_consts(N);
+    }
+    STK_STAMP(layer, 9);
+    {
+      // the <= 8 group sums (hi + lo), added in index order: every workgroup computes the same statistics
+      const int g = tid >> 6, i4 = tid & 63;                       // 4 granules per lane: values 2 i4, 2 i4 + 1
+      const u64* p[4];
+      unsigned v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p[k] = g < n_groups ? A.ggran + ((size_t)layer * STK_GROUPS + g) * 4 * C + 4 * i4 + k : nullptr;
+      alive = stk_sweep<4>(p, tag, v, status) && alive;
+      FIN[g * 2 * C + 2 * i4] = g < n_groups ? (double)__uint_as_float(v[0]) + (double)__uint_as_float(v[1]) : 0.0;
+      FIN[g * 2 * C + 2 * i4 + 1] = g < n_groups ? (double)__uint_as_float(v[2]) + (double)__uint_as_float(v[3]) : 0.0;
+      if (!alive) FLAG[1] = 1;                       // (benign race: every writer writes 1)
       __syncthreads();
       if (tid < C) {
         double s1 = 0.0, s2 = 0.0;
@@ -504,7 +578,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
         SCSH[tid] = sc;
         SCSH[C + tid] = sh;
-        if (last_layer || bid == 0) {               // one writer of the layer's outputs
+        if (bid == 0) {                              // one writer of the layer's outputs
           float* so = A.scsh_out + layer * 2 * C;
           float* mr = A.mean_rstd + layer * 3 * C;
           so[tid] = sc;
@@ -519,12 +593,11 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         }
       }
       __syncthreads();
+      if (FLAG[1]) return;                           // a sweep timed out (status raised)
     }
-    if (last_layer) {
-      // every workgroup has made all its adds and finished all its polls: leave the counters at zero for the next launch
-      for (int k = tid; k < STK_MAX_LAYERS * STK_GROUPS + STK_MAX_LAYERS; k += STK_THREADS)
-        __hip_atomic_store(A.sync + k * STK_CNT_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    STK_STAMP(layer, 10);
+    // every workgroup has read the sequence number (it published its last-layer row after): advance it for the next launch
+    if (last_layer && tid == 0) __hip_atomic_store(A.sync, (int)(seq + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -534,7 +607,7 @@ static size_t stk_lds_bytes(int mt, int KP, int ldA) {
 }
 
 struct StackPlan {
-  int mt_max, grid, n_cu;
+  int mt_max, grid, n_cu, tiles_max;
   size_t lds;
   int S[STK_MAX_LAYERS], ntiles[STK_MAX_LAYERS], mt[STK_MAX_LAYERS];
 };
@@ -576,6 +649,7 @@ static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, StackP
   }
   const GcnGeom g = make_geom(1, V, 1);
   P->mt_max = mt_max;
+  P->tiles_max = tiles_max;
   P->lds = stk_lds_bytes(mt_max, g.KP, g.ldA);
   P->n_cu = n_cu;
   if (P->lds > 160 * 1024) { set_error("hopmi_wn_stack: tile needs %zu bytes of LDS", P->lds); return HOPMI_EINVAL; }
@@ -621,8 +695,8 @@ extern "C" int hopmi_wn_stack_grid(int B, int T_in, int V, const int* dilations,
 extern "C" size_t hopmi_wn_stack_ws_bytes(int B, int T_in, int V, const int* dilations, int n_layers) {
   StackPlan P;
   if (stk_plan(B, T_in, V, dilations, n_layers, &P)) return 0;
-  return (size_t)STK_SYNC_INTS * sizeof(int) + (size_t)n_layers * P.grid * 2 * C * sizeof(float) +
-         (size_t)n_layers * STK_GROUPS * 2 * C * sizeof(double);
+  return (size_t)STK_SYNC_INTS * sizeof(int) + ((size_t)n_layers * P.grid * 2 * C + (size_t)n_layers * STK_GROUPS * 4 * C) * sizeof(u64) +
+         (size_t)n_layers * P.tiles_max * sizeof(unsigned);
 }
 
 extern "C" int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float* const* bf, const float* const* bg, const float* prep,
@@ -663,8 +737,10 @@ extern "C" int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float
   A.scsh_out = scsh_out;
   A.mean_rstd = mean_rstd_out;
   A.sync = static_cast<int*>(ws);
-  A.part = reinterpret_cast<float*>(A.sync + STK_SYNC_INTS);
-  A.gsum = reinterpret_cast<double*>(A.part + (size_t)n_layers * P.grid * 2 * C);
+  A.pgran = reinterpret_cast<u64*>(A.sync + STK_SYNC_INTS);
+  A.ggran = A.pgran + (size_t)n_layers * P.grid * 2 * C;
+  A.yflag = reinterpret_cast<unsigned*>(A.ggran + (size_t)n_layers * STK_GROUPS * 4 * C);
+  A.max_tiles = P.tiles_max;
   A.n_layers = n_layers; A.B = B; A.V = V; A.utail_ld4 = utail_ld / 4;
   A.KP = g.KP; A.ldA = g.ldA; A.MP = g.MP;
   A.invV = 1.0f / V; A.momentum = momentum; A.eps = eps;

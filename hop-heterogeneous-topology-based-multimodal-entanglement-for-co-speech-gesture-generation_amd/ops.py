@@ -981,7 +981,7 @@ def wn_stack_fwd(x0, wimg, tcn_biases, prep, mlp_biases, bns, tails, dilations):
                                                    tab([bn.running_mean for bn in bns]), tab([bn.running_var for bn in bns]), mom, eps, ytab,
                                                    tails.data_ptr(), tails.stride(2), scsh.data_ptr(), mean_rstd.data_ptr(), ws.data_ptr(),
                                                    B, T_in, V, dil, n, st), exact=True), "hopmi_wn_stack_fwd")
-    _track_status(ws[:(8 * 8 + 8) * 32 + 16])           # (status word at index [-16] of this view)
+    _track_status(ws[:48])                              # (status word = int 32 of the control block = index [-16] of this view)
     return ys, scsh, mean_rstd
 
 

@@ -129,9 +129,9 @@ int hopmi_wn_bn_replay(const float* mean_rstd, float* running_mean, float* runni
 /* ---- the whole WaveNet stack, training-mode forward, as ONE persistent launch: model/gwnet.py:181-237 for all layers
  *      (what n_layers x (hopmi_wn_layer_fwd + hopmi_wn_bn_finalize) compute; csrc/wavenet_stack.hip).  Training-mode BatchNorm
  *      makes every layer a chip-wide dependency (the statistics of layer i over all clips feed layer i + 1); inside this launch
- *      the per-workgroup partial sums are exchanged through memory (sc1 stores, per-group and per-layer arrival counters,
- *      fixed-order sums: bitwise reproducible), so the seam costs an exchange instead of a kernel boundary plus a
- *      finalisation launch.
+ *      the per-workgroup partial sums are exchanged through memory (data-tagged 8-byte granules, two levels, fixed-order
+ *      sums: bitwise reproducible) while the next layer's activations are already being loaded, so the seam costs three
+ *      memory hops instead of a kernel boundary plus a finalisation launch.
  *
  *   x0        [B][T_in][V][64]   start-conv output;  dilations[n_layers];  T shrinks by dilations[l] per layer
  *   wimg      hopmi_wn_prepare_weights image of the n_layers layers;  bf, bg, bm, gamma, beta: n_layers pointers to [64]
@@ -141,9 +141,9 @@ int hopmi_wn_bn_replay(const float* mean_rstd, float* running_mean, float* runni
  *   utail     [B][4][V][utail_ld]: layer l's gated activations of the last 4 frames at channel offset 64 l
  *   scsh_out  [n_layers][128]  scale | shift of BN_l (what layer l + 1 applies on load);  mean_rstd_out [n_layers][192]
  *             mean | rstd | unbiased variance
- *   ws        hopmi_wn_stack_ws_bytes(...) bytes; its first 4 KiB-aligned block of counters must be ZERO before the first launch
- *             and is left zero by every completed launch; int word [(8*8 + 8) * 32] is the status word (non-zero: a wait timed
- *             out, results invalid, re-zero ws).
+ *   ws        hopmi_wn_stack_ws_bytes(...) bytes, ZERO before the first launch and reused from launch to launch (it holds the
+ *             launch sequence number the hand-off tags are made of); int word [32] is the status word (non-zero: a wait timed
+ *             out, results invalid; zero the whole workspace before using it again).
  *   The grid (hopmi_wn_stack_grid, <= one workgroup per CU) must be resident at once: do not launch beside kernels that hold
  *   CUs indefinitely.  hopmi_wn_stack_grid returns 0 when the configuration is not supported (use the per-layer calls).
  *   Honours hopmi_time_next_launch. */

@@ -553,16 +553,53 @@ def test_wn_stack_one_launch_vs_per_layer_launches(V, B):
     assert torch.equal(a["out"], b["out"]) and torch.equal(a["dx"], b["dx"]) and torch.equal(a["out_ng"], b["out_ng"])
     assert all(torch.equal(a["bufs"][n], b["bufs"][n]) for n in a["bufs"])
     assert torch.equal(a["out"], a["out_ng"])         # same inputs, same weights: the second forward repeats the first
-    assert_close(a["out"], c["out"], 1e-5, "out")
-    assert_close(a["dx"], c["dx"], 1e-4, "dx")
+    assert_close(a["out"], c["out"], 5e-5, "out")
+    # gradients: the two ReLUs behind the skip sum have ~1e5..1e6 pre-activations, a few of them within the 1e-5 by which the two
+    # forwards differ of the kink; each one that lands on the other side changes the gradients of its clip by a per-cent-level
+    # amount (see test_gwnet_training_vs_oracle_ragged_and_full_size, which pins the masks).  Compared in the L2 norm, where a
+    # handful of such clips weigh what they are worth; a wrong statistic or a wrong saved activation moves every element.
+    l2 = lambda g, w: ((g - w).double().norm() / w.double().norm().clamp_min(1e-30)).item()
+    assert l2(a["dx"], c["dx"]) <= 2e-2, l2(a["dx"], c["dx"])
     assert sorted(a["grads"]) == sorted(c["grads"])
     for n in a["grads"]:
         if n.endswith("mlp.mlp.bias"):               # analytically zero gradients: rounding noise on both sides
             continue
-        assert_close(a["grads"][n], c["grads"][n], 1e-4, n)
+        assert l2(a["grads"][n], c["grads"][n]) <= 2e-2, (n, l2(a["grads"][n], c["grads"][n]))
+    # what the backward consumes, compared directly and tightly: every layer's saved output, the skip tails, the scale / shift
+    # rows and the (mean, rstd, unbiased variance) rows of the two forms on the same inputs
+    import sys
+    gw = sys.modules["hopmi.gwnet"]
+    mm = copy.deepcopy(m)
+    with torch.no_grad():
+        x0 = ops.linear(x.permute(0, 3, 2, 1), mm.start_conv.weight.flatten(1), mm.start_conv.bias).float().contiguous()
+        A1, A2 = mm.adjacency()
+        prep = ops.gcn_prepare(A1, A2)
+        wimg = mm._weight_images()
+        n = len(gw.DILATIONS)
+        tails_s = torch.empty(B, 4, V, 64 * n, device=dev)
+        ys, scsh_rows, mr_rows = ops.wn_stack_fwd(x0, wimg, [(mm.filter_convs[i].bias, mm.gate_convs[i].bias) for i in range(n)], prep,
+                                                  [mm.gconv[i].mlp.mlp.bias for i in range(n)], list(mm.bn), tails_s, gw.DILATIONS)
+        m2 = copy.deepcopy(m)
+        tails_l = torch.empty_like(tails_s)
+        scsh, xin = gw._identity_scsh(dev), x0
+        for i, d in enumerate(gw.DILATIONS):
+            bn = m2.bn[i]
+            y, _, scsh_out, mr = ops.wn_layer_fwd(xin, scsh, wimg[i], m2.filter_convs[i].bias, m2.gate_convs[i].bias, prep, m2.gconv[i].mlp.mlp.bias,
+                                                  tails_l[..., 64 * i:64 * (i + 1)], d, want_y=i < n - 1, do_gcn=True,
+                                                  bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps))
+            # (same arithmetic per row; the statistics' partial sums are grouped differently, and the difference feeds forward
+            # through 8 normalisations: 5e-5 of the largest element)
+            assert_close(scsh_rows[i], scsh_out, 5e-5, f"scale/shift {i}")
+            assert_close(mr_rows[i], mr, 5e-5, f"mean/rstd {i}")
+            assert_close(mm.bn[i].running_var, bn.running_var, 5e-5, f"running_var {i}")
+            if i < n - 1:
+                assert_close(ys[i], y, 5e-5, f"y {i}")
+                scsh, xin = scsh_out, y
+        assert_close(tails_s, tails_l, 5e-5, "skip tails")
+    ops.check_status_now()
     for n in a["bufs"]:
         if a["bufs"][n].is_floating_point():
-            assert_close(a["bufs"][n], c["bufs"][n], 1e-5, n)
+            assert_close(a["bufs"][n], c["bufs"][n], 5e-5, n)
         else:
             assert torch.equal(a["bufs"][n], c["bufs"][n]), n
 
