@@ -28,6 +28,11 @@
 // status word and leaves the kernel, so the launch always drains (results are then garbage, the host raises on the status word).
 #include <hip/hip_ext.h>
 
+#include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "bf16_dev.h"
 #include "wn_dev.h"
 
@@ -627,9 +632,9 @@ static const void* stk_fn_for(int mt) {
 }
 
 // Geometry of every layer for a grid of `grid_target` workgroups (the per-layer launches' own rule, wn_dev.h), the largest tile,
-// and the resident grid: occupancy (the runtime's answer for this kernel / block / LDS size) x CUs.
-static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, StackPlan* P) {
-  if (n_layers < 1 || n_layers > STK_MAX_LAYERS || dil == nullptr) { set_error("hopmi_wn_stack: 1..%d layers", STK_MAX_LAYERS); return HOPMI_EINVAL; }
+// and the resident grid: occupancy (the runtime's answer for this kernel / block / LDS size) x CUs.  Plans are cached per
+// geometry: the device / occupancy queries run once, outside any stream capture (a recorded step replays launches only).
+static int stk_plan_build(int B, int T_in, int V, const int* dil, int n_layers, StackPlan* P) {
   int dev = 0, n_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) {
     (void)hipGetLastError();
@@ -655,11 +660,7 @@ static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, StackP
   if (P->lds > 160 * 1024) { set_error("hopmi_wn_stack: tile needs %zu bytes of LDS", P->lds); return HOPMI_EINVAL; }
   const void* fn = stk_fn_for(mt_max);
   if (fn == nullptr) { set_error("hopmi_wn_stack: internal: %d m-tiles", mt_max); return HOPMI_EINVAL; }
-  static bool attr_done[WN_MAX_MT + 1] = {};
-  if (!attr_done[mt_max]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
-    attr_done[mt_max] = true;
-  }
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, STK_THREADS, P->lds) != hipSuccess || per_cu < 1) {
     (void)hipGetLastError();
@@ -671,6 +672,23 @@ static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, StackP
   const int resident = n_cu;
   P->grid = tiles_max < target ? tiles_max : target;
   if (P->grid > resident) P->grid = resident;
+  return HOPMI_OK;
+}
+
+struct StackPlanKey { int B, T_in, V, n_layers, dil[STK_MAX_LAYERS]; };
+static std::mutex g_plan_mu;
+static std::vector<std::pair<StackPlanKey, StackPlan>> g_plans;
+
+static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, StackPlan* P) {
+  if (n_layers < 1 || n_layers > STK_MAX_LAYERS || dil == nullptr) { set_error("hopmi_wn_stack: 1..%d layers", STK_MAX_LAYERS); return HOPMI_EINVAL; }
+  StackPlanKey k{};
+  k.B = B; k.T_in = T_in; k.V = V; k.n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) k.dil[l] = dil[l];
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  for (const auto& e : g_plans)
+    if (memcmp(&e.first, &k, sizeof(k)) == 0) { *P = e.second; return HOPMI_OK; }
+  if (int e = stk_plan_build(B, T_in, V, dil, n_layers, P)) return e;
+  g_plans.emplace_back(k, *P);
   return HOPMI_OK;
 }
 

@@ -94,13 +94,14 @@ class _Capture:
         self.keep = []              # tensors the recording owns (flat exchange buffers, ...)
 
     def begin(self):
-        self.graph = torch.cuda.CUDAGraph()
-        if self.owner.debug:
-            self.graph.enable_debug_mode()            # keeps the hipGraph_t behind the executable graph (dump_graphs)
+        # debug: the hipGraph_t is kept behind the executable graph (node_census / dump_graphs)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if self.owner.debug else torch.cuda.CUDAGraph()
         self.graph.capture_begin(pool=self.owner._pool)
 
     def end(self):
         self.graph.capture_end()
+        if self.owner.debug:
+            self.graph.instantiate()
         self.plan.append(("graph", self.graph))
         self.graph = None
 
@@ -150,7 +151,9 @@ class GraphedTrainStep:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.accel = accelerator if accelerator is not None else _PlainBackward()
-        self.eager_calls = eager_calls
+        # at least one eager call per phase: besides library handles, every model builds state lazily in its first call
+        # (the frozen BERT's operand images, the GRU's packed weights, selection matrices), and some of that cannot be recorded
+        self.eager_calls = max(1, int(eager_calls))
         self.eager_left = {}                        # phase (gan flag) -> eager calls still to make before recording it
         self.grad_dtype = grad_dtype
         self.enabled = enabled
@@ -276,6 +279,15 @@ class GraphedTrainStep:
                     if cap.status:
                         self._bwd_status.copy_(torch.stack([w.float().reshape(()) for w in cap.status]).sum())
                         cap.status.clear()
+                except BaseException:
+                    # ending a capture that an exception interrupted can bring the process down inside the runtime (seen:
+                    # SIGSEGV in hipStreamEndCapture): say what happened first
+                    import sys
+                    import traceback
+                    print("hopmi GraphedTrainStep: exception while recording the step:", file=sys.stderr)
+                    traceback.print_exc()
+                    sys.stderr.flush()
+                    raise
                 finally:
                     cap.end()
             finally:
@@ -321,9 +333,44 @@ class GraphedTrainStep:
         self._event.synchronize()
         return _steps._LossFetch.decode(rec["terms"], self._host[:rec["n_vals"]].tolist(), True)
 
+    def node_census(self):
+        """Node types of every recorded graph segment (needs `debug=True`): a list, one dict {type name: count} per segment,
+        read from the hipGraph_t objects with hipGraphGetNodes / hipGraphNodeGetType.  tests/test_gpu_graph.py uses it to
+        check that a recording holds no memset node."""
+        import ctypes
+        if not self.debug:
+            raise RuntimeError("hopmi GraphedTrainStep.node_census: construct with debug=True")
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        hip.hipGraphNodeGetType.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record",
+                 8: "ext_semaphore_signal", 9: "ext_semaphore_wait", 10: "mem_alloc", 11: "mem_free", 12: "memcpy_from_symbol",
+                 13: "memcpy_to_symbol"}
+        out = []
+        for rec in self.records.values():
+            for kind, x in rec["cap"].plan:
+                if kind != "graph":
+                    continue
+                g = ctypes.c_void_p(x.raw_cuda_graph())
+                n = ctypes.c_size_t(0)
+                if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+                    raise RuntimeError("hipGraphGetNodes failed")
+                nodes = (ctypes.c_void_p * max(n.value, 1))()
+                if n.value and hip.hipGraphGetNodes(g, nodes, ctypes.byref(n)) != 0:
+                    raise RuntimeError("hipGraphGetNodes failed")
+                counts = {}
+                for k in range(n.value):
+                    t = ctypes.c_int(-1)
+                    if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[k]), ctypes.byref(t)) != 0:
+                        raise RuntimeError("hipGraphNodeGetType failed")
+                    name = names.get(t.value, f"type{t.value}")
+                    counts[name] = counts.get(name, 0) + 1
+                out.append(counts)
+        return out
+
     def dump_graphs(self, directory):
-        """Write every recorded graph segment as a DOT file (hipGraphDebugDotPrint; needs `debug=True`) and return the paths:
-        what tests/test_gpu_graph.py reads to check which node types a recording holds."""
+        """Write every recorded graph segment as a DOT file (hipGraphDebugDotPrint; needs `debug=True`) and return the paths
+        (diagnostic: which launch a node belongs to)."""
         import os
         if not self.debug:
             raise RuntimeError("hopmi GraphedTrainStep.dump_graphs: construct with debug=True")

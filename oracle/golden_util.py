@@ -20,13 +20,28 @@ def checksum(t: torch.Tensor) -> np.ndarray:
     return np.array([t64.sum().item(), t64.abs().sum().item(), (t64 * w).sum().item()], dtype=np.float64)
 
 
-def checksum_close(got: np.ndarray, want: np.ndarray, rel: float, atol: float = 1e-4) -> bool:
+def checksum_close(got: np.ndarray, want: np.ndarray, rel: float, atol: float = 0.0) -> bool:
     """Compare two checksums relative to the abs-sum (the natural scale of all three).
 
-    `atol` covers gradients that are analytically zero (e.g. a conv bias in front of a
-    training-mode BatchNorm), where both sides hold only rounding noise."""
+    `atol` (default none) is for tensors that are analytically zero, where both sides hold only
+    rounding noise: pass `zero_grad_atol(name)` for gradients."""
     scale = max(abs(want[1]), 1e-30)
     return bool(np.all(np.abs(got - want) <= rel * scale + atol))
+
+
+def zero_grad_param(name: str) -> bool:
+    """Parameters whose gradient is analytically zero: biases that feed straight into a training-mode
+    BatchNorm (gwnet's graph-conv bias, the discriminator's pre_conv conv biases and its first BatchNorm's shift, which
+    the next conv turns into a per-channel constant in front of the next BatchNorm) and the key-projection bias
+    (softmax is invariant to a per-key bias).  What either implementation holds there is rounding noise
+    (~1e-7), which Adam turns into +-lr steps of arbitrary sign."""
+    zero = ("pre_conv.0.bias", "pre_conv.1.bias", "pre_conv.3.bias")      # (1: a BatchNorm shift in front of conv 3 -> BatchNorm 4)
+    return (name.endswith("mlp.mlp.bias") or name in zero or name.split(".", 1)[-1] in zero or name.endswith("key_projection.bias"))
+
+
+def zero_grad_atol(name: str) -> float:
+    """Absolute slack of a gradient checksum: 1e-4 for the analytically-zero gradients, none otherwise."""
+    return 1e-4 if zero_grad_param(str(name)) else 0.0
 
 
 def grad_table(module: torch.nn.Module):

@@ -4,11 +4,14 @@
     melspec     = librosa.feature.melspectrogram(y=audio_padded, sr=16000, n_fft=1024, hop_length=1096, power=2)
     log_melspec = librosa.power_to_db(melspec, ref=np.max).T
 
-PARITY UNPINNED: librosa (pinned at 0.8.1 by the reference, requirements_HOP:35) is a third-party dependency that is neither
-under /root/reference nor importable in the build container, and the reference holds no fixture of this feature.  This file
-restates the published librosa 0.8.1 definitions -- stft(center=True, pad_mode='reflect', window='hann' = scipy
+PARITY PARTLY PINNED: librosa (pinned at 0.8.1 by the reference, requirements_HOP:35) is a third-party dependency that is
+neither under /root/reference nor importable in the build container, and the reference holds no fixture of this feature.
+This file restates the published librosa 0.8.1 definitions -- stft(center=True, pad_mode='reflect', window='hann' = scipy
 get_window('hann', 1024, fftbins=True), win_length = n_fft), filters.mel(htk=False, norm='slaney', fmin=0, fmax=sr/2),
-power_to_db(amin=1e-10, top_db=80.0) -- in float64 numpy (an O(N^2) DFT-free path: numpy.fft.rfft); only tests import it.
+power_to_db(amin=1e-10, top_db=80.0) -- in float64 numpy; only tests import it.  What independent implementations in this
+container can pin is pinned by tests/test_mel_pin.py: the framing / window / reflect padding / FFT half (`stft_power`) against
+torch.stft and scipy's window, the dB stage (`power_to_db`) against its closed form.  The Slaney filter bank (`mel_basis`)
+remains UNPINNED by necessity: only its published structural properties are checked there.
 """
 import numpy as np
 
@@ -41,15 +44,28 @@ def mel_basis(sr=16000, n_fft=1024, n_mels=128):
     return w.astype(np.float32).astype(np.float64)          # librosa returns float32 weights
 
 
-def log_melspec(y, sr=16000, n_fft=1024, hop=1096, n_mels=128, amin=1e-10, top_db=80.0):
-    """y (n_samples,) -> (1 + n_samples // hop, n_mels) float64."""
+def hann_periodic(n_fft=1024):
+    k = np.arange(n_fft)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n_fft)
+
+
+def stft_power(y, n_fft=1024, hop=1096):
+    """|STFT|^2 of librosa.stft(y, n_fft, hop_length=hop, center=True, pad_mode='reflect', window='hann'): (frames, 1 + n_fft/2)."""
     y = np.asarray(y, dtype=np.float64)
     ypad = np.pad(y, n_fft // 2, mode="reflect")
-    k = np.arange(n_fft)
-    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n_fft)    # periodic Hann
+    window = hann_periodic(n_fft)
     n_frames = 1 + y.size // hop
     frames = np.stack([ypad[t * hop:t * hop + n_fft] * window for t in range(n_frames)])
-    power = np.abs(np.fft.rfft(frames, axis=1)) ** 2        # (frames, 513)
-    mel = power @ mel_basis(sr, n_fft, n_mels).T            # (frames, mels)
-    log_spec = 10.0 * np.log10(np.maximum(amin, mel)) - 10.0 * np.log10(np.maximum(amin, mel.max()))
+    return np.abs(np.fft.rfft(frames, axis=1)) ** 2
+
+
+def power_to_db(S, amin=1e-10, top_db=80.0):
+    """librosa.power_to_db(S, ref=np.max, amin, top_db)."""
+    log_spec = 10.0 * np.log10(np.maximum(amin, S)) - 10.0 * np.log10(np.maximum(amin, S.max()))
     return np.maximum(log_spec, log_spec.max() - top_db)
+
+
+def log_melspec(y, sr=16000, n_fft=1024, hop=1096, n_mels=128, amin=1e-10, top_db=80.0):
+    """y (n_samples,) -> (1 + n_samples // hop, n_mels) float64."""
+    mel = stft_power(y, n_fft, hop) @ mel_basis(sr, n_fft, n_mels).T            # (frames, mels)
+    return power_to_db(mel, amin, top_db)

@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.golden_util import zero_grad_atol
+
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-3          # north_star tolerance: 1e-3 relative, fp32
@@ -14,16 +16,37 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def rel_err(got, want):
+def _f64(got, want):
     got = got.detach().cpu().double()
     want = torch.as_tensor(np.asarray(want)).double() if not torch.is_tensor(want) else want.detach().cpu().double()
     assert got.shape == want.shape, (got.shape, want.shape)
+    return got, want
+
+
+def rel_err(got, want):
+    """max |got - want| / max |want|: the max-norm number (reported next to the elementwise criterion, used where a scalar
+    error is propagated into another tolerance)."""
+    got, want = _f64(got, want)
     return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
 
 
 def assert_close(got, want, rtol=RTOL, what=""):
-    e = rel_err(got, want)
-    assert e <= rtol, f"{what} rel err {e:.3e} > {rtol}"
+    """Elementwise: |got - want| <= rtol |want| + rtol rms(want).  The absolute term is tied to the tensor's RMS, not to its
+    largest element: an element far below the typical magnitude may only be off by rtol of that typical magnitude (what fp32
+    accumulation over terms of typical size allows), never by rtol of the maximum.  The message also carries the max-norm
+    relative error."""
+    got, want = _f64(got, want)
+    if want.numel() == 0:
+        return
+    rms = want.pow(2).mean().sqrt().item()
+    excess = (got - want).abs() - (rtol * want.abs() + rtol * rms)
+    worst = excess.max().item()
+    if not worst <= 0.0:                      # (also catches NaN)
+        k = int(torch.nan_to_num(excess, nan=float("inf")).argmax())
+        g, w = got.flatten()[k].item(), want.flatten()[k].item()
+        frac = (excess > 0).double().mean().item()
+        raise AssertionError(f"{what}: element {k}: got {g:.6e} want {w:.6e} (|d| {abs(g - w):.3e} > {rtol} (|want| + rms {rms:.3e})); "
+                             f"{frac:.2e} of the elements out of tolerance; max-norm rel err {rel_err(got, want):.3e}")
 
 
 # ------------------------------------------------------------------------------------ gcn kernel
@@ -380,7 +403,7 @@ def test_gwnet_vs_reference_golden(golden, V, training):
     assert_close(x0.grad.flatten()[::97], g["dx0_sample"], what="dx0")
     params = dict(m.named_parameters())
     for n, want in zip(g["grad_names"], g["grad_cs"]):
-        assert checksum_close(checksum(params[str(n)].grad), want, RTOL), n
+        assert checksum_close(checksum(params[str(n)].grad), want, RTOL, zero_grad_atol(n)), n
     for n in g["nograd_names"]:
         assert params[str(n)].grad is None, n
     for i in range(8):
@@ -640,7 +663,7 @@ def test_model_vs_reference_golden(golden, V):
     ((out * fill.uniform("model.gout", out.shape).to(dev)).sum() + 0.3 * z.sum() + 0.1 * (mu * mu).sum() + 0.2 * lv.exp().sum()).backward()
     params = dict(m.named_parameters())
     for n, want in zip(g["grad_names"], g["grad_cs"]):
-        assert checksum_close(checksum(params[str(n)].grad), want, RTOL), n
+        assert checksum_close(checksum(params[str(n)].grad), want, RTOL, zero_grad_atol(n)), n
     for n in g["nograd_names"]:
         assert params[str(n)].grad is None, n
     for i in range(8):
@@ -724,7 +747,7 @@ def test_model_ablation_branches_vs_reference_golden(golden, V, use_gwnet, use_r
             wgrad = params[n.replace(".bias", ".weight")].grad
             assert params[n].grad.abs().sum() <= 1e-3 * wgrad.abs().sum(), n
             continue
-        assert checksum_close(checksum(params[n].grad), want, RTOL), n
+        assert checksum_close(checksum(params[n].grad), want, RTOL, zero_grad_atol(n)), n
     for n in g["nograd_names"]:
         assert params[str(n)].grad is None, n
 
@@ -897,13 +920,14 @@ def _oracle_full_step(V, B, epoch, bcfg, inp, n_spk=11, n_steps=1):
     od = torch.optim.Adam([v for v in d_sd.values() if v.requires_grad], lr=1e-4, betas=(0.5, 0.999))
     torch.manual_seed(777)
     rng = lambda kind, shape: torch.randperm(shape[0]) if kind == "perm" else torch.randn(shape)
-    rets = []
+    rets, outs = [], []
     for _ in range(n_steps):
         want, out, _, _, out_rand = ref_cpu.train_llm_step(step_args(V), hop_cfg(V, bcfg.hidden_size), epoch, inp, g_sd, d_sd, og, od, rng,
                                                            bert_heads=bcfg.num_attention_heads)
         rets.append(want)
+        outs.append(out)
     keep = ("mapping_layer.weight", "gru.weight_hh_l0", "beat.0.weight", "reprogramming_layer.out_projection.weight")
-    _FULL[key] = dict(ret=want, rets=rets, out=out, out_rand=out_rand,
+    _FULL[key] = dict(ret=want, rets=rets, outs=outs, out=out, out_rand=out_rand,
                       bn={k: v.detach().clone() for k, v in g_sd.items() if ".bn." in k and "running_" in k},
                       params={k: g_sd[k].detach().clone() for k in keep},
                       dparams={k: v.detach().clone() for k, v in d_sd.items() if k in ("out.weight", "gru.weight_hh_l0")})
@@ -1069,7 +1093,7 @@ def test_discriminator_vs_reference_golden(golden, P):
     assert_close(x.grad, g["dx"], what="D dx")
     params = dict(d.named_parameters())
     for n, want in zip(g["grad_names"], g["grad_cs"]):
-        assert checksum_close(checksum(params[str(n)].grad), want, RTOL), n
+        assert checksum_close(checksum(params[str(n)].grad), want, RTOL, zero_grad_atol(n)), n
     assert_close(d.pre_conv[1].running_mean, g["bn1_rm"], what="bn1 rm")
     assert_close(d.pre_conv[1].running_var, g["bn1_rv"], what="bn1 rv")
 
