@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3   # exact-f32 MFMA == vector peak
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def parse():
@@ -108,8 +108,12 @@ def cpu_baseline(args, V):
 
 
 def roofline(ks, V, B, n_kernel_steps):
-    """The roofline object from the kernel region's event timings."""
-    gf = ks["wn_layer_fwd"]
+    """The roofline object from the kernel region's event timings.  The graded kernel is the fused WaveNet forward: as ONE
+    persistent launch per training forward (hopmi_wn_stack_fwd: 8 layers incl. the BatchNorm statistics exchange) when the
+    run used it, else the per-layer launches (hopmi_wn_layer_fwd)."""
+    stack = "wn_stack_fwd" in ks and ks["wn_stack_fwd"]["launches"] > 0
+    name = "wn_stack_fwd" if stack else "wn_layer_fwd"
+    gf = ks[name]
     sec = gf["kernel_ms"] * 1e-3
     gbs = gf["bytes"] / sec / 1e9
     moved = (gf["bytes"] + gf["extra_bytes"]) / sec / 1e9
@@ -119,35 +123,44 @@ def roofline(ks, V, B, n_kernel_steps):
         with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_traffic.json")) as f:
             t = json.load(f)
         if t.get("V") == V and t.get("B") == B:
-            traffic = t["kernels"]["wn_layer_fwd"]["hbm_bytes_per_launch"]
+            traffic = t["kernels"][name]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         traffic = None
     floor_us = 1e3 * ks["noop"]["kernel_ms"] / ks["noop"]["launches"] if ks.get("noop", {}).get("launches") else None
-    r = {"kernel": "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv: BN-on-load, gated TCN, skip tail, "
-                   "node mix, graph conv, residual, BN statistics); the 8 layer launches of every training forward",
+    r = {"kernel": ("wn_stack_fwd_kernel: the WHOLE WaveNet stack of a training forward as one persistent launch -- per layer BN-on-load, "
+                    "gated TCN, skip tail, node mix, graph conv, residual, BatchNorm batch statistics, plus the chip-wide exchange of "
+                    "those statistics between layers (training-mode BatchNorm makes every layer depend on all clips) and the "
+                    "BatchNorm finalisation" if stack else
+                    "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv: BN-on-load, gated TCN, skip tail, "
+                    "node mix, graph conv, residual, BN statistics); the 8 layer launches of every training forward"),
          "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
          "traffic": traffic, "launches": gf["launches"], "avg_us": 1e3 * gf["kernel_ms"] / gf["launches"],
          "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
-         "bytes_definition": "SURVEY.md 8(d), fused layer: 4 B x 64 ch x V x (B*T_in read + B*T_out written + 4*B skip-tail frames)",
+         "bytes_definition": ("SURVEY.md 8(d), fused layers, summed over the 8 layers of the launch: 4 B x 64 ch x V x (B*T_in read + "
+                              "B*T_out written (not the dead last layer's) + 4*B skip-tail frames)" if stack else
+                              "SURVEY.md 8(d), fused layer: 4 B x 64 ch x V x (B*T_in read + B*T_out written + 4*B skip-tail frames)"),
          "moved_bytes_per_launch": (gf["bytes"] + gf["extra_bytes"]) / gf["launches"],
          "moved_gbs": moved, "moved_frac": moved / HBM_PEAK_GBS,
          "f32_mfma_equiv_tflops": tfl, "f32_mfma_equiv_frac": tfl / F32_MFMA_PEAK_TFLOPS,
          "empty_kernel_us": floor_us,
-         "empty_kernel_note": "duration the SAME timing method reports for an empty kernel of the same launch shape, launched next to "
-                              "the first layer kernel of every forward (rocprofv3's kernel trace shows the same ~3.6-3.9 us): "
+         "empty_kernel_note": "duration the SAME timing method reports for an empty kernel of a layer launch's shape, launched next to "
+                              "the graded kernel in every forward (rocprofv3's kernel trace shows the same ~3.6-3.9 us): "
                               "`achieved` / `frac` use the raw durations and so include it",
          "frac_net_of_empty_kernel": (gf["bytes"] / ((gf["kernel_ms"] - gf["launches"] * floor_us * 1e-3) * 1e-3) / 1e9 / HBM_PEAK_GBS
                                       if floor_us is not None and gf["kernel_ms"] > gf["launches"] * floor_us * 1e-3 else None),
-         "timing": f"start/stop HIP events attached to each wn_layer_fwd dispatch (hipExtLaunchKernelGGL) on the launch stream, "
+         "timing": f"start/stop HIP events attached to each {name} dispatch (hipExtLaunchKernelGGL) on the launch stream, "
                    f"over {n_kernel_steps} instrumented eager train_llm steps run before the timed region (the timed region "
                    "itself carries no instrumentation); the other kernels' *_avg_us are event pairs minus the smallest "
                    "empty-pair interval"}
-    for name in ("wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "bert_attn_fwd", "bert_attn_bwd", "gru_fwd", "gru_bwd"):
-        if name in ks and ks[name]["launches"]:
-            k = ks[name]
-            r[name + "_avg_us"] = 1e3 * k["kernel_ms"] / k["launches"]
+    if stack:
+        r["previous_form"] = ("rounds 1-2 ran this forward as 8 x (wn_layer_fwd + wn_bn_finalize) launches: 165 us per forward at "
+                              "TED / B = 128 (profiles/r02_bench_kernel_stats.csv), i.e. 0.043 of the HBM peak on the same bytes")
+    for name2 in ("wn_layer_regate", "wn_layer_bwd", "reprog_attn_fwd", "reprog_attn_bwd", "bert_attn_fwd", "bert_attn_bwd", "gru_fwd", "gru_bwd"):
+        if name2 in ks and ks[name2]["launches"]:
+            k = ks[name2]
+            r[name2 + "_avg_us"] = 1e3 * k["kernel_ms"] / k["launches"]
             if k["flops"]:
-                r[name + "_tflops"] = k["flops"] / (k["kernel_ms"] * 1e-3) / 1e12
+                r[name2 + "_tflops"] = k["flops"] / (k["kernel_ms"] * 1e-3) / 1e12
     return r
 
 
@@ -288,7 +301,13 @@ def main():
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "median_ms_per_step": median_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 library GEMMs (autocast), bf16 activations between them (dtype argument of the BERT / GRU / attention HIP kernels) + bf16 gradient exchange; f32 arithmetic inside the HIP kernels, f32 WaveNet stack, master weights and optimizer",
+            "dtype": ("f32 storage, accumulation and elementwise arithmetic; the contractions inside the hand-written kernels run on the bf16 "
+                      "matrix cores as split-bf16 products with f32 accumulation: THREE terms (~2^-16 per product) in the WaveNet "
+                      "(wn_stack / wn_layer fwd + bwd), reprogramming-attention and GRU-recurrence kernels, SIX terms (f32-equivalent) "
+                      "in the frozen BERT's linears; library GEMMs f32" if args.dtype == "fp32" else
+                      "bf16 library GEMMs (autocast), bf16 activations between them (dtype argument of the BERT / GRU / attention HIP "
+                      "kernels) + bf16 gradient exchange; inside the HIP kernels f32 accumulation and elementwise arithmetic with "
+                      "split-bf16 MFMA products (3 terms, ~2^-16 per product); f32 WaveNet stack, master weights and optimizer"),
             "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{1 if V == 9 else 3}] per GPU: {args.dataset} {V + 1}-joint ({V} graph nodes), "
                                    f"34-frame clips, batch {B}/GPU, {args.dtype}, one full train_llm step = "
@@ -317,6 +336,8 @@ def main():
                                    "prototype rows of the mapping layer sharded over ranks (all-gather S, all-reduce dS), "
                                    "one flat all-reduce of the other gradients per module, eager RCCL calls between graph launches",
                        "llm": "BERT-base geometry, 6 layers, random init, frozen",
+                       "arithmetic": "per-kernel error against float64 next to plain fp32 torch: tests/test_gpu_parity.py::test_*_vs_float64 "
+                                     "(three-term split-bf16 kernels: within K x the fp32 reference's own error, K stated per test)",
                        "bert_gemm": ("library bf16 GEMMs (autocast)" if args.dtype != "fp32" else
                                      {"library": "library fp32 GEMMs (hipBLASLt)",
                                       "split3": "hopmi_gemm_split, 3 bf16 parts per operand, 6 MFMA terms: fp32-equivalent (error vs float64 "

@@ -19,6 +19,10 @@
 // zero-padded to a multiple of 64 and split over the 4 waves in 16-wide chunks read back as ds_read_b128
 // MFMA operands; the 4 partial tiles are summed through LDS and the gate math is the epilogue.
 // h_prev is read from the layer output y itself.
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "bf16_dev.h"
 
 namespace hopmi {
@@ -803,12 +807,52 @@ static int gru_num_cus() {
 }
 
 
+// How many workgroups of a persistent kernel the device holds at once: the runtime's occupancy answer for this kernel, block
+// size and LDS request, times the CUs (cached per kernel; queried outside any stream capture: the first call of a shape is an
+// eager one).  These 512-thread, LDS-heavy kernels are admitted once or twice per CU by LDS and registers, far from the 7-8-per-CU
+// edge where the query reads one high (MI355X_MICROARCH.md, residency): the answer is used as it stands, capped at 2.
+static int gru_resident_capacity(const void* fn, size_t lds) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  for (const auto& e : cache)
+    if (e.first == fn) return e.second;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    per_cu = 1;                                      // the launch itself would fail if not even one fitted
+  }
+  if (per_cu > 2) per_cu = 2;
+  const int cap = per_cu * gru_num_cus();
+  cache.emplace_back(fn, cap);
+  return cap;
+}
+
+template <bool FWD, typename TG>
+static int gru_persistent_capacity(int H) {
+  const int mk = (H + 127) / 128;
+#define HOPMI_GP_CAP(MK_)                                                                                                    \
+  {                                                                                                                          \
+    constexpr int WS2 = (128 * MK_ + 48) / 2;                                                                                \
+    if (FWD)                                                                                                                 \
+      return gru_resident_capacity(reinterpret_cast<const void*>(&gru_fwd_persistent_kernel<MK_, TG>),                        \
+                                   (size_t)2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_F * sizeof(float));  \
+    return gru_resident_capacity(reinterpret_cast<const void*>(&gru_bwd_persistent_kernel<MK_, TG>),                          \
+                                 (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_B * sizeof(float)); \
+  }
+  if (mk <= 1) HOPMI_GP_CAP(1)
+  if (mk == 2) HOPMI_GP_CAP(2)
+  HOPMI_GP_CAP(3)
+#undef HOPMI_GP_CAP
+}
+
 // persistent path iff the caller gave a workspace (the host side withholds it when it cannot promise that nothing else
 // competes for the CUs: HOPMI_GRU_PERSISTENT=0, an RCCL exchange in flight, a shared device) and every workgroup can be
-// resident at once (at most one per CU asked for)
+// resident at once (occupancy query x CUs)
+template <bool FWD, typename TG>
 static bool gru_persistent_ok(int B, int H, const void* ws) {
   const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
-  return ws != nullptr && gp_grid(nJ, nbb) <= gru_num_cus();
+  return ws != nullptr && gp_grid(nJ, nbb) <= gru_persistent_capacity<FWD, TG>(H);
 }
 
 extern "C" size_t hopmi_gru_ws_bytes(int B, int T, int H) {
@@ -840,7 +884,7 @@ static int gru_fwd_impl(const TG* gi, const float* whh, const float* bhh, float*
     hipLaunchKernelGGL((gru_fwd_small_kernel<TG>), dim3(2 * ((B + 15) / 16)), dim3(256), 0, st, gi, whh, bhh, y, gates, B, T);
     return check_launch("hopmi_gru_fwd(small)");
   }
-  if (gru_persistent_ok(B, H, ws)) {
+  if (gru_persistent_ok<true, TG>(B, H, ws)) {
     const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
     int* status = gru_status_word(ws, B, T, H);
     gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), y, (size_t)B * T * 2 * H, st);
@@ -899,7 +943,7 @@ static int gru_bwd_impl(const float* dy, const float* y, const float* gates, con
   const void* ptrs[] = {dy, y, gates, whhT, dgi, dgh, ws};
   if (int e = gru_validate(ptrs, 7, B, T, H)) return e;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gru_persistent_ok(B, H, ws2)) {
+  if (gru_persistent_ok<false, TG>(B, H, ws2)) {
     const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
     int* status = gru_status_word(ws2, B, T, H);
     gru_prepare(ws2, hopmi_gru_ws_bytes(B, T, H), dgh, (size_t)B * T * 2 * 3 * H, st);

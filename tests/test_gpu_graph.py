@@ -368,7 +368,13 @@ def test_graphed_step_baseline_size_vs_oracle(V, B, epoch, monkeypatch):
             assert abs(ret[k] - want[k]) <= t * max(abs(want[k]), 1e-6), (it, k, ret[k], want[k], f"eps {eps} cond {cond:.1f}")
     sd = m.state_dict()
     for k, v in o["bn"].items():
-        assert_close(sd[k], v, tol(n_steps - 1), what=k)
+        if k.endswith("running_mean"):
+            # the graph-conv bias in front of this BatchNorm has an analytically zero gradient: Adam walks it by +-lr per step on
+            # rounding noise, differently on the two sides, and the batch mean moves with it (the normalised output does not)
+            diff = (sd[k].cpu() - v).abs().max().item()
+            assert diff <= tol(n_steps - 1) * v.abs().max().item() + n_steps * 1e-3, (k, diff)
+        else:
+            assert_close(sd[k], v, tol(n_steps - 1), what=k)
     for n, v in o["params"].items():
         a, b = checksum(sd[n]), checksum(v)
         assert checksum_close(a, b, tol(n_steps - 1), n_steps * 2e-3 * 64), (n, a, b)
@@ -412,15 +418,18 @@ def test_graphed_step_epoch_10_to_11_transition(eager_calls, monkeypatch):
         got = graphed(epoch, *batch)
         assert sorted(got) == sorted(want), (it, got, want)
         for k in want:
-            # (Adam noise as in test_graphed_step_equals_eager; the discriminator trains at lr 1e-3 here, 10 x the usual)
-            assert abs(got[k] - want[k]) <= 1e-3 * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])
+            # (Adam noise as in test_graphed_step_equals_eager; the discriminator trains at lr 1e-3 here, 10 x the usual.
+            # DIV_REG is a ratio of two small differences between the step's two forwards: it amplifies that noise ~50 x)
+            assert abs(got[k] - want[k]) <= (1e-3 if k != "DIV_REG" else 2e-2) * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])
     assert graphed.n_eager == 2 and len(graphed.records) == 2
     n_gan = sum(e > 10 for e in epochs)
     for (n, a), (_, b) in zip(d1.named_parameters(), d2.named_parameters()):
         assert float(o2.state[b]["step"]) == n_gan == float(o1.state[a]["step"]), n
         ea, eb = o1.state[a]["exp_avg"], o2.state[b]["exp_avg"]
         if not (n.startswith("pre_conv.") and n.endswith(".bias")):      # (analytically zero gradients: rounding noise)
-            assert (ea - eb).abs().max().item() <= 1e-3 * ea.abs().max().item() + 1e-9, n
+            # (a state re-created by every replay would hold (1 - beta1) g of the last step only: ~half of the accumulated moment;
+            # the Adam noise between the two runs is per cent at most)
+            assert (ea - eb).abs().max().item() <= 5e-2 * ea.abs().max().item() + 1e-9, n
         diff = (a - b).abs()
         assert diff.max().item() <= 4.5e-3 and diff.mean().item() <= 1e-3, (n, diff.max().item(), diff.mean().item())
 

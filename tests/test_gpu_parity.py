@@ -1337,6 +1337,121 @@ def test_gemm_split_vs_float64(M, N, K, parts, tol):
     assert torch.equal(y_ab, y.detach())
 
 
+# ---- the three-term split-bf16 kernels against float64, next to plain fp32 torch ---------------------------------------------
+# hopmi_gemm_split carries operands as three bf16 numbers (six MFMA terms) and is fp32-EQUIVALENT (test above).  The WaveNet,
+# reprogramming-attention and GRU-recurrence kernels carry them as TWO (hi + lo, 16 significand bits) and sum three MFMA terms
+# with fp32 accumulation: a product is good to ~2^-16 instead of fp32's 2^-24, so against float64 these kernels sit 2^8 = 256 x
+# above an fp32 evaluation of the same contraction in the worst case (random-sign terms: both errors grow with sqrt(K), the ratio
+# stays) -- and two orders of magnitude inside the north_star's 1e-3.  The tests pin exactly that: error vs float64 <= K_SPLIT3 x
+# the error of the plain-PyTorch fp32 evaluation (+ one fp32 rounding of the result), and <= CAP_SPLIT3 outright.
+K_SPLIT3 = 256.0
+CAP_SPLIT3 = 6e-5
+
+
+def _assert_split3_class(dev_out, f32_out, f64_out, what):
+    e_dev, e_32 = rel_err(dev_out, f64_out), rel_err(f32_out, f64_out)
+    assert e_dev <= CAP_SPLIT3, f"{what}: error vs float64 {e_dev:.3e} > {CAP_SPLIT3} (plain fp32: {e_32:.3e})"
+    assert e_dev <= K_SPLIT3 * e_32 + 1.2e-7, f"{what}: error vs float64 {e_dev:.3e} > {K_SPLIT3} x plain fp32's {e_32:.3e}"
+    return e_dev, e_32
+
+
+@pytest.mark.parametrize("V,B", [(9, 128), (42, 64)])
+def test_wn_layer_vs_float64(V, B):
+    """One fused WaveNet layer (hopmi_wn_layer_fwd: gated TCN K = 128, graph conv K = 192 as three-term split-bf16 products, node
+    mix on the exact-fp32 MFMA) at the BASELINE.json shapes: pre-BatchNorm output y and the gated activations' skip tail against
+    the float64 evaluation of gwnet.py:186-233, next to the same layer evaluated with plain fp32 torch ops."""
+    from hopmi import ops
+    from oracle import ref_cpu
+    dev = _dev()
+    g = torch.Generator().manual_seed(17 + V)
+    T, d = 16, 1
+    x = torch.randn(B, 64, V, T, generator=g)                                  # NCHW, as the oracle takes it
+    wf, wg = torch.randn(64, 64, 1, 2, generator=g) / 11, torch.randn(64, 64, 1, 2, generator=g) / 11
+    bf, bg = torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.3
+    Wm, bm = torch.randn(64, 192, 1, 1, generator=g) / 14, torch.randn(64, generator=g) * 0.3
+    A = torch.softmax(torch.randn(V, V, generator=g), 1)
+
+    def layer(cast):
+        c = lambda t: t.to(cast)
+        u = ref_cpu.gated_tcn(c(x), c(wf), c(bf), c(wg), c(bg), d)
+        y = ref_cpu.gcn(u, c(A), c(Wm), c(bm)) + c(x)[..., d:]
+        return y, u[..., -4:]
+
+    y64, t64 = layer(torch.float64)
+    y32, t32 = layer(torch.float32)
+    xd = x.permute(0, 3, 2, 1).contiguous().to(dev)
+    Ad = A.to(dev)
+    prep = ops.gcn_prepare(Ad, Ad @ Ad)
+    wimg = ops.wn_prepare_weights([(wf.to(dev), wg.to(dev), Wm.to(dev).contiguous())])[0]
+    tails = torch.empty(B, 4, V, 64, device=dev)
+    scsh = torch.cat([torch.ones(64), torch.zeros(64)]).to(dev)
+    y, _, _, _ = ops.wn_layer_fwd(xd, scsh, wimg, bf.to(dev), bg.to(dev), prep, bm.to(dev), tails, d, want_y=True, do_gcn=True)
+    torch.cuda.synchronize()
+    _assert_split3_class(y.permute(0, 3, 2, 1), y32, y64, "y")
+    _assert_split3_class(tails.permute(0, 3, 2, 1), t32, t64, "skip tail")
+
+
+def test_reprog_attention_vs_float64():
+    """hopmi_reprog_attn_fwd / _bwd (scores, P V and the three backward contractions as three-term split-bf16 products, softmax in
+    fp32) at the real dimensions (34 x 8 heads x 128 against 1500 prototypes; B = 16 keeps the float64 score tensor small):
+    output and dq, dk, dv against float64, next to plain fp32 torch."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    B, L, H, E, S = 16, 34, 8, 128, 1500
+    q, k, v = torch.randn(B, L, H, E, generator=g), torch.randn(S, H, E, generator=g), torch.randn(S, H, E, generator=g)
+    go = torch.randn(B, L, H, E, generator=g)
+    scale = 1.0 / E ** 0.5
+
+    def attn(cast):
+        qq, kk, vv = (t.to(cast).requires_grad_() for t in (q, k, v))
+        p = torch.softmax(scale * torch.einsum("blhe,she->bhls", qq, kk), dim=-1)
+        o = torch.einsum("bhls,she->blhe", p, vv)
+        (o * go.to(cast)).sum().backward()
+        return o.detach(), qq.grad, kk.grad, vv.grad
+
+    ref64, ref32 = attn(torch.float64), attn(torch.float32)
+    qd, kd, vd = (t.to(dev).requires_grad_() for t in (q, k, v))
+    o = ops.reprog_attention(qd, kd, vd, scale, 0.0, 0)
+    (o * go.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    for name, got, r32, r64 in zip(("o", "dq", "dk", "dv"), (o, qd.grad, kd.grad, vd.grad), ref32, ref64):
+        _assert_split3_class(got, r32, r64, name)
+
+
+def test_gru_recurrence_vs_float64(monkeypatch):
+    """hopmi_gru_fwd / hopmi_gru_bwd (the recurrent product h W_hh^T as three-term split-bf16 MFMA products with the fragments in
+    registers; input projections and weight gradients are library fp32 GEMMs) at the decoder's shape (B = 128, T = 34, 992 -> 350,
+    two of its four bidirectional layers): output, input gradient and the recurrent weights' gradients against a float64
+    nn.GRU, next to the fp32 nn.GRU on the host.  34 dependent steps carry a step's error forward, for both evaluations."""
+    from hopmi import ops
+    dev = _dev()
+    monkeypatch.setattr(ops, "GRU_CHECK_STATUS", True)
+    torch.manual_seed(5)
+    B, T, I, H, Lyr = 128, 34, 992, 350, 2
+    gru = torch.nn.GRU(I, H, num_layers=Lyr, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, I)
+    gy = torch.randn(B, T, 2 * H)
+
+    def run(mod, xx, gg):
+        xx = xx.clone().requires_grad_()
+        y, _ = mod(xx)
+        (y * gg).sum().backward()
+        return [y.detach(), xx.grad] + [mod.get_parameter(n).grad for n in ("weight_hh_l0", "weight_hh_l1_reverse", "weight_ih_l1")]
+
+    import copy
+    ref32 = run(copy.deepcopy(gru), x, gy)
+    ref64 = run(copy.deepcopy(gru).double(), x.double(), gy.double())
+    gd = copy.deepcopy(gru).to(dev)
+    xd = x.to(dev).requires_grad_()
+    yd = ops.gru_bidirectional(xd, gd)
+    (yd * gy.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    got = [yd, xd.grad] + [gd.get_parameter(n).grad for n in ("weight_hh_l0", "weight_hh_l1_reverse", "weight_ih_l1")]
+    for name, a, r32, r64 in zip(("y", "dx", "dW_hh l0", "dW_hh l1 reverse", "dW_ih l1"), got, ref32, ref64):
+        _assert_split3_class(a, r32, r64, name)
+
+
 def test_bert_fast_path_split_gemm_vs_reference_golden(golden):
     """The frozen BERT through hopmi_gemm_split (3 and 2 parts) against the HF reference golden (BERT-base geometry)."""
     import hopmi
