@@ -32,6 +32,11 @@ SIGNATURES = {
     "hopmi_wn_stack_grid": (_I, [_I, _I, _I, _VP, _I]),
     "hopmi_wn_stack_ws_bytes": (ctypes.c_size_t, [_I, _I, _I, _VP, _I]),
     "hopmi_wn_stack_fwd": (_I, [_VP] * 10 + [ctypes.c_float, ctypes.c_float] + [_VP] * 2 + [_I] + [_VP] * 3 + [_I] * 3 + [_VP, _I, _VP]),
+    "hopmi_gcn_fwd_dt": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "hopmi_gcn_bwd_dt": (_I, [_VP] * 10 + [_I, _I, _I, _VP]),
+    "hopmi_wn_layer_fwd_dt": (_I, [_VP] * 10 + [_I] + [_VP] + [_I] * 6 + [_VP]),
+    "hopmi_wn_stack_fwd_dt": (_I, [_VP] * 10 + [ctypes.c_float, ctypes.c_float] + [_VP] * 2 + [_I] + [_VP] * 3 + [_I] * 3 + [_VP, _I, _I, _VP]),
+    "hopmi_wn_layer_bwd_dt": (_I, [_VP] * 9 + [_I] + [_VP] * 3 + [_I] + [_VP] * 11 + [_I] + [_VP] * 4 + [_I] * 6 + [_VP]),
     "hopmi_wn_layer_bwd_ws_floats": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "hopmi_wn_layer_bwd": (_I, [_VP] * 9 + [_I] + [_VP] * 3 + [_I] + [_VP] * 11 + [_I] + [_VP] * 4 + [_I] * 5 + [_VP]),
     "hopmi_hop_losses_ws_floats": (ctypes.c_size_t, [_I]),

@@ -42,10 +42,11 @@ __global__ __launch_bounds__(256) void gcn_prepare_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(256) void gcn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prep,
+// TS = storage type of x and h (float or __bf16, io_dev.h); arithmetic fp32
+template <int MT, typename TS>
+__global__ __launch_bounds__(256) void gcn_fwd_kernel(const TS* __restrict__ x, const float* __restrict__ prep,
                                                       const float* __restrict__ Wm,
-                                                      const float* __restrict__ bm, float* __restrict__ h,
+                                                      const float* __restrict__ bm, TS* __restrict__ h,
                                                       int n_slabs, GcnGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hc = smem;                               // [rows_lds][LDH]
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * mt + 4 * q + r;
-      if (row < R) h[(row0 + row) * C + 16 * w + j] = acc[mt][r] + bias;
+      if (row < R) st1(h + (row0 + row) * C + 16 * w + j, acc[mt][r] + bias);
     }
   }
   HOPMI_STAMP(5);
@@ -122,10 +123,10 @@ constexpr int DA_SLOTS = 5;        // ceil(3*6/4): dA accumulator tiles per wave
 // Persistent over tiles: dWm / dbm / dA partial sums stay in registers across the block's
 // tiles and are written once to part[blockIdx.x][...] (summed by gcn_bwd_reduce_kernel in a
 // fixed order: reproducible, no atomics).  MT = 16-row MFMA tiles per block tile (exact).
-template <int MT>
-__global__ __launch_bounds__(256) void gcn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dh,
+template <int MT, typename TS>
+__global__ __launch_bounds__(256) void gcn_bwd_kernel(const TS* __restrict__ x, const TS* __restrict__ dh,
                                                       const float* __restrict__ prep,
-                                                      const float* __restrict__ Wm, float* __restrict__ dx,
+                                                      const float* __restrict__ Wm, TS* __restrict__ dx,
                                                       float* __restrict__ part, int n_slabs, GcnGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hc = smem;                                // [rows_lds][LDH]  X | X A1 | X A2
@@ -223,9 +224,9 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(const float* __restrict__ 
     __syncthreads();
 
     // (3) dX[s] = G0 + A1 G1 + A2 G2
-    if (g.K2P == 20) dx_mix<5>(Gs, AB, dx, row0, g, nsl, w, q, j);          // V = 9
-    else if (g.K2P == 84) dx_mix<21>(Gs, AB, dx, row0, g, nsl, w, q, j);    // V = 42
-    else dx_mix<0>(Gs, AB, dx, row0, g, nsl, w, q, j);
+    if (g.K2P == 20) dx_mix<5, TS>(Gs, AB, dx, row0, g, nsl, w, q, j);          // V = 9
+    else if (g.K2P == 84) dx_mix<21, TS>(Gs, AB, dx, row0, g, nsl, w, q, j);    // V = 42
+    else dx_mix<0, TS>(Gs, AB, dx, row0, g, nsl, w, q, j);
 
     // (4) dA{1,2}[v][w'] += sum_{s,c} X[s,v,c] G{1,2}[s,w',c]; output tiles dealt round-robin to waves;
     //     K (= c) permuted as c = 16i + 4q + e -> b128 operand reads
@@ -359,29 +360,29 @@ static int validate(const void* const* ptrs, int nptr, int n_slabs, int V) {
   return HOPMI_OK;
 }
 
-template <int MT>
-static int launch_fwd(const float* x, const float* prep, const float* Wm, const float* bm, float* h,
+template <int MT, typename TS>
+static int launch_fwd(const TS* x, const float* prep, const float* Wm, const float* bm, TS* h,
                       int n_slabs, const GcnGeom& g, hipStream_t st) {
   const size_t lds = (size_t)(g.rows_lds * LDH + g.KP * g.ldA) * sizeof(float);
   // only raise the dynamic-LDS cap when a launch needs it, and only to what it needs
   static size_t attr_lds = 64 * 1024;
   if (lds > attr_lds && env_int("HOPMI_NO_LDS_ATTR", 0) == 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_fwd_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_fwd_kernel<MT, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(gcn_fwd_kernel<MT>, dim3(g.ntiles), dim3(256), lds, st, x, prep, Wm, bm, h, n_slabs, g);
+  hipLaunchKernelGGL((gcn_fwd_kernel<MT, TS>), dim3(g.ntiles), dim3(256), lds, st, x, prep, Wm, bm, h, n_slabs, g);
   return check_launch("hopmi_gcn_fwd");
 }
 
-template <int MT>
-static void launch_bwd(const float* x, const float* dh, const float* prep, const float* Wm, float* dx,
+template <int MT, typename TS>
+static void launch_bwd(const TS* x, const TS* dh, const float* prep, const float* Wm, TS* dx,
                        float* ws, int n_slabs, const GcnGeom& g, int grid, size_t lds, hipStream_t st) {
   static size_t attr_lds = 64 * 1024;
   if (lds > attr_lds && env_int("HOPMI_NO_LDS_ATTR", 0) == 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_bwd_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gcn_bwd_kernel<MT, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(gcn_bwd_kernel<MT>, dim3(grid), dim3(256), lds, st, x, dh, prep, Wm, dx, ws, n_slabs, g);
+  hipLaunchKernelGGL((gcn_bwd_kernel<MT, TS>), dim3(grid), dim3(256), lds, st, x, dh, prep, Wm, dx, ws, n_slabs, g);
 }
 
 }  // namespace hopmi
@@ -402,23 +403,36 @@ extern "C" int hopmi_gcn_prepare(const float* A1, const float* A2, float* prep, 
   return check_launch("hopmi_gcn_prepare");
 }
 
-extern "C" int hopmi_gcn_fwd(const float* x, const float* prep, const float* Wm, const float* bm,
-                             float* h, int n_slabs, int V, void* stream) {
+template <typename TS>
+static int gcn_fwd_impl(const TS* x, const float* prep, const float* Wm, const float* bm, TS* h, int n_slabs, int V, void* stream) {
   const void* ptrs[] = {x, prep, Wm, bm, h};
   if (int e = validate(ptrs, 5, n_slabs, V)) return e;
   const GcnGeom g = make_geom(n_slabs, V, pick_fwd_slabs(n_slabs, V));
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (g.mtiles) {
-    case 1: return launch_fwd<1>(x, prep, Wm, bm, h, n_slabs, g, st);
-    case 2: return launch_fwd<2>(x, prep, Wm, bm, h, n_slabs, g, st);
-    case 3: return launch_fwd<3>(x, prep, Wm, bm, h, n_slabs, g, st);
-    case 4: return launch_fwd<4>(x, prep, Wm, bm, h, n_slabs, g, st);
-    case 5: return launch_fwd<5>(x, prep, Wm, bm, h, n_slabs, g, st);
-    case 6: return launch_fwd<6>(x, prep, Wm, bm, h, n_slabs, g, st);
-    case 7: return launch_fwd<7>(x, prep, Wm, bm, h, n_slabs, g, st);
-    case 8: return launch_fwd<8>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 1: return launch_fwd<1, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 2: return launch_fwd<2, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 3: return launch_fwd<3, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 4: return launch_fwd<4, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 5: return launch_fwd<5, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 6: return launch_fwd<6, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 7: return launch_fwd<7, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
+    case 8: return launch_fwd<8, TS>(x, prep, Wm, bm, h, n_slabs, g, st);
   }
   set_error("hopmi_gcn_fwd: internal: %d m-tiles", g.mtiles);
+  return HOPMI_EINVAL;
+}
+
+extern "C" int hopmi_gcn_fwd(const float* x, const float* prep, const float* Wm, const float* bm,
+                             float* h, int n_slabs, int V, void* stream) {
+  return gcn_fwd_impl<float>(x, prep, Wm, bm, h, n_slabs, V, stream);
+}
+
+extern "C" int hopmi_gcn_fwd_dt(const void* x, const float* prep, const float* Wm, const float* bm, void* h, int n_slabs, int V,
+                                int dtype, void* stream) {
+  if (dtype == HOPMI_F32) return gcn_fwd_impl<float>(static_cast<const float*>(x), prep, Wm, bm, static_cast<float*>(h), n_slabs, V, stream);
+  if (dtype == HOPMI_BF16) return gcn_fwd_impl<__bf16>(static_cast<const __bf16*>(x), prep, Wm, bm, static_cast<__bf16*>(h), n_slabs, V, stream);
+  set_error("hopmi_gcn_fwd_dt: dtype %d (0 = fp32, 1 = bf16)", dtype);
   return HOPMI_EINVAL;
 }
 
@@ -434,9 +448,9 @@ extern "C" size_t hopmi_gcn_bwd_ws_floats(int n_slabs, int V) {
   return (size_t)bwd_grid(g.ntiles) * (C * K3 + C + 2 * V * V);
 }
 
-extern "C" int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const float* Wm,
-                             float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
-                             int n_slabs, int V, void* stream) {
+template <typename TS>
+static int gcn_bwd_impl(const TS* x, const TS* dh, const float* prep, const float* Wm, TS* dx, float* dA1, float* dA2, float* dWm,
+                        float* dbm, float* ws, int n_slabs, int V, void* stream) {
   const void* ptrs[] = {x, dh, prep, Wm, dx, dA1, dA2, dWm, dbm, ws};
   if (int e = validate(ptrs, 10, n_slabs, V)) return e;
   const GcnGeom g = make_geom(n_slabs, V, bwd_slabs(V));
@@ -445,14 +459,32 @@ extern "C" int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep,
   const size_t lds = (size_t)(2 * g.rows_lds * LDH + g.rows_lds * LDD + g.KP * g.ldA + g.K2P * g.ldB) * sizeof(float);
   if (lds > 160 * 1024) { set_error("hopmi_gcn_bwd: LDS footprint %zu exceeds 160 KiB", lds); return HOPMI_EINVAL; }
   switch (g.mtiles) {
-    case 1: launch_bwd<1>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
-    case 2: launch_bwd<2>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
-    case 3: launch_bwd<3>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
-    case 4: launch_bwd<4>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    case 1: launch_bwd<1, TS>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    case 2: launch_bwd<2, TS>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    case 3: launch_bwd<3, TS>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
+    case 4: launch_bwd<4, TS>(x, dh, prep, Wm, dx, ws, n_slabs, g, grid, lds, st); break;
     default: set_error("hopmi_gcn_bwd: internal: %d m-tiles", g.mtiles); return HOPMI_EINVAL;
   }
   if (int e = check_launch("hopmi_gcn_bwd")) return e;
   const int psz = C * K3 + C + 2 * V * V;
   hipLaunchKernelGGL(gcn_bwd_reduce_kernel, dim3((psz + 255) / 256), dim3(256), 0, st, ws, grid, V, dWm, dbm, dA1, dA2);
   return check_launch("hopmi_gcn_bwd_reduce");
+}
+
+extern "C" int hopmi_gcn_bwd(const float* x, const float* dh, const float* prep, const float* Wm,
+                             float* dx, float* dA1, float* dA2, float* dWm, float* dbm, float* ws,
+                             int n_slabs, int V, void* stream) {
+  return gcn_bwd_impl<float>(x, dh, prep, Wm, dx, dA1, dA2, dWm, dbm, ws, n_slabs, V, stream);
+}
+
+extern "C" int hopmi_gcn_bwd_dt(const void* x, const void* dh, const float* prep, const float* Wm, void* dx, float* dA1, float* dA2,
+                                float* dWm, float* dbm, float* ws, int n_slabs, int V, int dtype, void* stream) {
+  if (dtype == HOPMI_F32)
+    return gcn_bwd_impl<float>(static_cast<const float*>(x), static_cast<const float*>(dh), prep, Wm, static_cast<float*>(dx), dA1, dA2,
+                               dWm, dbm, ws, n_slabs, V, stream);
+  if (dtype == HOPMI_BF16)
+    return gcn_bwd_impl<__bf16>(static_cast<const __bf16*>(x), static_cast<const __bf16*>(dh), prep, Wm, static_cast<__bf16*>(dx), dA1,
+                                dA2, dWm, dbm, ws, n_slabs, V, stream);
+  set_error("hopmi_gcn_bwd_dt: dtype %d (0 = fp32, 1 = bf16)", dtype);
+  return HOPMI_EINVAL;
 }

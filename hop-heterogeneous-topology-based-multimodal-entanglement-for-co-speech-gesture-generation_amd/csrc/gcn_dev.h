@@ -2,6 +2,7 @@
 // kernels (wavenet.hip): tile geometry, prepared mix-matrix images, row streaming, node mix, dX mix.
 #pragma once
 #include "common.h"
+#include "io_dev.h"
 
 namespace hopmi {
 
@@ -95,14 +96,13 @@ __device__ __forceinline__ void prep_commit(float* dst, const PrepRegs& r, int n
 template <int NIT>
 struct RowRegs { float4 v[NIT]; };
 
-template <int NIT>
-__device__ __forceinline__ void rows_issue(RowRegs<NIT>& r, const float* __restrict__ src, int R, int tid) {
-  const float4* src4 = reinterpret_cast<const float4*>(src);
+template <int NIT, typename TS>
+__device__ __forceinline__ void rows_issue(RowRegs<NIT>& r, const TS* __restrict__ src, int R, int tid) {
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int idx = tid + 256 * it;
     const int row = idx >> 4, c4 = idx & 15;
-    const float4 v = src4[min(row, R - 1) * 16 + c4];
+    const float4 v = ld4(src + 4 * (min(row, R - 1) * 16 + c4));
     r.v[it] = (row < R) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
@@ -209,8 +209,8 @@ __device__ __forceinline__ void node_mix_dispatch(float* Hc, const float* AT, co
 
 // dX[s] = G0 + A1 G1 + A2 G2 for the slabs of a tile; wave w owns channels 16w + [0,16).
 // KS = K steps (ceil(2V/4)) when known at compile time (0 = runtime loop).
-template <int KS>
-__device__ __forceinline__ void dx_mix(const float* Gs, const float* AB, float* __restrict__ dx, size_t row0,
+template <int KS, typename TS>
+__device__ __forceinline__ void dx_mix(const float* Gs, const float* AB, TS* __restrict__ dx, size_t row0,
                                        const GcnGeom& g, int nsl, int w, int q, int j) {
   const int V = g.V;
   const int ksteps = KS ? KS : (g.K2P >> 2), mt_n = g.VP >> 4;
@@ -251,7 +251,7 @@ __device__ __forceinline__ void dx_mix(const float* Gs, const float* AB, float* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int v = 16 * mt + 4 * q + r;
-        if (v < V) dx[(row0 + s * V + v) * C + 16 * w + j] = acc[r];
+        if (v < V) st1(dx + (row0 + s * V + v) * C + 16 * w + j, acc[r]);
       }
     }
   }

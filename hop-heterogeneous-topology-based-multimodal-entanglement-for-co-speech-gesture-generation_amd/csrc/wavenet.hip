@@ -23,6 +23,7 @@
 #include <hip/hip_ext.h>
 
 #include "bf16_dev.h"
+#include "io_dev.h"
 #include "wn_dev.h"
 
 namespace hopmi {
@@ -184,13 +185,15 @@ __device__ __forceinline__ void node_mix2_generic(const float* U, __bf16* Hh, __
 // workgroup walks several tiles (plain loop, loads at the top of every iteration); !MULTI = the grid covers the launch,
 // one tile per workgroup: straight-line code whose first loads are issued before anything else.
 // GCN = false: the gate-only form (TCN + gate, no graph conv: what the backward uses to regenerate the gate values).
-template <int MT, bool MULTI, bool GCN>
-__global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ scsh,
+// TS = storage type of the activation tensors xin, y and utail (float or __bf16, io_dev.h): read / written 4 channels at a time,
+// all arithmetic in fp32 (the bf16 form of BASELINE.json configs 2 / 4: y is rounded once, when it is stored).
+template <int MT, bool MULTI, bool GCN, typename TS>
+__global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __restrict__ xin, const float* __restrict__ scsh,
                                                                   const u32x4* __restrict__ wimg,
                                                                   const float* __restrict__ bfp, const float* __restrict__ bgp,
                                                                   const float* __restrict__ prep,
-                                                                  const float* __restrict__ bm, float* __restrict__ y,
-                                                                  float* __restrict__ fs, float* __restrict__ utail,
+                                                                  const float* __restrict__ bm, TS* __restrict__ y,
+                                                                  float* __restrict__ fs, TS* __restrict__ utail,
                                                                   float* __restrict__ stats_part, LayerGeom L, int utail_ld4) {
   constexpr int do_gcn = GCN ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -223,7 +226,6 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
   auto issue_tile = [&](int tile) {
     const int slab0 = tile * g.S;
     const int R = min(g.S, L.n_slabs - slab0) * V;
-    const float4* src4 = reinterpret_cast<const float4*>(xin);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = (tid >> 4) + (WN_THREADS / 16) * it;
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
       rm.ok[it] = row < R;
       rm.in0[it] = ((b * L.T_in + tp) * V + v) * 16 + c4;
       rm.tail[it] = (utail != nullptr && rm.ok[it] && tp >= L.T_out - 4) ? ((b * 4 + tp - (L.T_out - 4)) * V + v) * utail_ld4 + c4 : -1;
-      x0r[it] = src4[rm.in0[it]];
-      x1r[it] = src4[rm.in0[it] + shift4];
+      x0r[it] = ld4(xin + 4 * (size_t)rm.in0[it]);
+      x1r[it] = ld4(xin + 4 * (size_t)(rm.in0[it] + shift4));
     }
   };
   if (!MULTI) issue_tile(blockIdx.x);
@@ -387,8 +389,7 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = (tid >> 4) + (WN_THREADS / 16) * it;
-      if (rm.tail[it] >= 0)
-        reinterpret_cast<float4*>(utail)[rm.tail[it]] = *reinterpret_cast<const float4*>(U + row * LDD + 4 * c4);
+      if (rm.tail[it] >= 0) st4(utail + 4 * (size_t)rm.tail[it], *reinterpret_cast<const float4*>(U + row * LDD + 4 * c4));
     }
 
     if (do_gcn) {
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const float* _
                                    *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q));        // gwnet.py:233
           const f32x4 yv = {acc[i][0] + bias4.x + res.x, acc[i][1] + bias4.y + res.y, acc[i][2] + bias4.z + res.z,
                             acc[i][3] + bias4.w + res.w};
-          if (y != nullptr) *reinterpret_cast<f32x4*>(y + (orow0 + row) * C + 16 * w + 4 * q) = yv;
+          if (y != nullptr) st4(y + (orow0 + row) * C + 16 * w + 4 * q, make_float4(yv[0], yv[1], yv[2], yv[3]));
           st1 += yv;
           st2 += yv * yv;
         }
@@ -561,26 +562,26 @@ hipEvent_t wn_take_timing_events(hipEvent_t* stop) {
   return e0;
 }
 
-template <int MT>
-static int launch_wn_fwd(const float* xin, const float* scsh, const u32x4* wimg, const float* bf, const float* bg,
-                         const float* prep, const float* bm, float* y, float* fs, float* utail, int utail_ld, float* part,
+template <int MT, typename TS>
+static int launch_wn_fwd(const TS* xin, const float* scsh, const u32x4* wimg, const float* bf, const float* bg,
+                         const float* prep, const float* bm, TS* y, float* fs, TS* utail, int utail_ld, float* part,
                          const LayerGeom& L, int do_gcn, int grid, hipStream_t st) {
   const size_t lds = wn_fwd_lds_bytes(L.g);
   static bool attr_done = false;                         // > 64 KiB of dynamic LDS needs the attribute once per kernel
   if (!attr_done) {
-    const void* fns[] = {reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, true, true>),
-                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, false, true>),
-                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, true, false>),
-                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, false, false>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, true, true, TS>),
+                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, false, true, TS>),
+                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, true, false, TS>),
+                         reinterpret_cast<const void*>(&wn_layer_fwd_kernel<MT, false, false, TS>)};
     for (const void* fn : fns)
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
     attr_done = true;
   }
-  const hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;      // null unless a measurement asked for this launch
-  t_ev_start = t_ev_stop = nullptr;
+  hipEvent_t e1 = nullptr;
+  const hipEvent_t e0 = wn_take_timing_events(&e1);      // null unless a measurement asked for this launch
   const bool multi = L.g.ntiles > grid;
 #define HOPMI_WN_LAUNCH(MULTI_, GCN_)                                                                                          \
-  hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, MULTI_, GCN_>), dim3(grid), dim3(WN_THREADS), lds, st, e0, e1, 0, xin, scsh, wimg, bf, \
+  hipExtLaunchKernelGGL((wn_layer_fwd_kernel<MT, MULTI_, GCN_, TS>), dim3(grid), dim3(WN_THREADS), lds, st, e0, e1, 0, xin, scsh, wimg, bf, \
                         bg, prep, bm, y, fs, utail, part, L, utail_ld / 4)
   if (do_gcn) { if (multi) HOPMI_WN_LAUNCH(true, true); else HOPMI_WN_LAUNCH(false, true); }
   else { if (multi) HOPMI_WN_LAUNCH(true, false); else HOPMI_WN_LAUNCH(false, false); }
@@ -644,9 +645,10 @@ extern "C" size_t hopmi_wn_layer_ws_floats(int B, int T_in, int V, int dilation)
   return (size_t)wn_grid(L) * 2 * 2 * C + (size_t)WN_FIN_G * 2 * C * 2 + 4;
 }
 
-extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const void* wimg, const float* bf, const float* bg,
-                                  const float* prep, const float* bm, float* y, float* fs, float* utail,
-                                  int utail_ld, float* ws, int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
+template <typename TS>
+static int wn_layer_fwd_impl(const TS* xin, const float* scsh_in, const void* wimg, const float* bf, const float* bg,
+                             const float* prep, const float* bm, TS* y, float* fs, TS* utail, int utail_ld, float* ws, int B, int T_in,
+                             int V, int dilation, int do_gcn, void* stream) {
   if (int e = wn_validate(B, T_in, V, dilation)) return e;
   if (!xin || !scsh_in || !wimg || !bf || !bg) { set_error("hopmi_wn_layer_fwd: null pointer argument"); return HOPMI_EINVAL; }
   if (utail != nullptr && (utail_ld < C || (utail_ld & 3))) { set_error("hopmi_wn_layer_fwd: utail_ld=%d must be a multiple of 4 and >= 64", utail_ld); return HOPMI_EINVAL; }
@@ -660,14 +662,33 @@ extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const 
   float* part = stats ? ws : nullptr;
   const u32x4* img = static_cast<const u32x4*>(wimg);
   switch (L.g.mtiles) {
-    case 1: launch_wn_fwd<1>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 2: launch_wn_fwd<2>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 3: launch_wn_fwd<3>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 4: launch_wn_fwd<4>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
-    case 5: launch_wn_fwd<5>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 1: launch_wn_fwd<1, TS>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 2: launch_wn_fwd<2, TS>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 3: launch_wn_fwd<3, TS>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 4: launch_wn_fwd<4, TS>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
+    case 5: launch_wn_fwd<5, TS>(xin, scsh_in, img, bf, bg, prep, bm, y, fs, utail, utail_ld, part, L, do_gcn, grid, st); break;
     default: set_error("hopmi_wn_layer_fwd: internal: %d m-tiles", L.g.mtiles); return HOPMI_EINVAL;
   }
   return check_launch("hopmi_wn_layer_fwd");
+}
+
+extern "C" int hopmi_wn_layer_fwd(const float* xin, const float* scsh_in, const void* wimg, const float* bf, const float* bg,
+                                  const float* prep, const float* bm, float* y, float* fs, float* utail,
+                                  int utail_ld, float* ws, int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
+  return wn_layer_fwd_impl<float>(xin, scsh_in, wimg, bf, bg, prep, bm, y, fs, utail, utail_ld, ws, B, T_in, V, dilation, do_gcn, stream);
+}
+
+extern "C" int hopmi_wn_layer_fwd_dt(const void* xin, const float* scsh_in, const void* wimg, const float* bf, const float* bg,
+                                     const float* prep, const float* bm, void* y, float* fs, void* utail, int utail_ld, float* ws,
+                                     int B, int T_in, int V, int dilation, int do_gcn, int dtype, void* stream) {
+  if (dtype == HOPMI_F32)
+    return wn_layer_fwd_impl<float>(static_cast<const float*>(xin), scsh_in, wimg, bf, bg, prep, bm, static_cast<float*>(y), fs,
+                                    static_cast<float*>(utail), utail_ld, ws, B, T_in, V, dilation, do_gcn, stream);
+  if (dtype == HOPMI_BF16)
+    return wn_layer_fwd_impl<__bf16>(static_cast<const __bf16*>(xin), scsh_in, wimg, bf, bg, prep, bm, static_cast<__bf16*>(y), fs,
+                                     static_cast<__bf16*>(utail), utail_ld, ws, B, T_in, V, dilation, do_gcn, stream);
+  set_error("hopmi_wn_layer_fwd_dt: dtype %d (0 = fp32, 1 = bf16)", dtype);
+  return HOPMI_EINVAL;
 }
 
 extern "C" int hopmi_wn_bn_finalize(const float* ws, const float* gamma, const float* beta, float* running_mean,

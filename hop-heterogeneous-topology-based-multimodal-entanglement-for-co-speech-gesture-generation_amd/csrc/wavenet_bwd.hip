@@ -16,6 +16,7 @@
 // P0/P1 are separate tensors so that no two workgroups ever add into the same element (layer i-1 sums
 // them on load); all parameter-gradient partials stay in accumulator registers across a workgroup's tiles and
 // are summed by wn_bwd_reduce_kernel in a fixed order: bitwise reproducible, no atomics.
+#include "io_dev.h"
 #include "wn_dev.h"
 
 namespace hopmi {
@@ -42,12 +43,14 @@ struct BwdRowMap {
   bool ok[NIT];
 };
 
-template <int MT>
+// TS = storage type of the saved activations xin, y and of the incoming skip-tail gradient dutail (float or __bf16, io_dev.h);
+// the gradients between layers (P0n / P1n in, P0 / P1 out) and all arithmetic stay fp32.
+template <int MT, typename TS>
 __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
-    const float* __restrict__ xin, const float* __restrict__ fs, const float* __restrict__ wf, const float* __restrict__ wg,
+    const TS* __restrict__ xin, const float* __restrict__ fs, const float* __restrict__ wf, const float* __restrict__ wg,
     const float* __restrict__ prep, const float* __restrict__ Wm, const float* __restrict__ P0n,
-    const float* __restrict__ P1n, const float* __restrict__ y, const float* __restrict__ bn_coef,
-    const float* __restrict__ dutail, float* __restrict__ P0, float* __restrict__ P1, float* __restrict__ part,
+    const float* __restrict__ P1n, const TS* __restrict__ y, const float* __restrict__ bn_coef,
+    const TS* __restrict__ dutail, float* __restrict__ P0, float* __restrict__ P1, float* __restrict__ part,
     LayerGeom L, int do_gcn, int d_next, int T_next, int dutail_ld4) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GcnGeom& g = L.g;
@@ -114,7 +117,6 @@ __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
     BwdRowMap<NIT> rm;
     RowRegs<NIT> x0r, x1r, dyr, ur, tr;
     {
-      const float4* x4 = reinterpret_cast<const float4*>(xin);
       const float4* f4 = reinterpret_cast<const float4*>(fs);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
         rm.p0[it] = (do_gcn && tp < T_next) ? ((b * T_next + tp) * V + v) * 16 + c4 : -1;
         rm.p1[it] = (do_gcn && tp >= d_next) ? ((b * T_next + tp - d_next) * V + v) * 16 + c4 : -1;
         rm.tail[it] = (tp >= L.T_out - 4) ? ((b * 4 + tp - (L.T_out - 4)) * V + v) * dutail_ld4 + c4 : -1;
-        x0r.v[it] = x4[rm.in0[it]];
-        x1r.v[it] = x4[rm.in0[it] + shift4];
+        x0r.v[it] = ld4(xin + 4 * (size_t)rm.in0[it]);
+        x1r.v[it] = ld4(xin + 4 * (size_t)(rm.in0[it] + shift4));
         const size_t orow = orow0 + rc;
         const float4 fv = f4[orow * 32 + c4], sv = f4[orow * 32 + 16 + c4];
         ur.v[it] = make_float4(fv.x * sv.x, fv.y * sv.y, fv.z * sv.z, fv.w * sv.w);
@@ -139,13 +141,13 @@ __global__ __launch_bounds__(256) void wn_layer_bwd_kernel(
         if (do_gcn) {
           const float4 a = reinterpret_cast<const float4*>(P0n)[max(rm.p0[it], 0)];
           const float4 bq = reinterpret_cast<const float4*>(P1n)[max(rm.p1[it], 0)];
-          const float4 yv = reinterpret_cast<const float4*>(y)[orow * 16 + c4];
+          const float4 yv = ld4(y + 4 * (orow * 16 + c4));
           const float m0 = rm.p0[it] >= 0 ? 1.f : 0.f, m1 = rm.p1[it] >= 0 ? 1.f : 0.f;
           dx = make_float4(ca4.x * (a.x * m0 + bq.x * m1) + cb4.x * yv.x + ck4.x, ca4.y * (a.y * m0 + bq.y * m1) + cb4.y * yv.y + ck4.y,
                            ca4.z * (a.z * m0 + bq.z * m1) + cb4.z * yv.z + ck4.z, ca4.w * (a.w * m0 + bq.w * m1) + cb4.w * yv.w + ck4.w);
         }
         dyr.v[it] = dx;
-        const float4 tv = reinterpret_cast<const float4*>(dutail)[max(rm.tail[it], 0)];
+        const float4 tv = ld4(dutail + 4 * (size_t)max(rm.tail[it], 0));
         tr.v[it] = (rm.tail[it] >= 0 && rm.ok[it]) ? tv : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       __syncthreads();                             // previous tile's LDS fully consumed
@@ -516,14 +518,14 @@ static int wnb_grid(const LayerGeom& L) {
   return L.g.ntiles < cap ? L.g.ntiles : cap;
 }
 
-template <int MT>
-static void launch_wn_bwd(const float* xin, const float* fs, const float* wf, const float* wg, const float* prep, const float* Wm,
-                          const float* P0n, const float* P1n, const float* y, const float* coef, const float* dutail,
+template <int MT, typename TS>
+static void launch_wn_bwd(const TS* xin, const float* fs, const float* wf, const float* wg, const float* prep, const float* Wm,
+                          const float* P0n, const float* P1n, const TS* y, const float* coef, const TS* dutail,
                           float* P0, float* P1, float* part, const LayerGeom& L, int do_gcn, int d_next, int T_next,
                           int dutail_ld, int grid, hipStream_t st) {
   const GcnGeom& g = L.g;
   const size_t lds = wnb_lds_bytes(g);
-  hipLaunchKernelGGL(wn_layer_bwd_kernel<MT>, dim3(grid), dim3(256), lds, st, xin, fs, wf, wg, prep, Wm, P0n, P1n, y, coef,
+  hipLaunchKernelGGL((wn_layer_bwd_kernel<MT, TS>), dim3(grid), dim3(256), lds, st, xin, fs, wf, wg, prep, Wm, P0n, P1n, y, coef,
                      dutail, P0, P1, part, L, do_gcn, d_next, T_next, dutail_ld / 4);
 }
 
@@ -538,14 +540,15 @@ extern "C" size_t hopmi_wn_layer_bwd_ws_floats(int B, int T_in, int V, int dilat
   return (size_t)wnb_grid(L) * part_floats(V);
 }
 
-extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wf, const float* wg,
-                                  const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
-                                  const float* y, const float* bn_coef, const float* dutail, int dutail_ld,
-                                  const float* gamma_prev, const float* mean_rstd_prev,
-                                  float* P0, float* P1, float* dwf, float* dwg, float* dbtcn, float* dWm, float* dbm,
-                                  float* dA1, float* dA2, int accumulate_dA, float* dgamma_prev, float* dbeta_prev,
-                                  float* coef_prev, float* ws,
-                                  int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
+template <typename TS>
+static int wn_layer_bwd_impl(const TS* xin, const float* scsh_in, const float* fs, const float* wf, const float* wg,
+                             const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
+                             const TS* y, const float* bn_coef, const TS* dutail, int dutail_ld,
+                             const float* gamma_prev, const float* mean_rstd_prev,
+                             float* P0, float* P1, float* dwf, float* dwg, float* dbtcn, float* dWm, float* dbm,
+                             float* dA1, float* dA2, int accumulate_dA, float* dgamma_prev, float* dbeta_prev,
+                             float* coef_prev, float* ws,
+                             int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
   if (int e = wn_validate(B, T_in, V, dilation)) return e;
   if (!xin || !scsh_in || !fs || !wf || !wg || !dutail || !P0 || !P1 || !dwf || !dwg || !dbtcn || !ws) {
     set_error("hopmi_wn_layer_bwd: null pointer argument");
@@ -572,9 +575,9 @@ extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int T_next = T_out - d_next;
   switch (L.g.mtiles) {
-    case 1: launch_wn_bwd<1>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
-    case 2: launch_wn_bwd<2>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
-    case 3: launch_wn_bwd<3>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
+    case 1: launch_wn_bwd<1, TS>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
+    case 2: launch_wn_bwd<2, TS>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
+    case 3: launch_wn_bwd<3, TS>(xin, fs, wf, wg, prep, Wm, P0n, P1n, y, bn_coef, dutail, P0, P1, ws, L, do_gcn, d_next, T_next, dutail_ld, grid, st); break;
     default: set_error("hopmi_wn_layer_bwd: internal: %d m-tiles", L.g.mtiles); return HOPMI_EINVAL;
   }
   if (int e = check_launch("hopmi_wn_layer_bwd")) return e;
@@ -583,4 +586,39 @@ extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const 
                      mean_rstd_prev, (double)B * T_in * V, dwf, dwg, dbtcn, dWm, dbm, dA1, dA2, accumulate_dA, dgamma_prev, dbeta_prev,
                      coef_prev);
   return check_launch("hopmi_wn_bwd_reduce");
+}
+
+extern "C" int hopmi_wn_layer_bwd(const float* xin, const float* scsh_in, const float* fs, const float* wf, const float* wg,
+                                  const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
+                                  const float* y, const float* bn_coef, const float* dutail, int dutail_ld,
+                                  const float* gamma_prev, const float* mean_rstd_prev,
+                                  float* P0, float* P1, float* dwf, float* dwg, float* dbtcn, float* dWm, float* dbm,
+                                  float* dA1, float* dA2, int accumulate_dA, float* dgamma_prev, float* dbeta_prev,
+                                  float* coef_prev, float* ws,
+                                  int B, int T_in, int V, int dilation, int do_gcn, void* stream) {
+  return wn_layer_bwd_impl<float>(xin, scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next, y, bn_coef, dutail, dutail_ld, gamma_prev,
+                                  mean_rstd_prev, P0, P1, dwf, dwg, dbtcn, dWm, dbm, dA1, dA2, accumulate_dA, dgamma_prev, dbeta_prev,
+                                  coef_prev, ws, B, T_in, V, dilation, do_gcn, stream);
+}
+
+extern "C" int hopmi_wn_layer_bwd_dt(const void* xin, const float* scsh_in, const float* fs, const float* wf, const float* wg,
+                                     const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
+                                     const void* y, const float* bn_coef, const void* dutail, int dutail_ld,
+                                     const float* gamma_prev, const float* mean_rstd_prev,
+                                     float* P0, float* P1, float* dwf, float* dwg, float* dbtcn, float* dWm, float* dbm,
+                                     float* dA1, float* dA2, int accumulate_dA, float* dgamma_prev, float* dbeta_prev,
+                                     float* coef_prev, float* ws,
+                                     int B, int T_in, int V, int dilation, int do_gcn, int dtype, void* stream) {
+  if (dtype == HOPMI_F32)
+    return wn_layer_bwd_impl<float>(static_cast<const float*>(xin), scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next,
+                                    static_cast<const float*>(y), bn_coef, static_cast<const float*>(dutail), dutail_ld, gamma_prev,
+                                    mean_rstd_prev, P0, P1, dwf, dwg, dbtcn, dWm, dbm, dA1, dA2, accumulate_dA, dgamma_prev, dbeta_prev,
+                                    coef_prev, ws, B, T_in, V, dilation, do_gcn, stream);
+  if (dtype == HOPMI_BF16)
+    return wn_layer_bwd_impl<__bf16>(static_cast<const __bf16*>(xin), scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next,
+                                     static_cast<const __bf16*>(y), bn_coef, static_cast<const __bf16*>(dutail), dutail_ld, gamma_prev,
+                                     mean_rstd_prev, P0, P1, dwf, dwg, dbtcn, dWm, dbm, dA1, dA2, accumulate_dA, dgamma_prev, dbeta_prev,
+                                     coef_prev, ws, B, T_in, V, dilation, do_gcn, stream);
+  set_error("hopmi_wn_layer_bwd_dt: dtype %d (0 = fp32, 1 = bf16)", dtype);
+  return HOPMI_EINVAL;
 }

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "bf16_dev.h"
+#include "io_dev.h"
 #include "wn_dev.h"
 
 namespace hopmi {
@@ -46,8 +47,8 @@ constexpr int STK_SYNC_INTS = 64, STK_STATUS_AT = 32;
 typedef unsigned long long u64;
 
 struct StackLayer {
-  const float* xin;      // (B, T_in, V, 64): x0 for layer 0, y_{i-1} after
-  float* y;              // (B, T_out, V, 64) or null (last layer: its output is dead, gwnet.py:240)
+  const void* xin;       // (B, T_in, V, 64) of the storage type: x0 for layer 0, y_{i-1} after
+  void* y;               // (B, T_out, V, 64) or null (last layer: its output is dead, gwnet.py:240)
   const float* bf; const float* bg; const float* bm;
   const float* gamma; const float* beta;
   float* rmean; float* rvar;       // running statistics (updated in place) or null
@@ -59,7 +60,7 @@ struct StackArgs {
   StackLayer L[STK_MAX_LAYERS];
   const u32x4* wimg;     // n_layers weight images (hopmi_wn_prepare_weights)
   const float* prep;     // mix-matrix images (hopmi_gcn_prepare)
-  float* utail;          // (B, 4, V, utail_ld): layer i's skip tail at channel offset 64 i
+  void* utail;           // (B, 4, V, utail_ld) of the storage type: layer i's skip tail at channel offset 64 i
   float* scsh_out;       // [n_layers][128]  scale | shift of BN_i
   float* mean_rstd;      // [n_layers][192]  mean | rstd | unbiased variance
   int* sync;             // STK_SYNC_INTS ints: launch sequence number, status word (zero before the first launch)
@@ -96,6 +97,28 @@ __device__ __forceinline__ auto stk_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 constexpr int AUX_SC1 = 16;                                     // gfx940+: cache-policy bit 4 = sc1 (write-through / bypass L1)
+
+// Storage type of the activation tensors (x0, y_i, skip tails): 4 channels per access, sc1 buffer loads / stores for what is
+// handed between workgroups inside the launch; all arithmetic in fp32 (bf16: y is rounded once, when it is stored).
+template <typename TS> struct StkIO;
+template <> struct StkIO<float> {
+  typedef u32x4 raw;
+  static constexpr int ES = 4;
+  template <typename R> static __device__ __forceinline__ raw load(R r, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX_SC1); }
+  static __device__ __forceinline__ float4 cvt(raw v) { return __builtin_bit_cast(float4, v); }
+  template <typename R> static __device__ __forceinline__ void store(float4 v, R r, int byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, AUX_SC1);
+  }
+};
+template <> struct StkIO<__bf16> {
+  typedef u32x2 raw;
+  static constexpr int ES = 2;
+  template <typename R> static __device__ __forceinline__ raw load(R r, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, AUX_SC1); }
+  static __device__ __forceinline__ float4 cvt(raw v) { return make_float4(bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])); }
+  template <typename R> static __device__ __forceinline__ void store(float4 v, R r, int byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)}, r, byte_off, 0, AUX_SC1);
+  }
+};
 
 __device__ __forceinline__ bool stk_expired(unsigned long long t0, int* status) {
   if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {              // 2 s at 100 MHz
@@ -209,8 +232,10 @@ __device__ __forceinline__ void stk_node_mix_generic(const float* U, __bf16* Hh,
 // MT = the LARGEST tile (in 16-row MFMA tiles) of any layer of the launch: it fixes the LDS layout; a layer whose tiles are
 // smaller skips the MFMA tiles it does not have (wave-uniform predicates).  16-row tile mt belongs to row half mt & 1, so the
 // two halves stay balanced at every tile size.
-template <int MT>
+template <int MT, typename TS>
 __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) {
+  typedef StkIO<TS> IO;
+  constexpr int ES = IO::ES;                          // bytes per stored element
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NIT = ((16 * MT + 4) * 16 + STK_THREADS - 1) / STK_THREADS;
   constexpr int MTH = (MT + 1) / 2;
@@ -286,12 +311,12 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
   // registers (tail[]: where the skip tail of the row goes, or -1; ok[]: row < R)
   int tail[NIT];
   bool ok[NIT];
-  u32x4 x0r[NIT], x1r[NIT];
+  typename IO::raw x0r[NIT], x1r[NIT];
   auto issue_tile = [&](const StackLayer& L, int tile) {
     const int slab0 = tile * L.S;
     const int R = min(L.S, L.n_slabs - slab0) * V;
-    const auto xr = stk_rsrc(L.xin, (unsigned)A.B * L.T_in * V * 256u);
-    const int shift4b = L.d * V * 256;               // tap-1 row offset in bytes
+    const auto xr = stk_rsrc(L.xin, (unsigned)A.B * L.T_in * V * (64u * ES));
+    const int shift4b = L.d * V * 64 * ES;           // tap-1 row offset in bytes
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = (tid >> 4) + (STK_THREADS / 16) * it;
@@ -302,10 +327,10 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       const int b = (int)((slab + 0.5f) * L.invT);
       const int tp = slab - b * L.T_out;
       ok[it] = row < R;
-      const int in0 = (((b * L.T_in + tp) * V + v) * 16 + c4) * 16;              // byte offset
+      const int in0 = (((b * L.T_in + tp) * V + v) * 16 + c4) * 4 * ES;          // byte offset
       tail[it] = (ok[it] && tp >= L.T_out - 4) ? ((b * 4 + tp - (L.T_out - 4)) * V + v) * A.utail_ld4 + c4 : -1;
-      x0r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0, 0, AUX_SC1);
-      x1r[it] = __builtin_amdgcn_raw_buffer_load_b128(xr, in0 + shift4b, 0, AUX_SC1);
+      x0r[it] = IO::load(xr, in0);
+      x1r[it] = IO::load(xr, in0 + shift4b);
     }
   };
   // per-layer constants (this lane's 4 channels): requested with the first tile's panels, i.e. during the previous layer's
@@ -333,9 +358,9 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
     STK_STAMP(layer, 0);
     const bool last_layer = layer == A.n_layers - 1;
     const unsigned tag = (seq << 4) | (unsigned)(layer + 1);
-    const auto yr = stk_rsrc(L.y, L.y != nullptr ? (unsigned)A.B * L.T_out * V * 256u : 0u);   // (null y: zero records, stores dropped)
+    const auto yr = stk_rsrc(L.y, L.y != nullptr ? (unsigned)A.B * L.T_out * V * (64u * ES) : 0u);   // (null y: zero records, stores dropped)
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
-    float* utail = A.utail + C * layer;
+    TS* utail = static_cast<TS*>(A.utail) + C * layer;
 
     // the first tile's tap panels are in flight since the previous layer's exchange
     for (int tile = bid; tile < L.ntiles; tile += G) {
@@ -356,7 +381,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       for (int it = 0; it < NIT; ++it) {
         const int row = (tid >> 4) + (STK_THREADS / 16) * it;
         if (row < rows_lds) {
-          float4 a = __builtin_bit_cast(float4, x0r[it]), b2 = __builtin_bit_cast(float4, x1r[it]);
+          float4 a = IO::cvt(x0r[it]), b2 = IO::cvt(x1r[it]);
           a = make_float4(a.x * sc4.x + sh4.x, a.y * sc4.y + sh4.y, a.z * sc4.z + sh4.z, a.w * sc4.w + sh4.w);
           b2 = make_float4(b2.x * sc4.x + sh4.x, b2.y * sc4.y + sh4.y, b2.z * sc4.z + sh4.z, b2.w * sc4.w + sh4.w);
           if (!ok[it]) { a = make_float4(0.f, 0.f, 0.f, 0.f); b2 = a; }
@@ -424,7 +449,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int row = (tid >> 4) + (STK_THREADS / 16) * it;
-        if (tail[it] >= 0) reinterpret_cast<float4*>(utail)[tail[it]] = *reinterpret_cast<const float4*>(U + row * LDD + 4 * c4);
+        if (tail[it] >= 0) st4(utail + 4 * (size_t)tail[it], *reinterpret_cast<const float4*>(U + row * LDD + 4 * c4));
       }
 
       // ---- phase 2: node mix (exact fp32 MFMA, K = V) -> split images ------------------------------------------------
@@ -461,7 +486,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
                                    *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q));
           const f32x4 yv = {acc[i][0] + bias4.x + res.x, acc[i][1] + bias4.y + res.y, acc[i][2] + bias4.z + res.z,
                             acc[i][3] + bias4.w + res.w};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), yr, ((orow0 + row) * C + 16 * w + 4 * q) * 4, 0, AUX_SC1);
+          IO::store(make_float4(yv[0], yv[1], yv[2], yv[3]), yr, ((orow0 + row) * C + 16 * w + 4 * q) * ES);
           st1 += yv;
           st2 += yv * yv;
         }
@@ -618,15 +643,18 @@ struct StackPlan {
 };
 
 template <int MT>
-static const void* stk_fn() { return reinterpret_cast<const void*>(&wn_stack_fwd_kernel<MT>); }
+static const void* stk_fn(int dtype) {
+  return dtype == HOPMI_BF16 ? reinterpret_cast<const void*>(&wn_stack_fwd_kernel<MT, __bf16>)
+                             : reinterpret_cast<const void*>(&wn_stack_fwd_kernel<MT, float>);
+}
 
-static const void* stk_fn_for(int mt) {
+static const void* stk_fn_for(int mt, int dtype) {
   switch (mt) {
-    case 1: return stk_fn<1>();
-    case 2: return stk_fn<2>();
-    case 3: return stk_fn<3>();
-    case 4: return stk_fn<4>();
-    case 5: return stk_fn<5>();
+    case 1: return stk_fn<1>(dtype);
+    case 2: return stk_fn<2>(dtype);
+    case 3: return stk_fn<3>(dtype);
+    case 4: return stk_fn<4>(dtype);
+    case 5: return stk_fn<5>(dtype);
   }
   return nullptr;
 }
@@ -634,7 +662,7 @@ static const void* stk_fn_for(int mt) {
 // Geometry of every layer for a grid of `grid_target` workgroups (the per-layer launches' own rule, wn_dev.h), the largest tile,
 // and the resident grid: occupancy (the runtime's answer for this kernel / block / LDS size) x CUs.  Plans are cached per
 // geometry: the device / occupancy queries run once, outside any stream capture (a recorded step replays launches only).
-static int stk_plan_build(int B, int T_in, int V, const int* dil, int n_layers, StackPlan* P) {
+static int stk_plan_build(int B, int T_in, int V, const int* dil, int n_layers, int dtype, StackPlan* P) {
   int dev = 0, n_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) {
     (void)hipGetLastError();
@@ -658,7 +686,7 @@ static int stk_plan_build(int B, int T_in, int V, const int* dil, int n_layers, 
   P->lds = stk_lds_bytes(mt_max, g.KP, g.ldA);
   P->n_cu = n_cu;
   if (P->lds > 160 * 1024) { set_error("hopmi_wn_stack: tile needs %zu bytes of LDS", P->lds); return HOPMI_EINVAL; }
-  const void* fn = stk_fn_for(mt_max);
+  const void* fn = stk_fn_for(mt_max, dtype);
   if (fn == nullptr) { set_error("hopmi_wn_stack: internal: %d m-tiles", mt_max); return HOPMI_EINVAL; }
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
   int per_cu = 0;
@@ -675,19 +703,20 @@ static int stk_plan_build(int B, int T_in, int V, const int* dil, int n_layers, 
   return HOPMI_OK;
 }
 
-struct StackPlanKey { int B, T_in, V, n_layers, dil[STK_MAX_LAYERS]; };
+struct StackPlanKey { int B, T_in, V, n_layers, dtype, dil[STK_MAX_LAYERS]; };
 static std::mutex g_plan_mu;
 static std::vector<std::pair<StackPlanKey, StackPlan>> g_plans;
 
-static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, StackPlan* P) {
+static int stk_plan(int B, int T_in, int V, const int* dil, int n_layers, int dtype, StackPlan* P) {
   if (n_layers < 1 || n_layers > STK_MAX_LAYERS || dil == nullptr) { set_error("hopmi_wn_stack: 1..%d layers", STK_MAX_LAYERS); return HOPMI_EINVAL; }
+  if (dtype != HOPMI_F32 && dtype != HOPMI_BF16) { set_error("hopmi_wn_stack: dtype %d (0 = fp32, 1 = bf16)", dtype); return HOPMI_EINVAL; }
   StackPlanKey k{};
-  k.B = B; k.T_in = T_in; k.V = V; k.n_layers = n_layers;
+  k.B = B; k.T_in = T_in; k.V = V; k.n_layers = n_layers; k.dtype = dtype;
   for (int l = 0; l < n_layers; ++l) k.dil[l] = dil[l];
   std::lock_guard<std::mutex> lk(g_plan_mu);
   for (const auto& e : g_plans)
     if (memcmp(&e.first, &k, sizeof(k)) == 0) { *P = e.second; return HOPMI_OK; }
-  if (int e = stk_plan_build(B, T_in, V, dil, n_layers, P)) return e;
+  if (int e = stk_plan_build(B, T_in, V, dil, n_layers, dtype, P)) return e;
   g_plans.emplace_back(k, *P);
   return HOPMI_OK;
 }
@@ -706,24 +735,24 @@ extern "C" int hopmi_debug_set_stamps_stack(long long* p) {
 
 extern "C" int hopmi_wn_stack_grid(int B, int T_in, int V, const int* dilations, int n_layers) {
   StackPlan P;
-  if (stk_plan(B, T_in, V, dilations, n_layers, &P)) return 0;
+  if (stk_plan(B, T_in, V, dilations, n_layers, HOPMI_F32, &P)) return 0;
   return P.grid;
 }
 
 extern "C" size_t hopmi_wn_stack_ws_bytes(int B, int T_in, int V, const int* dilations, int n_layers) {
   StackPlan P;
-  if (stk_plan(B, T_in, V, dilations, n_layers, &P)) return 0;
+  if (stk_plan(B, T_in, V, dilations, n_layers, HOPMI_F32, &P)) return 0;
   return (size_t)STK_SYNC_INTS * sizeof(int) + ((size_t)n_layers * P.grid * 2 * C + (size_t)n_layers * STK_GROUPS * 4 * C) * sizeof(u64) +
          (size_t)n_layers * P.tiles_max * sizeof(unsigned);
 }
 
-extern "C" int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float* const* bf, const float* const* bg, const float* prep,
-                                  const float* const* bm, const float* const* gamma, const float* const* beta,
-                                  float* const* running_mean, float* const* running_var, float momentum, float eps, float* const* y,
-                                  float* utail, int utail_ld, float* scsh_out, float* mean_rstd_out, void* ws, int B, int T_in, int V,
-                                  const int* dilations, int n_layers, void* stream) {
+extern "C" int hopmi_wn_stack_fwd_dt(const void* x0, const void* wimg, const float* const* bf, const float* const* bg, const float* prep,
+                                     const float* const* bm, const float* const* gamma, const float* const* beta,
+                                     float* const* running_mean, float* const* running_var, float momentum, float eps, void* const* y,
+                                     void* utail, int utail_ld, float* scsh_out, float* mean_rstd_out, void* ws, int B, int T_in, int V,
+                                     const int* dilations, int n_layers, int dtype, void* stream) {
   StackPlan P;
-  if (int e = stk_plan(B, T_in, V, dilations, n_layers, &P)) return e;
+  if (int e = stk_plan(B, T_in, V, dilations, n_layers, dtype, &P)) return e;
   if (!x0 || !wimg || !bf || !bg || !prep || !bm || !gamma || !beta || !y || !utail || !scsh_out || !mean_rstd_out || !ws) {
     set_error("hopmi_wn_stack_fwd: null pointer argument");
     return HOPMI_EINVAL;
@@ -765,12 +794,26 @@ extern "C" int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipEvent_t e1 = nullptr;
   const hipEvent_t e0 = wn_take_timing_events(&e1);
+  const bool bf16 = dtype == HOPMI_BF16;
   switch (P.mt_max) {
-#define HOPMI_STK_CASE(MT_) \
-    case MT_: hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_>), dim3(P.grid), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A); break;
+#define HOPMI_STK_CASE(MT_)                                                                                                          \
+    case MT_:                                                                                                                        \
+      if (bf16) hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_, __bf16>), dim3(P.grid), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A);   \
+      else hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_, float>), dim3(P.grid), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A);       \
+      break;
     HOPMI_STK_CASE(1) HOPMI_STK_CASE(2) HOPMI_STK_CASE(3) HOPMI_STK_CASE(4) HOPMI_STK_CASE(5)
 #undef HOPMI_STK_CASE
     default: set_error("hopmi_wn_stack_fwd: internal: %d m-tiles", P.mt_max); return HOPMI_EINVAL;
   }
   return check_launch("hopmi_wn_stack_fwd");
+}
+
+extern "C" int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float* const* bf, const float* const* bg, const float* prep,
+                                  const float* const* bm, const float* const* gamma, const float* const* beta,
+                                  float* const* running_mean, float* const* running_var, float momentum, float eps, float* const* y,
+                                  float* utail, int utail_ld, float* scsh_out, float* mean_rstd_out, void* ws, int B, int T_in, int V,
+                                  const int* dilations, int n_layers, void* stream) {
+  return hopmi_wn_stack_fwd_dt(x0, wimg, bf, bg, prep, bm, gamma, beta, running_mean, running_var, momentum, eps,
+                               reinterpret_cast<void* const*>(y), utail, utail_ld, scsh_out, mean_rstd_out, ws, B, T_in, V, dilations,
+                               n_layers, HOPMI_F32, stream);
 }

@@ -29,7 +29,7 @@ class _WaveNetStackFn(torch.autograd.Function):
     the per-layer statistics workspaces (gwnet.replay_bn_update)."""
 
     @staticmethod
-    @ops._fwd32
+    @ops._fwd_any
     def forward(ctx, x0, A1, A2, prep, wimg, bns, keep, *params):
         n = len(DILATIONS)
         tcn = [params[4 * i:4 * i + 4] for i in range(n)]
@@ -37,7 +37,9 @@ class _WaveNetStackFn(torch.autograd.Function):
         aff = [params[6 * n + 2 * i:6 * n + 2 * i + 2] for i in range(n)]
         B, _, V, _ = x0.shape
         dev = x0.device
-        tails = torch.empty(B, 4, V, 64 * n, dtype=torch.float32, device=dev)
+        # x0 is fp32, or bf16 as the start conv's bf16 GEMM left it: the stack keeps that storage type for its saved
+        # activations and for the skip tails (arithmetic, statistics and the gradients between layers are fp32)
+        tails = torch.empty(B, 4, V, 64 * n, dtype=x0.dtype, device=dev)
         scsh = _identity_scsh(dev)
         xin = x0.contiguous()
         saved_x, saved_y, saved_scsh, saved_mr = [xin], [], [], []
@@ -83,6 +85,8 @@ class _WaveNetStackFn(torch.autograd.Function):
         xs, ys, scshs, mrs, wfs, wgs, bfs, bgs, Wms, gammas = (take(n), take(n - 1), take(n), take(n - 1), take(n), take(n),
                                                                take(n), take(n), take(n), take(n))
         dtails = dtails.contiguous()
+        if dtails.dtype != xs[0].dtype:
+            dtails = dtails.to(xs[0].dtype)
         V = xs[0].shape[2]
         dA1 = torch.zeros(V, V, dtype=torch.float32, device=dtails.device)
         dA2 = torch.zeros_like(dA1)
@@ -251,7 +255,7 @@ class gwnet(nn.Module):
         (B,4,V,8*64) gated activations of every layer's last 4 frames (all the skip path needs).
         Training mode uses batch statistics and advances the running statistics like nn.BatchNorm2d."""
         B, _, V, _ = x.shape
-        tails = torch.empty(B, 4, V, 64 * len(DILATIONS), dtype=torch.float32, device=x.device)
+        tails = torch.empty(B, 4, V, 64 * len(DILATIONS), dtype=x.dtype, device=x.device)
         scsh = _identity_scsh(x.device)
         xin = x.contiguous()
         last = len(DILATIONS) - 1
@@ -311,8 +315,10 @@ class gwnet(nn.Module):
         """x (B,T>=13,V,in_dim) channels-last -> (B,4,V,out_dim) channels-last."""
         if x.shape[1] < self.receptive_field:
             x = F.pad(x, (0, 0, 0, 0, self.receptive_field - x.shape[1], 0))          # gwnet.py:145-146
-        x = ops.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias).float()    # gwnet.py:149
-        with torch.autocast("cuda", enabled=False):                                     # the kernels are fp32
+        x = ops.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias)            # gwnet.py:149
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        with torch.autocast("cuda", enabled=False):        # the kernels compute in fp32 and take fp32 or bf16 activations
             A1, A2 = self.adjacency()
             prep = ops.gcn_prepare(A1, A2)      # on-chip images of the mix matrices, shared by all layers
             wimg = self._weight_images() if self.dropout == 0 else None

@@ -126,6 +126,27 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+_fwd_any = torch.amp.custom_fwd(device_type="cuda")      # no input cast: the graph-wavenet kernels take fp32 OR bf16 activations
+
+
+def _dev_act(t: torch.Tensor, name: str):
+    """An activation tensor of the graph-wavenet kernels: contiguous fp32 or bf16 on the device -> (tensor, dtype code of the
+    `_dt` entry points: 0 = fp32, 1 = bf16).  The kernels read / write it as it is (bf16: the storage form of BASELINE.json
+    configs 2 / 4, arithmetic stays fp32)."""
+    if not t.is_cuda:
+        raise _lib.HopmiError(f"hopmi: `{name}` is on {t.device}; the hot path only runs on a ROCm device (no CPU fallback)")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.HopmiError(f"hopmi: `{name}` must be float32 or bfloat16, got {t.dtype}")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t, (1 if t.dtype == torch.bfloat16 else 0)
+
+
+def _f32_param(t, name):
+    return _dev_f32(t if t.dtype == torch.float32 else t.float(), name)
+
+
 def gcn_prepare(A1: torch.Tensor, A2: torch.Tensor) -> torch.Tensor:
     """Padded on-chip images of the node-mix matrices (hopmi_gcn_prepare); build once per forward
     pass and hand to every `gcn(..., prep=...)` call of that pass.  Not differentiable: gradients
@@ -147,9 +168,10 @@ class _GcnFn(torch.autograd.Function):
     """h = Wm.[x ; xA1 ; xA2] + bm on channels-last slabs (gwnet.py:24-46)."""
 
     @staticmethod
-    @_fwd32
+    @_fwd_any
     def forward(ctx, x, A1, A2, Wm, bm, prep):
-        x, Wm, bm = (_dev_f32(t, n) for t, n in ((x, "x"), (Wm, "Wm"), (bm, "bm")))
+        x, dt = _dev_act(x, "x")                         # fp32, or bf16 as a bf16 GEMM left it (hopmi_gcn_fwd_dt)
+        Wm, bm = _f32_param(Wm, "Wm"), _f32_param(bm, "bm")
         V = A1.shape[0]
         if x.shape[-1] != 64 or x.shape[-2] != V or A1.shape != (V, V) or A2.shape != (V, V):
             raise _lib.HopmiError(f"hopmi gcn: bad shapes x{tuple(x.shape)} A1{tuple(A1.shape)} A2{tuple(A2.shape)}")
@@ -160,19 +182,19 @@ class _GcnFn(torch.autograd.Function):
             raise _lib.HopmiError("hopmi gcn: `prep` does not come from gcn_prepare for this V")
         n_slabs = x.numel() // (V * 64)
         h = torch.empty_like(x)
-        _lib.check(_timed("gcn_fwd", gcn_algorithmic_bytes(n_slabs, V), gcn_flops(n_slabs, V),
-                          lambda: L.hopmi_gcn_fwd(x.data_ptr(), prep.data_ptr(), Wm.data_ptr(), bm.data_ptr(),
-                                                  h.data_ptr(), n_slabs, V, st)), "hopmi_gcn_fwd")
+        _lib.check(_timed("gcn_fwd", gcn_algorithmic_bytes(n_slabs, V) // (2 if dt else 1), gcn_flops(n_slabs, V),
+                          lambda: L.hopmi_gcn_fwd_dt(x.data_ptr(), prep.data_ptr(), Wm.data_ptr(), bm.data_ptr(),
+                                                     h.data_ptr(), n_slabs, V, dt, st)), "hopmi_gcn_fwd")
         ctx.save_for_backward(x, prep, Wm)
-        ctx.wm_shape, ctx.V = Wm.shape, V
+        ctx.wm_shape, ctx.V, ctx.dt = Wm.shape, V, dt
         return h
 
     @staticmethod
     @_bwd32
     def backward(ctx, dh):
         x, prep, Wm = ctx.saved_tensors
-        dh = _dev_f32(dh, "dh")
-        V = ctx.V
+        dh, _ = _dev_act(dh if dh.dtype == x.dtype else dh.to(x.dtype), "dh")
+        V, dt = ctx.V, ctx.dt
         n_slabs = x.numel() // (V * 64)
         L = _lib.lib()
         ws = torch.empty(L.hopmi_gcn_bwd_ws_floats(n_slabs, V), dtype=torch.float32, device=x.device)
@@ -183,10 +205,10 @@ class _GcnFn(torch.autograd.Function):
         dbm = torch.empty(64, dtype=torch.float32, device=x.device)
         st = _stream()
         # backward: read x', dh, write dx' (+ tiny dA, dWm, dbm) = 1.5x forward bytes, ~2x forward FLOPs
-        _lib.check(_timed("gcn_bwd", n_slabs * 3 * 64 * V * 4, 2 * gcn_flops(n_slabs, V),
-                          lambda: L.hopmi_gcn_bwd(x.data_ptr(), dh.data_ptr(), prep.data_ptr(), Wm.data_ptr(),
-                                                  dx.data_ptr(), dA1.data_ptr(), dA2.data_ptr(),
-                                                  dWm.data_ptr(), dbm.data_ptr(), ws.data_ptr(), n_slabs, V, st)),
+        _lib.check(_timed("gcn_bwd", n_slabs * 3 * 64 * V * (2 if dt else 4), 2 * gcn_flops(n_slabs, V),
+                          lambda: L.hopmi_gcn_bwd_dt(x.data_ptr(), dh.data_ptr(), prep.data_ptr(), Wm.data_ptr(),
+                                                     dx.data_ptr(), dA1.data_ptr(), dA2.data_ptr(),
+                                                     dWm.data_ptr(), dbm.data_ptr(), ws.data_ptr(), n_slabs, V, dt, st)),
                    "hopmi_gcn_bwd")
         return dx, dA1, dA2, dWm, dbm, None
 
@@ -879,7 +901,9 @@ def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_
     B, T_in, V, _ = xin.shape
     T_out = T_in - dilation
     dev = xin.device
-    y = torch.empty(B, T_out, V, 64, dtype=torch.float32, device=dev) if want_y else None
+    xin, dt = _dev_act(xin, "xin")
+    esz = 2 if dt else 4
+    y = torch.empty(B, T_out, V, 64, dtype=xin.dtype, device=dev) if want_y else None
     fs = torch.empty(B, T_out, V, 128, dtype=torch.float32, device=dev) if want_fs else None
     L = _lib.lib()
     scsh_out = mean_rstd = ws = None
@@ -890,21 +914,21 @@ def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_
         scsh_out = torch.empty(128, dtype=torch.float32, device=dev)
         mean_rstd = torch.empty(192, dtype=torch.float32, device=dev)       # mean, rstd, unbiased variance
         ws = torch.empty(L.hopmi_wn_layer_ws_floats(B, T_in, V, dilation), dtype=torch.float32, device=dev)
-    if utail is not None and (utail.stride(-1) != 1 or utail.stride(2) % 4 or utail.shape != (B, 4, V, 64)):
-        raise _lib.HopmiError(f"hopmi wn_layer: bad utail view {tuple(utail.shape)} strides {utail.stride()}")
+    if utail is not None and (utail.stride(-1) != 1 or utail.stride(2) % 4 or utail.shape != (B, 4, V, 64) or utail.dtype != xin.dtype):
+        raise _lib.HopmiError(f"hopmi wn_layer: bad utail view {tuple(utail.shape)} strides {utail.stride()} {utail.dtype}")
     if wimg.dtype != torch.uint8 or wimg.numel() != L.hopmi_wn_weight_image_bytes(1) or not wimg.is_contiguous():
         raise _lib.HopmiError("hopmi wn_layer: `wimg` is not one layer's row of wn_prepare_weights()")
     st = _stream()
     n_out = B * T_out * V
     # SURVEY.md 8(d), fused layer: x in + x out + the last-4-frames skip tail (+ the per-launch weight image)
-    nbytes = 4 * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + (B * 4 * V * 64 if utail is not None else 0))
+    nbytes = esz * (B * T_in * V * 64 + n_out * 64 * (1 if want_y else 0) + (B * 4 * V * 64 if utail is not None else 0))
     extra = 4 * n_out * 128 * (1 if want_fs else 0)
     flops = n_out * (2 * 2 * 2 * 64 * 64 + (2 * 192 * 64 + 4 * 64 * V if do_gcn else 0))
     _lib.check(_timed(timer_name, nbytes, flops,
-                      lambda: L.hopmi_wn_layer_fwd(xin.data_ptr(), scsh_in.data_ptr(), wimg.data_ptr(), bf.data_ptr(), bg.data_ptr(),
-                                                   _ptr(prep), _ptr(bm), _ptr(y), _ptr(fs), _ptr(utail),
-                                                   utail.stride(2) if utail is not None else 64, _ptr(ws), B, T_in, V, dilation,
-                                                   1 if do_gcn else 0, st), exact=True, extra=extra), "hopmi_wn_layer_fwd")
+                      lambda: L.hopmi_wn_layer_fwd_dt(xin.data_ptr(), scsh_in.data_ptr(), wimg.data_ptr(), bf.data_ptr(), bg.data_ptr(),
+                                                      _ptr(prep), _ptr(bm), _ptr(y), _ptr(fs), _ptr(utail),
+                                                      utail.stride(2) if utail is not None else 64, _ptr(ws), B, T_in, V, dilation,
+                                                      1 if do_gcn else 0, dt, st), exact=True, extra=extra), "hopmi_wn_layer_fwd")
     if bn is not None:
         _lib.check(L.hopmi_wn_bn_finalize(ws.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(rm), _ptr(rv),
                                           float(momentum), float(eps), scsh_out.data_ptr(), mean_rstd.data_ptr(),
@@ -945,13 +969,14 @@ def wn_stack_fwd(x0, wimg, tcn_biases, prep, mlp_biases, bns, tails, dilations):
     nbytes = L.hopmi_wn_stack_ws_bytes(B, T_in, V, dil, n)
     if nbytes == 0:
         raise _lib.HopmiError(f"hopmi wn_stack_fwd: unsupported geometry: {L.hopmi_last_error().decode()}")
-    x0 = _dev_f32(x0, "x0")
+    x0, dt = _dev_act(x0, "x0")
+    esz = 2 if dt else 4
     st = _stream()
     key = (dev.index, st, B, T_in, V, tuple(dilations))
     ws = _STACK_WS.get(key)
     if ws is None:
         ws = _STACK_WS[key] = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
-    if tails.stride(-1) != 1 or tails.stride(2) % 4 or tails.shape != (B, 4, V, 64 * n) or tails.dtype != torch.float32:
+    if tails.stride(-1) != 1 or tails.stride(2) % 4 or tails.shape != (B, 4, V, 64 * n) or tails.dtype != x0.dtype:
         raise _lib.HopmiError(f"hopmi wn_stack_fwd: bad tails tensor {tuple(tails.shape)} strides {tails.stride()}")
     if wimg.dtype != torch.uint8 or wimg.numel() != L.hopmi_wn_weight_image_bytes(n) or not wimg.is_contiguous():
         raise _lib.HopmiError("hopmi wn_stack_fwd: `wimg` is not the wn_prepare_weights() image of these layers")
@@ -961,7 +986,7 @@ def wn_stack_fwd(x0, wimg, tcn_biases, prep, mlp_biases, bns, tails, dilations):
     ys, T = [], T_in
     for l in range(n - 1):
         T -= dilations[l]
-        ys.append(torch.empty(B, T, V, 64, dtype=torch.float32, device=dev))
+        ys.append(torch.empty(B, T, V, 64, dtype=x0.dtype, device=dev))
     scsh = torch.empty(n, 128, dtype=torch.float32, device=dev)
     mean_rstd = torch.empty(n, 192, dtype=torch.float32, device=dev)
     tab = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else _dev_f32(t, "stack parameter").data_ptr() for t in ts])
@@ -972,15 +997,15 @@ def wn_stack_fwd(x0, wimg, tcn_biases, prep, mlp_biases, bns, tails, dilations):
     # SURVEY.md 8(d), fused layers: per layer x in + x out (not the dead last one) + the last-4-frames skip tail
     n_rows, nbytes_alg, flops, T = 0, 0, 0, T_in
     for l, d in enumerate(dilations):
-        nbytes_alg += 4 * 64 * V * (B * T + (B * (T - d) if l < n - 1 else 0) + 4 * B)
+        nbytes_alg += esz * 64 * V * (B * T + (B * (T - d) if l < n - 1 else 0) + 4 * B)
         flops += B * (T - d) * V * (2 * 2 * 2 * 64 * 64 + 2 * 192 * 64 + 4 * 64 * V)
         T -= d
     _lib.check(_timed("wn_stack_fwd", nbytes_alg, flops,
-                      lambda: L.hopmi_wn_stack_fwd(x0.data_ptr(), wimg.data_ptr(), tab([b[0] for b in tcn_biases]), tab([b[1] for b in tcn_biases]),
+                      lambda: L.hopmi_wn_stack_fwd_dt(x0.data_ptr(), wimg.data_ptr(), tab([b[0] for b in tcn_biases]), tab([b[1] for b in tcn_biases]),
                                                    prep.data_ptr(), tab(mlp_biases), tab([bn.weight for bn in bns]), tab([bn.bias for bn in bns]),
                                                    tab([bn.running_mean for bn in bns]), tab([bn.running_var for bn in bns]), mom, eps, ytab,
                                                    tails.data_ptr(), tails.stride(2), scsh.data_ptr(), mean_rstd.data_ptr(), ws.data_ptr(),
-                                                   B, T_in, V, dil, n, st), exact=True), "hopmi_wn_stack_fwd")
+                                                   B, T_in, V, dil, n, dt, st), exact=True), "hopmi_wn_stack_fwd")
     _track_status(ws[:48])                              # (status word = int 32 of the control block = index [-16] of this view)
     return ys, scsh, mean_rstd
 
@@ -1006,6 +1031,9 @@ def wn_layer_bwd(xin, scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next, y, bn_coe
     B, T_in, V, _ = xin.shape
     T_out = T_in - dilation
     dev = xin.device
+    xin, dt = _dev_act(xin, "xin")                     # saved activations and the skip-tail gradient: fp32 or bf16 (one storage type)
+    if (y is not None and y.dtype != xin.dtype) or dutail.dtype != xin.dtype:
+        raise _lib.HopmiError(f"hopmi wn_layer_bwd: xin {xin.dtype}, y {None if y is None else y.dtype}, dutail {dutail.dtype} must share a dtype")
     new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
     out = dict(P0=new(B, T_out, V, 64), P1=new(B, T_out, V, 64), dwf=new(64, 64, 1, 2), dwg=new(64, 64, 1, 2), dbtcn=new(128),
                dWm=new(64, 192) if do_gcn else None, dbm=new(64) if do_gcn else None,
@@ -1021,14 +1049,14 @@ def wn_layer_bwd(xin, scsh_in, fs, wf, wg, prep, Wm, P0n, P1n, d_next, y, bn_coe
     st = _stream()
     n_out = B * T_out * V
     _lib.check(_timed("wn_layer_bwd", 4 * (2 * B * T_in * V * 64 + n_out * 64 * 5 + n_out * 128), 0,
-                      lambda: L.hopmi_wn_layer_bwd(xin.data_ptr(), scsh_in.data_ptr(), fs.data_ptr(), _conv_w(wf), _conv_w(wg),
+                      lambda: L.hopmi_wn_layer_bwd_dt(xin.data_ptr(), scsh_in.data_ptr(), fs.data_ptr(), _conv_w(wf), _conv_w(wg),
                                                    _ptr(prep), _ptr(Wm), _ptr(P0n), _ptr(P1n), int(d_next), _ptr(y),
                                                    _ptr(bn_coef), dutail.data_ptr(), dutail.stride(2), _ptr(gamma_prev),
                                                    _ptr(mean_rstd_prev), out["P0"].data_ptr(), out["P1"].data_ptr(),
                                                    out["dwf"].data_ptr(), out["dwg"].data_ptr(), out["dbtcn"].data_ptr(),
                                                    _ptr(out["dWm"]), _ptr(out["dbm"]), _ptr(out["dA1"]), _ptr(out["dA2"]),
                                                    1 if dA is not None else 0, _ptr(out["dgamma_prev"]), _ptr(out["dbeta_prev"]), _ptr(out["coef_prev"]),
-                                                   ws.data_ptr(), B, T_in, V, dilation, 1 if do_gcn else 0, st)),
+                                                   ws.data_ptr(), B, T_in, V, dilation, 1 if do_gcn else 0, dt, st)),
                "hopmi_wn_layer_bwd")
     return out
 

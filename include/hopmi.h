@@ -155,6 +155,34 @@ int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float* const* bf
                        float* utail, int utail_ld, float* scsh_out, float* mean_rstd_out, void* ws, int B, int T_in, int V,
                        const int* dilations, int n_layers, void* stream);
 
+/* ---- storage type of the graph-wavenet activations (BASELINE.json configs 2 / 4: bf16).  The `_dt` forms of the graph-conv,
+ *      WaveNet-layer and WaveNet-stack entry points take `dtype` (0 = fp32, 1 = bf16) for the ACTIVATION tensors that enter and
+ *      leave the kernels -- x / h / dh / dx of hopmi_gcn_*, xin / y / utail of the forward, xin / y / dutail of the backward, x0 /
+ *      y[l] / utail of the stack -- read as the previous GEMM leaves them and written as the next one reads them (no cast launches
+ *      at the block's boundary, half the bytes).  Arithmetic, statistics, weights, scale / shift, the tanh / sigmoid diagnostic
+ *      output fs and the gradients between layers (P0 / P1) stay fp32; y is rounded once, when it is stored.  Every other
+ *      argument is as in the untyped form, which is the dtype = 0 case. */
+int hopmi_gcn_fwd_dt(const void* x, const float* prep, const float* Wm, const float* bm, void* h, int n_slabs, int V, int dtype,
+                     void* stream);
+int hopmi_gcn_bwd_dt(const void* x, const void* dh, const float* prep, const float* Wm, void* dx, float* dA1, float* dA2, float* dWm,
+                     float* dbm, float* ws, int n_slabs, int V, int dtype, void* stream);
+int hopmi_wn_layer_fwd_dt(const void* xin, const float* scsh_in, const void* wimg, const float* bf, const float* bg,
+                          const float* prep, const float* bm, void* y, float* fs, void* utail, int utail_ld, float* ws, int B,
+                          int T_in, int V, int dilation, int do_gcn, int dtype, void* stream);
+int hopmi_wn_stack_fwd_dt(const void* x0, const void* wimg, const float* const* bf, const float* const* bg, const float* prep,
+                          const float* const* bm, const float* const* gamma, const float* const* beta,
+                          float* const* running_mean, float* const* running_var, float momentum, float eps, void* const* y,
+                          void* utail, int utail_ld, float* scsh_out, float* mean_rstd_out, void* ws, int B, int T_in, int V,
+                          const int* dilations, int n_layers, int dtype, void* stream);
+int hopmi_wn_layer_bwd_dt(const void* xin, const float* scsh_in, const float* fs, const float* wf, const float* wg,
+                          const float* prep, const float* Wm, const float* P0n, const float* P1n, int d_next,
+                          const void* y, const float* bn_coef, const void* dutail, int dutail_ld,
+                          const float* gamma_prev, const float* mean_rstd_prev,
+                          float* P0, float* P1, float* dwf, float* dwg, float* dbtcn, float* dWm, float* dbm,
+                          float* dA1, float* dA2, int accumulate_dA, float* dgamma_prev, float* dbeta_prev,
+                          float* coef_prev, float* ws,
+                          int B, int T_in, int V, int dilation, int do_gcn, int dtype, void* stream);
+
 /* Backward of one fused WaveNet layer (autograd of gwnet.py:181-237), see csrc/wavenet_bwd.hip.
  *   xin, scsh_in, fs, wf, wg, prep, Wm : as in / saved by the forward
  *   P0n, P1n [B][T_out - d_next][V][64]: gradient w.r.t. this layer's BatchNorm output as written by the NEXT

@@ -627,6 +627,130 @@ def test_wn_stack_one_launch_vs_per_layer_launches(V, B):
             assert torch.equal(a["bufs"][n], c["bufs"][n]), n
 
 
+# ---- bf16 storage of the graph-wavenet activations (BASELINE.json configs 2 / 4; the `dtype` argument of the _dt entry points) ----
+@pytest.mark.parametrize("V,B,T", [(9, 128, 15), (42, 64, 13), (17, 3, 4)])
+def test_gcn_bf16_storage_equals_rounded_fp32(V, B, T):
+    """hopmi_gcn_fwd_dt / hopmi_gcn_bwd_dt with bf16 activations: the same arithmetic as the fp32 form on the same (bf16-
+    representable) inputs, rounded once at the store -- h and dx equal the fp32 form's results rounded to bf16 BIT FOR BIT;
+    the parameter gradients (fp32 sums over the same products) are equal."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(V + B)
+    x = torch.randn(B, T, V, 64, generator=g).to(dev).bfloat16()
+    dh = torch.randn(B, T, V, 64, generator=g).to(dev).bfloat16()
+    A = torch.softmax(torch.randn(V, V, generator=g), 1).to(dev)
+    W = (torch.randn(64, 192, generator=g) / 14).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    res = {}
+    for name, cast in (("bf16", lambda t: t), ("fp32", lambda t: t.float())):
+        xx, Ag, Wg, bg = cast(x).clone().requires_grad_(), A.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
+        h = ops.gcn(xx, Ag, Ag.detach() @ Ag.detach(), Wg, bg)
+        assert h.dtype == xx.dtype
+        h.backward(cast(dh))
+        res[name] = (h.detach(), xx.grad, Wg.grad, bg.grad, Ag.grad)
+    hb, dxb, dWb, dbb, dAb = res["bf16"]
+    hf, dxf, dWf, dbf, dAf = res["fp32"]
+    assert torch.equal(hb, hf.bfloat16()) and torch.equal(dxb, dxf.bfloat16())
+    assert torch.equal(dWb, dWf) and torch.equal(dbb, dbf) and torch.equal(dAb, dAf)
+
+
+@pytest.mark.parametrize("V,B", [(9, 128), (42, 64), (5, 3)])
+def test_wn_stack_bf16_storage(V, B):
+    """The WaveNet stack with bf16 activations (x0, saved y_l, skip tails), as one persistent launch and as per-layer launches:
+    (1) layer 0 sees the same inputs as the fp32 form fed the same bf16-representable x0, so its y and skip tail equal the
+    fp32 form's rounded to bf16 BIT FOR BIT; (2) from layer 1 on the input is the ROUNDED y (2^-9 relative per element, 8
+    layers in sequence): statistics and the last layers' tails stay within sqrt(8) * 2^-8 = 1.1e-2 of the fp32 form (1.5e-2
+    allowed); (3) the two launch forms agree with each other as they do in fp32."""
+    import copy
+    import sys
+    import hopmi
+    from hopmi import ops
+    gw = sys.modules["hopmi.gwnet"]
+    dev = _dev()
+    torch.manual_seed(4)
+    m = hopmi.gwnet(None, V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173,
+                    out_dim=173, residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512).to(dev).train()
+    x0 = torch.randn(B, 16, V, 64, device=dev).bfloat16()
+    n = len(gw.DILATIONS)
+    out = {}
+    with torch.no_grad():
+        A1, A2 = m.adjacency()
+        prep = ops.gcn_prepare(A1, A2)
+        wimg = m._weight_images()
+        for name, xin, stack in (("bf16", x0, True), ("fp32", x0.float(), True), ("bf16_layers", x0, False)):
+            mm = copy.deepcopy(m)
+            tails = torch.empty(B, 4, V, 64 * n, dtype=xin.dtype, device=dev)
+            if stack:
+                ys, scsh, mr = ops.wn_stack_fwd(xin, wimg, [(mm.filter_convs[i].bias, mm.gate_convs[i].bias) for i in range(n)], prep,
+                                                [mm.gconv[i].mlp.mlp.bias for i in range(n)], list(mm.bn), tails, gw.DILATIONS)
+                assert all(y.dtype == xin.dtype for y in ys)
+            else:
+                ops.STACK_ENABLED = False
+                try:
+                    tails = mm._skip_tails_fused(xin, prep, wimg)
+                finally:
+                    ops.STACK_ENABLED = True
+                ys, mr = None, torch.stack(mm._bn_keep.items)
+            out[name] = (ys, tails, mr, {k: v.clone() for k, v in mm.named_buffers()})
+    torch.cuda.synchronize()
+    ops.check_status_now()
+    (yb, tb, mrb, bufb), (yf, tf, mrf, buff) = out["bf16"], out["fp32"]
+    assert tb.dtype == torch.bfloat16 and tf.dtype == torch.float32
+    assert torch.equal(yb[0], yf[0].bfloat16()), "layer 0: y"
+    assert torch.equal(tb[..., :64], tf[..., :64].bfloat16()), "layer 0: skip tail"
+    assert_close(mrb[0], mrf[0], 1e-5, "layer 0 statistics (same fp32 sums)")
+    assert_close(tb.float(), tf, 1.5e-2, "tails")
+    assert_close(mrb[:, :64], mrf[:, :64], 1.5e-2, "means")
+    assert_close(mrb[:, 64:128], mrf[:, 64:128], 1.5e-2, "rstd")
+    for k in bufb:
+        if bufb[k].is_floating_point():
+            assert_close(bufb[k], buff[k], 1.5e-2, k)
+    _, tl, mrl, _ = out["bf16_layers"]
+    assert tl.dtype == torch.bfloat16
+    assert_close(tl.float(), tb.float(), 1.5e-2, "per-layer launches vs one launch (bf16)")
+    assert torch.equal(tl[..., :64], tb[..., :64])
+
+
+@pytest.mark.parametrize("V,B", [(9, 128), (42, 64)])
+def test_gwnet_bf16_autocast_vs_oracle(V, B):
+    """gwnet forward + backward under bf16 autocast (configs 2 / 4 of BASELINE.json: bf16 library GEMMs for the start / skip /
+    end convs, bf16 storage of the WaveNet stack's activations, fp32 arithmetic inside the kernels) against the fp32 oracle.
+    Tolerance, derived: 8 layers store their output rounded to bf16 (2^-9 each) and 4 bf16 GEMMs sit in sequence with them:
+    sqrt(12) * 2^-8 = 1.4e-2 of the tensor's scale for the output (1.6e-2 allowed); the gradients pass the same chain
+    backwards and are compared in the L2 norm (4e-2: a ReLU near its kink may land on the other side for a few elements)."""
+    import hopmi
+    from oracle import fill, ref_cpu, spec
+    dev = _dev()
+    m = hopmi.gwnet(None, V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173,
+                    out_dim=173, residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512)
+    fill.fill_state_(m)
+    m.to(dev).train()
+    x0 = fill.uniform("gwnet.x0", (B, 173, V, 16))
+    gout = fill.uniform("gwnet.gout", (B, 173, V, 4))
+    xg = x0.to(dev).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(xg)
+    (out.float() * gout.to(dev)).sum().backward()
+    sd = spec.build_sd(spec.gwnet_spec(V, prefix=""))
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    xo = x0.clone().requires_grad_()
+    want, upd = ref_cpu.gwnet_forward(sd, xo, prefix="", training=True)
+    (want * gout).sum().backward()
+    e = rel_err(out.float(), want)
+    assert e <= 1.6e-2, f"out rel err {e:.3e}"
+    l2 = lambda g, w: ((g.detach().cpu().double() - w.double()).norm() / w.double().norm().clamp_min(1e-30)).item()
+    assert l2(xg.grad, xo.grad) <= 4e-2, l2(xg.grad, xo.grad)
+    for n_, p in m.named_parameters():
+        if sd[n_].grad is None or n_.endswith("mlp.mlp.bias"):
+            continue
+        assert p.grad is not None and p.grad.dtype == torch.float32, n_
+        assert l2(p.grad, sd[n_].grad) <= 4e-2, (n_, l2(p.grad, sd[n_].grad))
+    for i in range(8):
+        assert_close(m.bn[i].running_var, upd[f"bn.{i}.running_var"], 2e-2, what=f"bn{i} rv")
+
+
 # ---------------------------------------------------------------------------------- full model
 def _make_model(V, dev):
     import hopmi
@@ -1404,14 +1528,14 @@ def test_reprog_attention_vs_float64():
     scale = 1.0 / E ** 0.5
 
     def attn(cast):
-        qq, kk, vv = (t.to(cast).requires_grad_() for t in (q, k, v))
+        qq, kk, vv = (t.detach().clone().to(cast).requires_grad_() for t in (q, k, v))
         p = torch.softmax(scale * torch.einsum("blhe,she->bhls", qq, kk), dim=-1)
         o = torch.einsum("bhls,she->blhe", p, vv)
         (o * go.to(cast)).sum().backward()
         return o.detach(), qq.grad, kk.grad, vv.grad
 
     ref64, ref32 = attn(torch.float64), attn(torch.float32)
-    qd, kd, vd = (t.to(dev).requires_grad_() for t in (q, k, v))
+    qd, kd, vd = (t.detach().clone().to(dev).requires_grad_() for t in (q, k, v))
     o = ops.reprog_attention(qd, kd, vd, scale, 0.0, 0)
     (o * go.to(dev)).sum().backward()
     torch.cuda.synchronize()

@@ -7,7 +7,7 @@
 #   5./6. kernel-trace + stats of the bf16 (configs[2] per GPU) and TED-Expressive (configs[3]) workloads
 # Raw output goes to gpurun_out/prof_*; tools/summarize_profiles.py turns it into profiles/<tag>_*.{csv,json}.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 REPO=$(pwd)
 mkdir -p gpurun_out
