@@ -751,6 +751,95 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
   }
 }
 
+// The same for the backward (BPTT of one direction, reference: multimodal_context_net.py:236-237 through autograd): workgroup =
+// (16 batch rows, direction), all T steps, nothing crosses workgroups.  Per step, with the step processed before it being the
+// direction's NEXT time step:   D = dy_t + D' z' + [dr' | dz' | dn' r'] W_hh   (the last term: 16 x 192 panel in LDS times the
+// wave's resident split fragments of W_hh^T, 18 MFMAs),   dn = D (1 - z)(1 - n^2),  dz = D (h_{t-1} - n) z (1 - z),
+// dr = dn hn r (1 - r);  dgi = (dr, dz, dn),  dgh = (dr, dz, dn r) (what the weight-gradient GEMMs and the next step read).
+// Wave w owns units [16 w, 16 w + 16); a lane's four accumulator rows are its four batch rows, so D' z' stays in registers.
+// The step's inputs (dy, the four saved gate values, h_{t-1}) of the next GS_AHEAD steps are kept in flight.
+template <typename TG>
+__global__ __launch_bounds__(256) void gru_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ gates, const float* __restrict__ whhT,
+                                                            TG* __restrict__ dgi, float* __restrict__ dgh, int B, int T) {
+  constexpr int H = GS_H, K = 3 * GS_H, LDP = 3 * GS_H + 4;             // panel rows of 196 floats: 16-byte aligned, 4 (mod 64)
+  __shared__ __attribute__((aligned(16))) float pbuf[2][16][LDP];
+  const int d = blockIdx.x & 1, b0 = (blockIdx.x >> 1) * 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
+  const int j = 16 * w + i;                                            // this lane's unit (C layout column)
+  u32x4 wh[3][2], wl[3][2];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float* wrow = whhT + ((size_t)d * H + j) * K + g * H;        // W_hh^T: row = unit, columns = the 3H recurrent pre-activations
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const Split8 f = load_w_frag(wrow, 32 * ks + 8 * q, H);
+      wh[g][ks] = f.hi; wl[g][ks] = f.lo;
+    }
+  }
+  int brow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) brow[r] = min(b0 + 4 * q + r, B - 1);
+  float dhz_own[4] = {0.f, 0.f, 0.f, 0.f};
+  float in_dy[GS_AHEAD][4], in_g[GS_AHEAD][4][4], in_hp[GS_AHEAD][4];
+  auto fetch = [&](int slot, int s) {
+    const int t = d ? s : T - 1 - s;
+    const int tp = d ? t + 1 : t - 1, tpc = min(max(tp, 0), T - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      in_dy[slot][r] = dy[((size_t)brow[r] * T + t) * 2 * H + d * H + j];
+      const float* gp = gates + (((size_t)brow[r] * T + t) * 2 + d) * 4 * H + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) in_g[slot][r][g] = gp[g * H];
+      in_hp[slot][r] = y[((size_t)brow[r] * T + tpc) * 2 * H + d * H + j];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < GS_AHEAD; ++u)
+    if (u < T) fetch(u, u);
+
+  for (int s0 = 0; s0 < T; s0 += GS_AHEAD) {
+#pragma unroll
+    for (int u = 0; u < GS_AHEAD; ++u) {
+      const int s = s0 + u;
+      if (s < T) {                                                     // (uniform over the workgroup)
+        const int t = d ? s : T - 1 - s;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+          const float* pp = &pbuf[(s - 1) & 1][i][8 * q];
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const Split8 a = split8(*reinterpret_cast<const float4*>(pp + g * H + 32 * ks), *reinterpret_cast<const float4*>(pp + g * H + 32 * ks + 4));
+              acc = mfma_split3(a.hi, a.lo, wh[g][ks], wl[g][ks], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float D = in_dy[u][r] + (s > 0 ? dhz_own[r] + acc[r] : 0.f);
+          const float gr = in_g[u][r][0], gz = in_g[u][r][1], gn = in_g[u][r][2], hn = in_g[u][r][3];
+          const float hp = (s < T - 1) ? in_hp[u][r] : 0.f;
+          const float dn = D * (1.f - gz) * (1.f - gn * gn);
+          const float dz = D * (hp - gn) * gz * (1.f - gz);
+          const float dr = dn * hn * gr * (1.f - gr);
+          float* pr = &pbuf[s & 1][4 * q + r][j];
+          pr[0] = dr; pr[H] = dz; pr[2 * H] = dn * gr;
+          const int b = b0 + 4 * q + r;
+          if (b < B) {
+            const size_t o = (((size_t)b * T + t) * 2 + d) * K + j;
+            dgh[o] = dr; dgh[o + H] = dz; dgh[o + 2 * H] = dn * gr;
+            dgi[o] = (TG)dr; dgi[o + H] = (TG)dz; dgi[o + 2 * H] = (TG)dn;
+          }
+          dhz_own[r] = D * gz;
+        }
+        if (s + GS_AHEAD < T) fetch(u, s + GS_AHEAD);
+        __syncthreads();                                               // this step's panel visible; everyone is done with the other
+      }
+    }
+  }
+}
+
 // Before a persistent launch: zero the status word and fill the hand-off array with the "not written yet" pattern.  A
 // kernel, not hipMemsetAsync: inside a replayed hipGraph a memset node was observed to land AFTER the dependent persistent
 // kernel had started; kernel -> kernel ordering holds in graphs and eagerly alike.
@@ -943,6 +1032,11 @@ static int gru_bwd_impl(const float* dy, const float* y, const float* gates, con
   const void* ptrs[] = {dy, y, gates, whhT, dgi, dgh, ws};
   if (int e = gru_validate(ptrs, 7, B, T, H)) return e;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (H == GS_H && env_int("HOPMI_GRU_SMALL", 1) != 0) {               // one workgroup per (16 rows, direction): no hand-off
+    if (ws2 != nullptr) gru_prepare(ws2, hopmi_gru_ws_bytes(B, T, H), nullptr, 0, st);                    // status = 0
+    hipLaunchKernelGGL((gru_bwd_small_kernel<TG>), dim3(2 * ((B + 15) / 16)), dim3(256), 0, st, dy, y, gates, whhT, dgi, dgh, B, T);
+    return check_launch("hopmi_gru_bwd(small)");
+  }
   if (gru_persistent_ok<false, TG>(B, H, ws2)) {
     const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
     int* status = gru_status_word(ws2, B, T, H);

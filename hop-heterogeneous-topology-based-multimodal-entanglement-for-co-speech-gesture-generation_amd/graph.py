@@ -184,6 +184,11 @@ class GraphedTrainStep:
             self._bg = torch.zeros_like(m.mapping_layer.bias)
         for opt in (self.g_opt, self.d_opt):
             _make_capturable(opt)
+        # more than one rank: every rank steps Adam on its own rows of the mapping layer only (see _after_backward)
+        self._rows_adam = bool(self._has_proto and self.world > 1 and isinstance(self.g_opt, torch.optim.Adam)
+                               and not isinstance(self.g_opt, torch.optim.AdamW))
+        if self._rows_adam:
+            self.g_opt.register_step_post_hook(self._adam_own_rows)
         # what a replay writes in place: the optimizers' parameters and the modules' buffers (BatchNorm statistics)
         seen, written = set(), []
         for t in [p for opt in (self.g_opt, self.d_opt) for g in opt.param_groups for p in g["params"]] + \
@@ -249,7 +254,31 @@ class GraphedTrainStep:
                     # (the step's precision, not the ambient autocast state: this runs behind train_llm's autocast block)
                     bf16 = (getattr(self.args, "mixed_precision", None) or _steps._MIXED) == "bf16"
                     mapping_grad_rows(dS, m.word_embeddings, self.r0, self.r1, self._Wg, self._bg, bf16=bf16)
-            m.mapping_layer.weight.grad, m.mapping_layer.bias.grad = self._Wg, self._bg
+            if self._rows_adam:
+                # this rank's rows only: the optimizer's own step skips the two tensors (no gradient), the step hook below
+                # runs Adam on the row views (and their moments) -- the other ranks' rows, whose gradient is identically zero
+                # here, are not touched at all (183 MB of weights + two moments read and written per step otherwise)
+                m.mapping_layer.weight.grad = m.mapping_layer.bias.grad = None
+            else:
+                m.mapping_layer.weight.grad, m.mapping_layer.bias.grad = self._Wg, self._bg
+
+    def _adam_own_rows(self, opt, *_):
+        """Optimizer step post-hook (recorded with the step): Adam on rows [r0, r1) of the mapping layer with the optimizer's own
+        state tensors and hyper-parameters, through torch's functional form on row views."""
+        if _steps._CAPTURE is None or not self._rows_adam or self.r1 <= self.r0:
+            return
+        from torch.optim.adam import adam as _adam
+        m = self.model
+        r0, r1 = self.r0, self.r1
+        for p, g in ((m.mapping_layer.weight, self._Wg), (m.mapping_layer.bias, self._bg)):
+            grp = next(gr for gr in opt.param_groups if any(q is p for q in gr["params"]))
+            st = opt.state[p]
+            with torch.no_grad():
+                _adam([p[r0:r1]], [g[r0:r1]], [st["exp_avg"][r0:r1]], [st["exp_avg_sq"][r0:r1]],
+                      [st["max_exp_avg_sq"][r0:r1]] if grp.get("amsgrad", False) else [], [st["step"]],
+                      foreach=grp.get("foreach"), capturable=True, differentiable=False, fused=grp.get("fused"),
+                      amsgrad=grp.get("amsgrad", False), beta1=grp["betas"][0], beta2=grp["betas"][1], lr=grp["lr"],
+                      weight_decay=grp.get("weight_decay", 0.0), eps=grp["eps"], maximize=grp.get("maximize", False))
 
     # -- capture -----------------------------------------------------------------------------------------------------
     def _capture(self, epoch, batch):

@@ -316,8 +316,8 @@ class gwnet(nn.Module):
         if x.shape[1] < self.receptive_field:
             x = F.pad(x, (0, 0, 0, 0, self.receptive_field - x.shape[1], 0))          # gwnet.py:145-146
         x = ops.linear(x, self.start_conv.weight.flatten(1), self.start_conv.bias)            # gwnet.py:149
-        if x.dtype not in (torch.float32, torch.bfloat16):
-            x = x.float()
+        if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and ops.WN_BF16_STORAGE):
+            x = x.float()                                  # (ops.WN_BF16_STORAGE = False: fp32 storage also under bf16 autocast)
         with torch.autocast("cuda", enabled=False):        # the kernels compute in fp32 and take fp32 or bf16 activations
             A1, A2 = self.adjacency()
             prep = ops.gcn_prepare(A1, A2)      # on-chip images of the mix matrices, shared by all layers

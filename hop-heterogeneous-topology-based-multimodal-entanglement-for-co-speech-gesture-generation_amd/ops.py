@@ -938,6 +938,11 @@ def wn_layer_fwd(xin, scsh_in, wimg, bf, bg, prep, bm, utail, dilation, *, want_
     return y, fs, scsh_out, mean_rstd
 
 
+# Under bf16 autocast the WaveNet stack keeps its activations (x0, the saved y_l, the skip tails and their gradient) in bf16, as
+# the reference's convolutions and BatchNorm do under accelerate's bf16 mode.  False: fp32 storage in every mode (two cast
+# launches at the block's boundary, twice the bytes; the BatchNorm backward then sees unrounded y).
+WN_BF16_STORAGE = True
+
 _STACK_WS = {}       # (device index, stream, geometry) -> workspace of the persistent stack kernel (counters zero between launches)
 STACK_ENABLED = True  # False: the training forward runs as per-layer launches (A/B runs, HOPMI_WN_STACK=0)
 
