@@ -27,7 +27,6 @@ namespace hopmi {
 
 constexpr int AE = 128;            // head dim (d_keys = d_ff = 128, HOP.py:119)
 constexpr int ABM = 64;            // query rows per workgroup (16 per wave)
-constexpr int KVK = 64;            // dK/dV kernel: keys per workgroup (16 per wave)
 
 // ------------------------------------------------------------------------------------------------------
 // bf16 operand images (split: hi + lo, bf16_dev.h) of a [S][H][E] fp32 tensor, made once per call by
@@ -400,13 +399,19 @@ __global__ __launch_bounds__(256, 3) void reprog_attn_bwd_dq_kernel(const TIO* _
   }
 }
 
-// dK/dV kernel: workgroup = (64-key chunk, head, row split), wave w owns 16 keys: their K and V rows are MFMA A fragments
-// in registers, dK / dV live in accumulators.  The query-row tiles t = split, split + nsplit, ... (32 rows each) are
+// dK/dV kernel: workgroup = (16 NW-key chunk, head, row split), NW waves, wave w owns 16 keys: their K and V rows are MFMA A
+// fragments in registers, dK / dV live in accumulators.  The query-row tiles t = split, split + nsplit, ... (32 rows each) are
 // staged from the Q / dO images: natural rows for S^T = K Q^T and dP^T = V dO^T, transposed rows for dV += (P o M)^T dO
 // and dK += dS^T Q.  The partial dK / dV go to slab `split` of dKp / dVp ([nsplit][S][H][E]); the caller adds the slabs
-// in a fixed order.  80 KB of LDS => 2 workgroups per CU.
-template <typename TIO>
-__global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const TIO* __restrict__ K, const TIO* __restrict__ Vv,
+// in a fixed order.
+// Every workgroup stages every one of its row tiles (64 KB of images per tile) whatever its number of keys, so the launch's
+// L2 -> LDS traffic is (key chunks x heads) x 8.7 MB: 1.67 GB with 64-key chunks at B = 128 -- that, not the matrix work,
+// set the 215 us of rounds 1-2, and the 8 row splits that filled the chip with 1 536 small workgroups wrote 8 partial slabs
+// (96 MB for 12 MB of dK / dV).  NW = 8 (default): 128-key chunks halve the staging traffic, 8 waves share each staged tile,
+// and 96 (chunk, head) units x 2 row splits = 192 workgroups of 512 threads fill the chip in one round with TWO slabs.
+// NW = 4 (HOPMI_ATTN_DKV_WAVES=4): the previous form (64-key chunks, 8 splits, 2 workgroups per CU).
+template <typename TIO, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void reprog_attn_bwd_dkv_kernel(const TIO* __restrict__ K, const TIO* __restrict__ Vv,
                                                                   const u16* __restrict__ Qnat, const u16* __restrict__ Qtr,
                                                                   const u16* __restrict__ Dnat, const u16* __restrict__ Dtr,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
@@ -415,12 +420,13 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const TIO* 
                                                                   float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   constexpr bool IN_LO = sizeof(TIO) == 4;
+  constexpr int KVK = 16 * NW, NT = 64 * NW, NIT = 512 / NT;       // keys per workgroup, threads, staging iterations per image part
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* Ql_ = lds;                        // [2 parts][32 rows][256 B]   (scaled) Q rows
   unsigned char* Dl_ = Ql_ + 2 * 32 * 256;         //                            dO rows
   unsigned char* QT_ = Dl_ + 2 * 32 * 256;         // [2 parts][128 rows][64 B]   (scaled) Q^T
   unsigned char* DT_ = QT_ + 2 * 128 * 64;         //                            dO^T
-  unsigned char* Pl_ = DT_ + 2 * 128 * 64;         // [4 waves][2 tiles][2 parts][16][64 B]   (P o M)^T and dS^T
+  unsigned char* Pl_ = DT_ + 2 * 128 * 64;         // [NW waves][2 tiles][2 parts][16][64 B]   (P o M)^T and dS^T
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int nchunk = (S + KVK - 1) / KVK;
   const int h = blockIdx.x % H, chunk = (blockIdx.x / H) % nchunk, split = blockIdx.x / (H * nchunk);
@@ -447,10 +453,10 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const TIO* 
   const u16* dn = Dnat + (size_t)h * 2 * Np * AE;
   const u16* qt = Qtr + (size_t)h * 2 * AE * Np;
   const u16* dt = Dtr + (size_t)h * 2 * AE * Np;
-  int dst_k[2], dst_t[2];
+  int dst_k[NIT], dst_t[NIT];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int u = tid + 256 * it;
+  for (int it = 0; it < NIT; ++it) {
+    const int u = tid + NT * it;
     const int k = u >> 4, s = u & 15, lrow = (k & 1) * 16 + (k >> 1);
     dst_k[it] = lrow * 256 + ((s ^ (lrow & 15)) << 4);
     const int e = u >> 2, s4 = u & 3;
@@ -461,18 +467,18 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const TIO* 
   const int key_c0 = chunk * KVK + 16 * w + 4 * q; // C-layout key rows 4q + r of this wave's tile
 
   for (int t = split; t < ntile; t += nsplit) {
-    u32x4 pre[16];
+    u32x4 pre[8 * NIT];
 #pragma unroll
     for (int part = 0; part < 2; ++part)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int u = tid + 256 * it;
+      for (int it = 0; it < NIT; ++it) {
+        const int u = tid + NT * it;
         const size_t nat_off = ((size_t)part * Np + t * 32 + (u >> 4)) * AE + 8 * (u & 15);
         const size_t tr_off = ((size_t)part * AE + (u >> 2)) * Np + t * 32 + 8 * (u & 3);
-        pre[part * 2 + it] = *reinterpret_cast<const u32x4*>(qn + nat_off);
-        pre[4 + part * 2 + it] = *reinterpret_cast<const u32x4*>(dn + nat_off);
-        pre[8 + part * 2 + it] = *reinterpret_cast<const u32x4*>(qt + tr_off);
-        pre[12 + part * 2 + it] = *reinterpret_cast<const u32x4*>(dt + tr_off);
+        pre[part * NIT + it] = *reinterpret_cast<const u32x4*>(qn + nat_off);
+        pre[2 * NIT + part * NIT + it] = *reinterpret_cast<const u32x4*>(dn + nat_off);
+        pre[4 * NIT + part * NIT + it] = *reinterpret_cast<const u32x4*>(qt + tr_off);
+        pre[6 * NIT + part * NIT + it] = *reinterpret_cast<const u32x4*>(dt + tr_off);
       }
     // lane holds key rows 4q + r, query rows row0 + 2j + nt
     const int row0 = t * 32 + 2 * j;
@@ -487,11 +493,11 @@ __global__ __launch_bounds__(256, 2) void reprog_attn_bwd_dkv_kernel(const TIO* 
 #pragma unroll
     for (int part = 0; part < 2; ++part)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        *reinterpret_cast<u32x4*>(Ql_ + part * 32 * 256 + dst_k[it]) = pre[part * 2 + it];
-        *reinterpret_cast<u32x4*>(Dl_ + part * 32 * 256 + dst_k[it]) = pre[4 + part * 2 + it];
-        *reinterpret_cast<u32x4*>(QT_ + part * 128 * 64 + dst_t[it]) = pre[8 + part * 2 + it];
-        *reinterpret_cast<u32x4*>(DT_ + part * 128 * 64 + dst_t[it]) = pre[12 + part * 2 + it];
+      for (int it = 0; it < NIT; ++it) {
+        *reinterpret_cast<u32x4*>(Ql_ + part * 32 * 256 + dst_k[it]) = pre[part * NIT + it];
+        *reinterpret_cast<u32x4*>(Dl_ + part * 32 * 256 + dst_k[it]) = pre[2 * NIT + part * NIT + it];
+        *reinterpret_cast<u32x4*>(QT_ + part * 128 * 64 + dst_t[it]) = pre[4 * NIT + part * NIT + it];
+        *reinterpret_cast<u32x4*>(DT_ + part * 128 * 64 + dst_t[it]) = pre[6 * NIT + part * NIT + it];
       }
     __syncthreads();
 
@@ -630,9 +636,9 @@ extern "C" int hopmi_reprog_attn_fwd(const float* q, const float* k, const float
   return hopmi_reprog_attn_fwd_dt(q, k, v, o, HOPMI_F32, lse, ws, N, S, H, E, scale, p_drop, seed, seed_dev, stream);
 }
 
-// dK/dV grid = 24 key chunks x 8 heads x splits workgroups at 2 resident per CU (512 slots): 8 splits make
-// it exactly 3 full rounds at the B = 128 shape
-extern "C" int hopmi_reprog_attn_bwd_splits(void) { return 8; }
+// dK/dV kernel form: waves per workgroup (16 keys each) and the number of query-row splits = partial slabs (see the kernel)
+static int attn_dkv_waves() { return env_int("HOPMI_ATTN_DKV_WAVES", 8) == 4 ? 4 : 8; }
+extern "C" int hopmi_reprog_attn_bwd_splits(void) { return attn_dkv_waves() == 4 ? 8 : env_int("HOPMI_ATTN_DKV_SPLITS", 2) > 0 ? env_int("HOPMI_ATTN_DKV_SPLITS", 2) : 2; }
 
 static int attn_np(int N) { return (N + 31) / 32 * 32; }
 extern "C" size_t hopmi_reprog_attn_bwd_ws_bytes(int N, int S, int H, int E) {
@@ -668,9 +674,21 @@ static int launch_reprog_attn_bwd(const void* q_, const void* k_, const void* v_
                      lse, delta, dq, N, S, Sp, H, scale, thresh, dscale, seed, seed_dev);
   if (int e = check_launch("hopmi_reprog_attn_bwd(dq)")) return e;
   const int nsplit = hopmi_reprog_attn_bwd_splits();
-  const size_t lds_kv = (size_t)2 * 2 * 32 * 256 + 2 * 2 * 128 * 64 + 4 * 2 * 2 * 16 * 64;
-  hipLaunchKernelGGL(reprog_attn_bwd_dkv_kernel<TIO>, dim3(((S + KVK - 1) / KVK) * H * nsplit), dim3(256), lds_kv, st, k, v, qnat, qtr,
-                     dnat, dtr, lse, delta, dk, dv, N, Np, S, H, nsplit, thresh, dscale, seed, seed_dev);
+  if (attn_dkv_waves() == 8) {
+    const size_t lds_kv = (size_t)2 * 2 * 32 * 256 + 2 * 2 * 128 * 64 + 8 * 2 * 2 * 16 * 64;        // 96 KB: one workgroup per CU
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&reprog_attn_bwd_dkv_kernel<TIO, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_kv) != hipSuccess) (void)hipGetLastError();
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((reprog_attn_bwd_dkv_kernel<TIO, 8>), dim3(((S + 127) / 128) * H * nsplit), dim3(512), lds_kv, st, k, v, qnat, qtr,
+                       dnat, dtr, lse, delta, dk, dv, N, Np, S, H, nsplit, thresh, dscale, seed, seed_dev);
+  } else {
+    const size_t lds_kv = (size_t)2 * 2 * 32 * 256 + 2 * 2 * 128 * 64 + 4 * 2 * 2 * 16 * 64;
+    hipLaunchKernelGGL((reprog_attn_bwd_dkv_kernel<TIO, 4>), dim3(((S + 63) / 64) * H * nsplit), dim3(256), lds_kv, st, k, v, qnat, qtr,
+                       dnat, dtr, lse, delta, dk, dv, N, Np, S, H, nsplit, thresh, dscale, seed, seed_dev);
+  }
   return check_launch("hopmi_reprog_attn_bwd(dkv)");
 }
 

@@ -262,7 +262,7 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch, order):
         # phase 2: the replays after the first unshard() sharded the copies again, and both later consumers noticed
         assert row["resharded"] and row["stale_before_short_batch"] > 1e-4 and row["short_was_eager"], row
         assert row["replica_spread2"] <= 1e-6, row["replica_spread2"]
-        assert row["worst2_max"] <= 9e-3 and row["worst2_mean"] <= 4e-5, {k: row[k] for k in ("worst2_max", "worst2_mean")}
+        assert row["worst2_max"] <= 9e-3 and row["worst2_mean"] <= 1e-4, {k: row[k] for k in ("worst2_max", "worst2_mean")}   # (7 more steps, one of them at batch 1)
 
 
 # ----------------------------------------------------------------- the recorded step at the sizes bench.py times
