@@ -33,6 +33,7 @@
 #include <utility>
 #include <vector>
 
+#include "attn_dev.h"
 #include "bf16_dev.h"
 #include "io_dev.h"
 #include "wn_dev.h"
@@ -53,7 +54,8 @@ struct StackLayer {
   const float* gamma; const float* beta;
   float* rmean; float* rvar;       // running statistics (updated in place) or null
   int T_in, T_out, d, n_slabs, S, ntiles;
-  float invT;
+  float invT, unbias;    // 1 / T_out;  n / (n - 1)
+  double inv_n;          // 1 / (rows of the layer's output: B T_out V)
 };
 
 struct StackArgs {
@@ -130,9 +132,10 @@ __device__ __forceinline__ bool stk_expired(unsigned long long t0, int* status) 
 
 // N granules per lane, re-read until every tag matches (R2: the data is the flag); v[k] = the value bits.  Bounded.
 template <int N>
-__device__ __forceinline__ bool stk_sweep(const u64* const (&p)[N], unsigned tag, unsigned (&v)[N], int* status) {
+__device__ __forceinline__ bool stk_sweep(const u64* const (&p)[N], unsigned tag, unsigned (&v)[N], int* status, int* passes = nullptr) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
+    if (passes != nullptr) ++*passes;                 // (diagnostic builds only)
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -250,6 +253,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
   float* AT = reinterpret_cast<float*>(Hl + rows_lds * HS);
   float* SCSH = AT + A.KP * A.ldA;                                 // [128] scale | shift of the layer being read
   int* FLAG = reinterpret_cast<int*>(SCSH + 2 * C);                // [4]
+  float* GB = reinterpret_cast<float*>(FLAG + 4);                  // [n_layers][128] gamma | beta of every layer (read once: the
+                                                                   // finalisation sits on the critical path of every exchange)
   // exchange scratch, aliased onto the (dead between layers) operand images Hh | Hl: 2 x rows_lds x 416 B >= 16.6 KB at MT = 1
   float* RED = reinterpret_cast<float*>(Hh);                       // [2][128] floats
   double* COMB = reinterpret_cast<double*>(RED + 4 * C);           // [4][128] doubles
@@ -268,6 +273,10 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 
   // identity scale / shift for layer 0
   if (tid < 2 * C) SCSH[tid] = tid < C ? 1.f : 0.f;
+  for (int idx = tid; idx < A.n_layers * 2 * C; idx += STK_THREADS) {
+    const int l = idx / (2 * C), c = idx % (2 * C);
+    GB[idx] = c < C ? A.L[l].gamma[c] : A.L[l].beta[c - C];
+  }
   if (tid == 0) { FLAG[0] = FLAG[1] = FLAG[2] = 0; FLAG[3] = *reinterpret_cast<volatile int*>(A.sync); }   // [3]: launch sequence number
   // u rows this workgroup never writes (tiles smaller than MT, the 4 padding rows) are read by the node mix's K padding times
   // zero: they must be finite
@@ -377,6 +386,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       const float4 sc4 = reinterpret_cast<const float4*>(SCSH)[c4];
       const float4 sh4 = reinterpret_cast<const float4*>(SCSH + C)[c4];
       __syncthreads();                               // previous tile's LDS fully consumed
+      STK_STAMP(layer, 12);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int row = (tid >> 4) + (STK_THREADS / 16) * it;
@@ -396,8 +406,13 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       // the TCN weight fragments (L2-resident image, 128 KiB per workgroup through the CU's 64 B/clk vector-memory path: ~2 000
       // cycles).  Requested only here: in front of the commit the waves sit in the issue of these loads instead of committing,
       // and in front of the exchange's sweeps every sweep pass would wait for them (a load's data waits for every older one)
+      STK_STAMP(layer, 13);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef STK_EXP_NO_WT
+      if (layer == 0) load_wt(layer);                // (timing experiment: results wrong)
+#else
       load_wt(layer);
+#endif
       __syncthreads();
       STK_STAMP(layer, 1);
 
@@ -440,7 +455,11 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef STK_EXP_NO_WT
+        if (layer == 0) load_wm(layer);
+#else
         load_wm(layer);                              // (behind the gate for the same reason) lands behind the node-mix phase
+#endif
       }
       __syncthreads();
       STK_STAMP(layer, 3);
@@ -495,14 +514,11 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
     STK_STAMP(layer, 6);
 
     // ---- exchange -------------------------------------------------------------------------------------------------------
-    // this workgroup's partial row: 16 rows j of a DPP row (xor 1, 2, 4, 8), then the two row halves, fixed order
+    // this workgroup's partial row: the 16 rows j of a DPP row, then the two row halves, fixed order
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        st1[r] += __shfl_xor(st1[r], o);
-        st2[r] += __shfl_xor(st2[r], o);
-      }
+    for (int r = 0; r < 4; ++r) {                    // (DPP row sums on the VALU: no ds_bpermute round trips)
+      st1[r] = row16_sum(st1[r]);
+      st2[r] = row16_sum(st2[r]);
     }
     __syncthreads();                                 // the images are dead: RED / COMB / FIN alias them
     if (j == 0) {
@@ -583,29 +599,64 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       load_consts(N);
     }
     STK_STAMP(layer, 9);
+#ifdef STK_EXP_XLAT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (timing experiment: how long the next tile's panels take to arrive)
+    STK_STAMP(layer, 15);
+#endif
     {
-      // the <= 8 group sums (hi + lo), added in index order: every workgroup computes the same statistics
-      const int g = tid >> 6, i4 = tid & 63;                       // 4 granules per lane: values 2 i4, 2 i4 + 1
-      const u64* p[4];
-      unsigned v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) p[k] = g < n_groups ? A.ggran + ((size_t)layer * STK_GROUPS + g) * 4 * C + 4 * i4 + k : nullptr;
-      alive = stk_sweep<4>(p, tag, v, status) && alive;
-      FIN[g * 2 * C + 2 * i4] = g < n_groups ? (double)__uint_as_float(v[0]) + (double)__uint_as_float(v[1]) : 0.0;
-      FIN[g * 2 * C + 2 * i4 + 1] = g < n_groups ? (double)__uint_as_float(v[2]) + (double)__uint_as_float(v[3]) : 0.0;
+      // the <= 8 group sums (hi + lo), added in index order: every workgroup computes the same statistics.  Two 16-byte loads
+      // per lane (two granules each), each wave instruction one contiguous KiB of a group's 2 KiB
+      const int g = tid >> 6;                                      // wave = group
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      const auto gr = stk_rsrc(A.ggran + ((size_t)layer * STK_GROUPS + (g < n_groups ? g : 0)) * 4 * C, 4 * C * 8);
+      u32x4 v0, v1;
+#ifdef HOPMI_STAMPS
+      int npass = 0;
+#endif
+      for (;;) {
+        v0 = __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, 0, AUX_SC1);          // granules 2 lane, 2 lane + 1
+        v1 = __builtin_amdgcn_raw_buffer_load_b128(gr, 1024 + lane * 16, 0, AUX_SC1);   // granules 128 + 2 lane, ...
+#ifdef HOPMI_STAMPS
+        ++npass;
+#endif
+        const bool okk = g >= n_groups || (v0[1] == tag && v0[3] == tag && v1[1] == tag && v1[3] == tag);   // (value, tag) pairs
+        if (okk) break;
+        if (stk_expired(t0, status)) { alive = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#ifdef HOPMI_STAMPS
+      if (g_stk_stamps && threadIdx.x == 0) g_stk_stamps[(blockIdx.x * STK_MAX_LAYERS + layer) * 16 + 11] = npass;
+#endif
+      STK_STAMP(layer, 14);
+      float* FINF = reinterpret_cast<float*>(FIN);                   // [8 groups][256] floats: value v = (hi, lo) at 2 v, 2 v + 1
+      {
+        const bool live = g < n_groups;
+        float* f = FINF + g * 4 * C;
+        *reinterpret_cast<float2*>(f + 2 * lane) = live ? make_float2(__uint_as_float(v0[0]), __uint_as_float(v0[2])) : make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(f + 2 * C + 2 * lane) = live ? make_float2(__uint_as_float(v1[0]), __uint_as_float(v1[2])) : make_float2(0.f, 0.f);
+      }
       if (!alive) FLAG[1] = 1;                       // (benign race: every writer writes 1)
       __syncthreads();
+      STK_STAMP(layer, 15);
       if (tid < C) {
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < n_groups; ++k) { s1 += FIN[k * 2 * C + tid]; s2 += FIN[k * 2 * C + C + tid]; }
-        const double n = (double)L.n_slabs * V;
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
+        for (int k = 0; k < n_groups; ++k) {
+          const float2 a = *reinterpret_cast<const float2*>(FINF + k * 4 * C + 2 * tid);
+          const float2 b = *reinterpret_cast<const float2*>(FINF + k * 4 * C + 2 * (C + tid));
+          s1 += (double)a.x + (double)a.y;
+          s2 += (double)b.x + (double)b.y;
+        }
+        // mean and variance in double (E[y^2] - mean^2 cancels); everything behind them in float: 1 / sqrt by the hardware
+        // rsq with one Newton step (1e-7 relative)
+        const double mean = s1 * L.inv_n;
+        double var = s2 * L.inv_n - mean * mean;
         if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)A.eps));
-        const float sc = L.gamma[tid] * rstd;
-        const float sh = L.beta[tid] - (float)mean * sc;
-        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        const float varf = (float)var, ve = varf + A.eps;
+        float rstd = __builtin_amdgcn_rsqf(ve);
+        rstd = rstd * (1.5f - 0.5f * ve * rstd * rstd);
+        const float sc = GB[layer * 2 * C + tid] * rstd;
+        const float sh = GB[layer * 2 * C + C + tid] - (float)mean * sc;
+        const float unbiased = varf * L.unbias;
         SCSH[tid] = sc;
         SCSH[C + tid] = sh;
         if (bid == 0) {                              // one writer of the layer's outputs
@@ -615,10 +666,10 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           so[C + tid] = sh;
           mr[tid] = (float)mean;
           mr[C + tid] = rstd;
-          mr[2 * C + tid] = (float)unbiased;
+          mr[2 * C + tid] = unbiased;
           if (L.rmean != nullptr) {
             L.rmean[tid] = (1.f - A.momentum) * L.rmean[tid] + A.momentum * (float)mean;
-            L.rvar[tid] = (1.f - A.momentum) * L.rvar[tid] + A.momentum * (float)unbiased;
+            L.rvar[tid] = (1.f - A.momentum) * L.rvar[tid] + A.momentum * unbiased;
           }
         }
       }
@@ -633,7 +684,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 
 static size_t stk_lds_bytes(int mt, int KP, int ldA) {
   const size_t rows_lds = 16 * mt + 4;
-  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * LDD + (size_t)KP * ldA + 2 * C) * sizeof(float) + 16;
+  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * LDD + (size_t)KP * ldA + 2 * C) * sizeof(float) + 16 +
+         (size_t)STK_MAX_LAYERS * 2 * C * sizeof(float);
 }
 
 struct StackPlan {
@@ -775,6 +827,11 @@ extern "C" int hopmi_wn_stack_fwd_dt(const void* x0, const void* wimg, const flo
     L.T_in = T; L.d = dilations[l]; L.T_out = T - dilations[l];
     L.n_slabs = B * L.T_out; L.S = P.S[l]; L.ntiles = P.ntiles[l];
     L.invT = 1.0f / L.T_out;
+    {
+      const double n = (double)L.n_slabs * V;
+      L.inv_n = 1.0 / n;
+      L.unbias = n > 1.0 ? (float)(n / (n - 1.0)) : 1.0f;
+    }
     T = L.T_out;
   }
   const GcnGeom g = make_geom(1, V, 1);

@@ -30,7 +30,7 @@ SO = os.path.join(ROOT, "tools", "probes", "libhopmi_stamps_stack.so")
 
 def build_stamps():
     src = [os.path.join(PKG, "csrc", f) for f in ("api.hip", "gcn.hip", "wavenet.hip", "wavenet_bwd.hip", "wavenet_stack.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHOPMI_STAMPS",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHOPMI_STAMPS", *(["-DSTK_EXP_XLAT"] if os.environ.get("STK_EXP_XLAT") else []),
                     "-I" + os.path.join(ROOT, "include"), *src, "-o", SO], check=True)
 
 
@@ -42,10 +42,13 @@ def main():
     ap.add_argument("--warm", type=float, default=1.5)
     ap.add_argument("--stamps", action="store_true")
     ap.add_argument("--build-stamps", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative libhopmi.so (timing experiments)")
     a = ap.parse_args()
     if a.build_stamps:
         build_stamps()
         return
+    if a.lib:
+        hopmi._lib._LIB_PATH = os.path.abspath(a.lib)
     if a.stamps:
         hopmi._lib._LIB_PATH = SO
         hopmi._lib.SIGNATURES = {k: v for k, v in hopmi._lib.SIGNATURES.items()
@@ -102,6 +105,13 @@ def main():
             for k in range(6):
                 sgm = r[:, k + 1] - r[:, k]
                 print(f"      {names[k]:56s} median {sgm.median().item():7.0f}  max {sgm.max().item():7.0f}")
+            print(f"      commit detail: start -> first barrier {(r[:, 12] - r[:, 0]).median().item():.0f}; convert + LDS writes {(r[:, 13] - r[:, 12]).median().item():.0f}; "
+                  f"weight-load issue + barrier {(r[:, 1] - r[:, 13]).median().item():.0f}")
+            if layer < 7:
+                print(f"      final detail: sweep (wave 0) {(row[:, 14] - row[:, 9]).median().item():.0f} (max {(row[:, 14] - row[:, 9]).max().item():.0f}); "
+                      f"-> barrier (slowest wave's sweep) {(row[:, 15] - row[:, 14]).median().item():.0f}; statistics + barrier {(row[:, 10] - row[:, 15]).median().item():.0f}")
+            if layer < 7:
+                print(f"      final sweep passes (thread 0): median {row[:, 11].median().item():.0f}  max {row[:, 11].max().item():.0f}")
             for k in range(6, 10 if layer < 7 else 7):
                 sgm = row[:, k + 1] - row[:, k]
                 sgm = sgm[(row[:, k + 1] > 0) & (row[:, k] > 0)]
