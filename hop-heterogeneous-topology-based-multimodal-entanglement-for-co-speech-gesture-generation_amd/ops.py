@@ -481,11 +481,30 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_MM_F32_OUT = None            # torch.mm(bf16, bf16, out_dtype=float32) available on this device?
+
+
+def _mm_f32(a, b):
+    """a @ b for low-precision a, b with the product accumulated AND returned in fp32 (a weight gradient goes into an fp32
+    .grad: no rounding to bf16 in between, no cast launch); falls back to a cast where the library has no such GEMM."""
+    global _MM_F32_OUT
+    if _MM_F32_OUT is None:
+        try:
+            torch.mm(a[:1], b[:, :1], out_dtype=torch.float32)
+            _MM_F32_OUT = True
+        except (RuntimeError, TypeError):
+            _MM_F32_OUT = False
+    return torch.mm(a, b, out_dtype=torch.float32) if _MM_F32_OUT else (a @ b).float()
+
+
 class _LinearFn(torch.autograd.Function):
     """torch.nn.functional.linear whose backward takes the bias gradient with hopmi_colsum (the library's column reduction
     is the slowest piece of a trainable linear layer's backward here).  Under autocast the operands are cast as
     F.linear's autocast rule does and both gradient GEMMs run in that type; the results are handed back in the
-    parameters' types."""
+    parameters' types (the weight gradient straight from the GEMM's fp32 accumulators: no rounding to bf16, no cast launch).
+    (Tried and dropped in round 3: persistent bf16 shadows of the parameters, re-cast in one multi-tensor copy per step -- no
+    measurable gain on the bf16 step, and a cache keyed on storage is wrong for temporaries such as gwnet's concatenated skip
+    weights, whose address the allocator recycles.)"""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -493,11 +512,13 @@ class _LinearFn(torch.autograd.Function):
         xc, wc, bc = x, w, b
         if amp:
             dt = torch.get_autocast_dtype("cuda")
-            xc, wc, bc = x.to(dt), w.to(dt), b.to(dt)
+            xc = x if x.dtype == dt else x.to(dt)
+            wc = w if w.dtype == dt else w.to(dt)
+            bc = b if (b is None or b.dtype == dt) else b.to(dt)
         with torch.autocast("cuda", enabled=False):
             y = torch.nn.functional.linear(xc.reshape(-1, xc.shape[-1]), wc, bc)
         ctx.save_for_backward(xc, wc)
-        ctx.types = (x.dtype, w.dtype, b.dtype)
+        ctx.types = (x.dtype, w.dtype, b.dtype if b is not None else None)
         # (not a tracked view: an in-place activation may follow, e.g. HOP.py:131's LeakyReLU(inplace=True))
         return torch.ops.aten._unsafe_view(y, list(x.shape[:-1]) + [w.shape[0]])
 
@@ -506,10 +527,23 @@ class _LinearFn(torch.autograd.Function):
         xc, wc = ctx.saved_tensors
         tx, tw, tb = ctx.types
         with torch.autocast("cuda", enabled=False):
-            dy2 = dy.reshape(-1, dy.shape[-1]).to(wc.dtype)
-            dx = (dy2 @ wc).view(xc.shape).to(tx) if ctx.needs_input_grad[0] else None
-            dw = (dy2.t() @ xc.reshape(-1, xc.shape[-1])).to(tw) if ctx.needs_input_grad[1] else None
-            db = colsum(dy2).to(tb) if ctx.needs_input_grad[2] else None
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            if dy2.dtype != wc.dtype:
+                dy2 = dy2.to(wc.dtype)
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = (dy2 @ wc).view(xc.shape)
+                dx = dx if dx.dtype == tx else dx.to(tx)
+            if ctx.needs_input_grad[1]:
+                x2 = xc.reshape(-1, xc.shape[-1])
+                if tw == torch.float32 and dy2.dtype != torch.float32:
+                    dw = _mm_f32(dy2.t(), x2)
+                else:
+                    dw = dy2.t() @ x2
+                    dw = dw if dw.dtype == tw else dw.to(tw)
+            if tb is not None and ctx.needs_input_grad[2]:
+                db = colsum(dy2)
+                db = db if db.dtype == tb else db.to(tb)
         return dx, dw, db
 
 

@@ -83,6 +83,40 @@ def test_graphed_step_equals_eager(V, epoch, monkeypatch):
             assert torch.equal(a, b), n
 
 
+def test_graphed_step_bf16_follows_eager(monkeypatch):
+    """The bf16 mode through the recording: the parameters' bf16 shadows are re-cast INSIDE the recording (a replay updates the
+    parameters itself), so five steps of train_llm and of GraphedTrainStep on copies of one model see the same losses (the
+    arithmetic is the same on both sides; what differs is Adam's capturable form)."""
+    import hopmi
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m1, d1, inp = _pair(9, dev)
+    m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
+    m2._randn_like = m1._randn_like
+    mk = lambda m, d: (torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999)),
+                       torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999)))
+    g1, o1 = mk(m1, d1)
+    g2, o2 = mk(m2, d2)
+    args = step_args(9)
+    batch = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"], inp["vid_indices"])
+    prev = hopmi.mixed_precision("bf16")
+    try:
+        graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, eager_calls=1)
+        for it in range(5):
+            want = hopmi.train_llm(args, 11, *batch, m1, d1, g1, o1, Accel())
+            got = graphed(11, *batch)
+            assert sorted(got) == sorted(want), (it, got, want)
+            for k in want:
+                # (bf16 roundings are the same on both sides; Adam's +-lr noise on rounding-level gradients is not, and bf16
+                # forwards amplify it ~10 x relative to the fp32 test's 2e-4)
+                tol = 4e-3 if k != "DIV_REG" else 8e-2
+                assert abs(got[k] - want[k]) <= tol * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])
+        assert graphed.n_replay == 4
+    finally:
+        hopmi.mixed_precision(prev)
+
+
 def test_graphed_step_new_batches_and_other_shapes(monkeypatch):
     """Replays read the batch from static buffers (a new batch of the recorded shape is copied in), another batch size
     falls back to the eager step, and both keep training the same model."""
