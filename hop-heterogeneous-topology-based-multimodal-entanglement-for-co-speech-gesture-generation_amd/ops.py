@@ -488,6 +488,9 @@ def _mm_f32(a, b):
     """a @ b for low-precision a, b with the product accumulated AND returned in fp32 (a weight gradient goes into an fp32
     .grad: no rounding to bf16 in between, no cast launch); falls back to a cast where the library has no such GEMM."""
     global _MM_F32_OUT
+    if _MM_F32_OUT is None and __import__("os").environ.get("HOPMI_MM_F32", "0") != "1":
+        _MM_F32_OUT = False       # default: bf16-out GEMM + cast (measured 0.9 % faster on the bf16 step: the library's fp32-out
+                                  # kernels for these shapes are not in the tuned table); HOPMI_MM_F32=1 for the unrounded gradient
     if _MM_F32_OUT is None:
         try:
             torch.mm(a[:1], b[:, :1], out_dtype=torch.float32)
@@ -501,7 +504,8 @@ class _LinearFn(torch.autograd.Function):
     """torch.nn.functional.linear whose backward takes the bias gradient with hopmi_colsum (the library's column reduction
     is the slowest piece of a trainable linear layer's backward here).  Under autocast the operands are cast as
     F.linear's autocast rule does and both gradient GEMMs run in that type; the results are handed back in the
-    parameters' types (the weight gradient straight from the GEMM's fp32 accumulators: no rounding to bf16, no cast launch).
+    parameters' types (HOPMI_MM_F32=1: the weight gradient straight from the GEMM's fp32 accumulators, no rounding to bf16 and
+    no cast launch -- 0.9 % slower on the bf16 step with the library's default kernel selection, so not the default).
     (Tried and dropped in round 3: persistent bf16 shadows of the parameters, re-cast in one multi-tensor copy per step -- no
     measurable gain on the bf16 step, and a cache keyed on storage is wrong for temporaries such as gwnet's concatenated skip
     weights, whose address the allocator recycles.)"""

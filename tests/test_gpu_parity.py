@@ -341,9 +341,26 @@ def test_linear_with_colsum_bias_gradient_equals_functional_linear(amp):
         (y.float() * g).sum().backward()
         res.append((y.detach(), x.grad, w.grad, b.grad))
     assert res[0][0].dtype == res[1][0].dtype == (torch.bfloat16 if amp else torch.float32)
-    for i in range(2 if amp else 3):
+    for i in range(3):
         assert torch.equal(res[0][i], res[1][i]), i
     if amp:
+        # optional form (HOPMI_MM_F32=1): the same gradient from the GEMM's fp32 accumulators
+        prev, ops._MM_F32_OUT = ops._MM_F32_OUT, None
+        monkey_env = __import__("os").environ
+        old_env = monkey_env.get("HOPMI_MM_F32")
+        monkey_env["HOPMI_MM_F32"] = "1"
+        try:
+            x, w, b = (t.to(dev).requires_grad_() for t in (x0, w0, b0))
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = ops.linear(x, w, b)
+            (y.float() * g).sum().backward()
+            res[1] = (y.detach(), x.grad, w.grad, b.grad)
+        finally:
+            ops._MM_F32_OUT = prev
+            if old_env is None:
+                monkey_env.pop("HOPMI_MM_F32", None)
+            else:
+                monkey_env["HOPMI_MM_F32"] = old_env
         # the weight gradient comes straight from the GEMM's fp32 accumulators (F.linear's autograd rounds it to bf16 and casts
         # it back): within bf16 rounding of F.linear's, and at least as close to the float64 product
         want = (g.bfloat16().double().reshape(-1, 2100).t() @ x0.to(dev).bfloat16().double().reshape(-1, 700)).float()
