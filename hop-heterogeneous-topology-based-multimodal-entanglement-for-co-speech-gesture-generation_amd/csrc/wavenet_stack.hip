@@ -70,7 +70,7 @@ struct StackArgs {
   u64* ggran;            // [n_layers][STK_GROUPS][256]  group sums, granules (hi, lo) per value
   unsigned* yflag;       // [n_layers][max_tiles]        "the y rows of this tile have left the workgroup" (= tag)
   int max_tiles;
-  int n_layers, B, V, utail_ld4;
+  int n_layers, B, V, utail_ld4, n_comb;
   int KP, ldA, MP;       // mix-matrix image geometry (GcnGeom)
   float invV, momentum, eps;
 };
@@ -264,11 +264,13 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), w = wv & 3, h = wv >> 2;
   int lane = tid & 63, q = lane >> 4, j = lane & 15, c4 = tid & 15;
   const int V = A.V;
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int grp = bid & (STK_GROUPS - 1);
-  const int n_groups = G < STK_GROUPS ? G : STK_GROUPS;
-  const int gsz = (G - grp + STK_GROUPS - 1) / STK_GROUPS;         // workgroups b = grp + 8 m, m < gsz
-  const bool combiner = bid < n_groups;                            // the first workgroup of its group adds the group's rows
+  // roles: the first G workgroups compute tiles, the last n_groups are DEDICATED combiners (one per group: they have no tile,
+  // so they sweep their group's granules from the moment the layer starts and publish the group sum as soon as the slowest
+  // member's row is visible -- a computing combiner reached its sweep ~5 000 cycles after its own tile)
+  const int n_groups = A.n_comb, G = gridDim.x - n_groups, bid = blockIdx.x;
+  const bool combiner = bid >= G;
+  const int grp = combiner ? bid - G : bid % n_groups;
+  const int gsz = (G - grp + n_groups - 1) / n_groups;             // computing workgroups b = grp + n_groups m, m < gsz
   int* status = A.sync + STK_STATUS_AT;
 
   // identity scale / shift for layer 0
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
     bg4 = *reinterpret_cast<const float4*>(L.bg + 16 * w + 4 * q);
     bias4 = *reinterpret_cast<const float4*>(L.bm + 16 * w + 4 * q);
   };
-  if (bid < A.L[0].ntiles) issue_tile(A.L[0], bid);
+  if (!combiner && bid < A.L[0].ntiles) issue_tile(A.L[0], bid);
   load_consts(A.L[0]);
   {
     // touch every layer's descriptor now (first, middle and last word: all its cache lines): the scalar loads of a layer's
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
     TS* utail = static_cast<TS*>(A.utail) + C * layer;
 
     // the first tile's tap panels are in flight since the previous layer's exchange
-    for (int tile = bid; tile < L.ntiles; tile += G) {
+    for (int tile = combiner ? L.ntiles : bid; tile < L.ntiles; tile += G) {
       asm volatile("" : "+v"(tid));                  // keep per-lane address math from being hoisted out of the loops
       lane = tid & 63; q = lane >> 4; j = lane & 15; c4 = tid & 15;
       const int slab0 = tile * L.S;
@@ -514,13 +516,45 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
     STK_STAMP(layer, 6);
 
     // ---- exchange -------------------------------------------------------------------------------------------------------
+    bool alive = true;
+    if (combiner) {
+      // the group's rows, added in index order (members b = grp + n_groups m): slice = m mod 4 per thread, then the 4 slices
+      const int col = tid & (2 * C - 1), slice = tid >> 7;
+      double acc = 0.0;
+      for (int m0 = slice; m0 < gsz && alive; m0 += 32) {
+        const u64* p[8];
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int m = m0 + 4 * u;
+          p[u] = m < gsz ? A.pgran + ((size_t)layer * G + grp + n_groups * m) * 2 * C + col : nullptr;
+        }
+        alive = stk_sweep<8>(p, tag, v, status);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (m0 + 4 * u < gsz) ? (double)__uint_as_float(v[u]) : 0.0;
+      }
+      __syncthreads();                               // (COMB may still be read by the previous layer's publication)
+      COMB[slice * 2 * C + col] = acc;
+      __syncthreads();
+      if (tid < 2 * C) {
+        const double t = ((COMB[tid] + COMB[2 * C + tid]) + COMB[4 * C + tid]) + COMB[6 * C + tid];
+        const float hi = (float)t, lo = (float)(t - (double)hi);
+        u64* g = A.ggran + ((size_t)layer * STK_GROUPS + grp) * 4 * C + 2 * tid;
+        __hip_atomic_store(g, ((u64)tag << 32) | __float_as_uint(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, ((u64)tag << 32) | __float_as_uint(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      STK_STAMP(layer, 8);
+      if (!alive) return;                            // (status raised)
+      continue;                                      // a combiner needs no statistics: on to the next layer's rows
+    }
     // this workgroup's partial row: the 16 rows j of a DPP row, then the two row halves, fixed order
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                    // (DPP row sums on the VALU: no ds_bpermute round trips)
       st1[r] = row16_sum(st1[r]);
       st2[r] = row16_sum(st2[r]);
     }
-    __syncthreads();                                 // the images are dead: RED / COMB / FIN alias them
+    __syncthreads();                                 // the images are dead: RED / FIN alias them
+    if (tid == 64) FLAG[0] = 0;                      // (wave 1's lane 0, which raises it below; every wave has left the previous wait loop)
     if (j == 0) {
       *reinterpret_cast<f32x4*>(RED + h * 2 * C + 16 * w + 4 * q) = st1;
       *reinterpret_cast<f32x4*>(RED + h * 2 * C + C + 16 * w + 4 * q) = st2;
@@ -532,50 +566,32 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
                          __HIP_MEMORY_SCOPE_AGENT);
     }
     STK_STAMP(layer, 7);
+    if (last_layer && bid != 0) break;               // nobody waits for the last layer's statistics: workgroup 0 finalises them
     if (!last_layer) {
-      // y of this layer: drained by every storing wave, then the tiles' flags (ONE lane).  (The drain also covers the granule
-      // stores above; a combiner loses nothing by it: its members' granules need the same time to become visible.)
+      // y of this layer: drained by every storing wave, then the tiles' flags (ONE lane)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0)
         for (int tile = bid; tile < L.ntiles; tile += G)
           __hip_atomic_store(A.yflag + (size_t)layer * A.max_tiles + tile, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    bool alive = true;
-    if (combiner) {
-      // the group's rows, added in index order (members b = grp + 8 m): slice = m mod 4 per thread, then the 4 slices
-      const int col = tid & (2 * C - 1), slice = tid >> 7;
-      double acc = 0.0;
-      for (int m0 = slice; m0 < gsz && alive; m0 += 32) {
-        const u64* p[8];
-        unsigned v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int m = m0 + 4 * u;
-          p[u] = m < gsz ? A.pgran + ((size_t)layer * G + grp + STK_GROUPS * m) * 2 * C + col : nullptr;
-        }
-        alive = stk_sweep<8>(p, tag, v, status);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (m0 + 4 * u < gsz) ? (double)__uint_as_float(v[u]) : 0.0;
-      }
-      COMB[slice * 2 * C + col] = acc;
-      __syncthreads();
-      if (tid < 2 * C) {
-        const double t = ((COMB[tid] + COMB[2 * C + tid]) + COMB[4 * C + tid]) + COMB[6 * C + tid];
-        const float hi = (float)t, lo = (float)(t - (double)hi);
-        u64* g = A.ggran + ((size_t)layer * STK_GROUPS + grp) * 4 * C + 2 * tid;
-        __hip_atomic_store(g, ((u64)tag << 32) | __float_as_uint(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g + 1, ((u64)tag << 32) | __float_as_uint(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
     STK_STAMP(layer, 8);
-    if (last_layer && bid != 0) break;               // nobody waits for the last layer's statistics: workgroup 0 finalises them
-    if (!last_layer) {
-      // the tiles that produced the rows this workgroup reads next (all of its tiles of layer + 1): neighbours, they drained at
-      // the same time.  Then the first tile's loads go out: they arrive while the statistics are still on their way.
-      const StackLayer& N = A.L[layer + 1];
-      if (wv == 1) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    // the <= 8 group sums (hi + lo): two 16-byte loads per lane (two granules each), each wave instruction one contiguous KiB of a
+    // group's 2 KiB, wave = group.  The first pass goes out NOW, in front of the neighbour-flag wait and of the next tile's loads
+    // (a wave's loads return in order: behind them every pass would wait for the tile's 48 KB first)
+    const int g = tid >> 6;
+    const auto gr = stk_rsrc(A.ggran + ((size_t)layer * STK_GROUPS + (g < n_groups ? g : 0)) * 4 * C, 4 * C * 8);
+    u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, 0, AUX_SC1);            // granules 2 lane, 2 lane + 1
+    u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(gr, 1024 + lane * 16, 0, AUX_SC1);     // granules 128 + 2 lane, ...
+    {
+      // Two things have to happen before the layer can start, in whatever order they become possible: (a) the next tile's loads go
+      // out as soon as the tiles that produced its rows have drained (neighbours: they drained when this workgroup did) -- wave 1
+      // polls their flags and raises FLAG[0] in LDS, every wave issues its share when it sees it; (b) the group sums arrive --
+      // every wave keeps sweeping its group's KiBs meanwhile.  No barrier between the two: a wave leaves when it has done both.
+      const StackLayer& N = A.L[last_layer ? layer : layer + 1];
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      volatile int* nb = FLAG;                       // [0]: 0 = waiting, 1 = neighbours drained, -1 = time-out
+      if (!last_layer && wv == 1) {
         bool good = true;
         for (int tile = bid; tile < N.ntiles && good; tile += G) {
           const int s_lo = tile * N.S, s_hi = min(s_lo + N.S, N.n_slabs) - 1;
@@ -591,39 +607,38 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
             good = __all(good);
           }
         }
-        if (lane == 0) FLAG[0] = good ? 1 : 0;
+        if (lane == 0) nb[0] = good ? 1 : -1;
       }
-      __syncthreads();
-      if (!FLAG[0]) return;                          // time-out (status raised): every other workgroup times out as well
-      if (bid < N.ntiles) issue_tile(N, bid);
-      load_consts(N);
-    }
-    STK_STAMP(layer, 9);
-#ifdef STK_EXP_XLAT
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (timing experiment: how long the next tile's panels take to arrive)
-    STK_STAMP(layer, 15);
-#endif
-    {
-      // the <= 8 group sums (hi + lo), added in index order: every workgroup computes the same statistics.  Two 16-byte loads
-      // per lane (two granules each), each wave instruction one contiguous KiB of a group's 2 KiB
-      const int g = tid >> 6;                                      // wave = group
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      const auto gr = stk_rsrc(A.ggran + ((size_t)layer * STK_GROUPS + (g < n_groups ? g : 0)) * 4 * C, 4 * C * 8);
-      u32x4 v0, v1;
+      bool swept = false, xdone = last_layer;
 #ifdef HOPMI_STAMPS
-      int npass = 0;
+      int npass = 1;
 #endif
       for (;;) {
-        v0 = __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, 0, AUX_SC1);          // granules 2 lane, 2 lane + 1
-        v1 = __builtin_amdgcn_raw_buffer_load_b128(gr, 1024 + lane * 16, 0, AUX_SC1);   // granules 128 + 2 lane, ...
-#ifdef HOPMI_STAMPS
-        ++npass;
-#endif
-        const bool okk = g >= n_groups || (v0[1] == tag && v0[3] == tag && v1[1] == tag && v1[3] == tag);   // (value, tag) pairs
-        if (okk) break;
+        if (!swept) {
+          swept = g >= n_groups || (v0[1] == tag && v0[3] == tag && v1[1] == tag && v1[3] == tag);          // (value, tag) pairs
+          swept = __all(swept);
+        }
+        if (!xdone) {
+          const int f = nb[0];
+          if (f < 0) { alive = false; break; }
+          if (f > 0) {
+            if (bid < N.ntiles) issue_tile(N, bid);
+            load_consts(N);
+            xdone = true;
+          }
+        }
+        if (swept && xdone) break;
         if (stk_expired(t0, status)) { alive = false; break; }
         __builtin_amdgcn_s_sleep(1);
+        if (!swept) {
+          v0 = __builtin_amdgcn_raw_buffer_load_b128(gr, lane * 16, 0, AUX_SC1);
+          v1 = __builtin_amdgcn_raw_buffer_load_b128(gr, 1024 + lane * 16, 0, AUX_SC1);
+#ifdef HOPMI_STAMPS
+          ++npass;
+#endif
+        }
       }
+      STK_STAMP(layer, 9);
 #ifdef HOPMI_STAMPS
       if (g_stk_stamps && threadIdx.x == 0) g_stk_stamps[(blockIdx.x * STK_MAX_LAYERS + layer) * 16 + 11] = npass;
 #endif
@@ -689,7 +704,7 @@ static size_t stk_lds_bytes(int mt, int KP, int ldA) {
 }
 
 struct StackPlan {
-  int mt_max, grid, n_cu, tiles_max;
+  int mt_max, grid, n_comb, n_cu, tiles_max;     // grid = computing workgroups; + n_comb dedicated combiners
   size_t lds;
   int S[STK_MAX_LAYERS], ntiles[STK_MAX_LAYERS], mt[STK_MAX_LAYERS];
 };
@@ -721,7 +736,9 @@ static int stk_plan_build(int B, int T_in, int V, const int* dil, int n_layers, 
     set_error("hopmi_wn_stack: no device");
     return HOPMI_EINVAL;
   }
-  const int target = wn_env_int("HOPMI_WN_GRID", n_cu) < n_cu ? wn_env_int("HOPMI_WN_GRID", n_cu) : n_cu;
+  // STK_GROUPS CUs are kept for the dedicated combiner workgroups
+  const int avail = n_cu > 2 * STK_GROUPS ? n_cu - STK_GROUPS : (n_cu > 1 ? n_cu - 1 : 1);
+  const int target = wn_env_int("HOPMI_WN_GRID", avail) < avail ? wn_env_int("HOPMI_WN_GRID", avail) : avail;
   int T = T_in, mt_max = 1, tiles_max = 1;
   for (int l = 0; l < n_layers; ++l) {
     if (int e = wn_validate(B, T, V, dil[l])) return e;
@@ -749,9 +766,9 @@ static int stk_plan_build(int B, int T_in, int V, const int* dil, int n_layers, 
   }
   // one workgroup per CU even where two would fit: the per-layer tiles are sized for n_cu workgroups, and a margin of
   // residency is worth more than the second workgroup (MI355X_MICROARCH.md: the query can read one high)
-  const int resident = n_cu;
   P->grid = tiles_max < target ? tiles_max : target;
-  if (P->grid > resident) P->grid = resident;
+  P->n_comb = P->grid < STK_GROUPS ? P->grid : STK_GROUPS;
+  if (P->grid + P->n_comb > n_cu) { set_error("hopmi_wn_stack: %d workgroups do not fit %d CUs", P->grid + P->n_comb, n_cu); return HOPMI_EINVAL; }
   return HOPMI_OK;
 }
 
@@ -788,7 +805,7 @@ extern "C" int hopmi_debug_set_stamps_stack(long long* p) {
 extern "C" int hopmi_wn_stack_grid(int B, int T_in, int V, const int* dilations, int n_layers) {
   StackPlan P;
   if (stk_plan(B, T_in, V, dilations, n_layers, HOPMI_F32, &P)) return 0;
-  return P.grid;
+  return P.grid + P.n_comb;
 }
 
 extern "C" size_t hopmi_wn_stack_ws_bytes(int B, int T_in, int V, const int* dilations, int n_layers) {
@@ -845,7 +862,7 @@ extern "C" int hopmi_wn_stack_fwd_dt(const void* x0, const void* wimg, const flo
   A.ggran = A.pgran + (size_t)n_layers * P.grid * 2 * C;
   A.yflag = reinterpret_cast<unsigned*>(A.ggran + (size_t)n_layers * STK_GROUPS * 4 * C);
   A.max_tiles = P.tiles_max;
-  A.n_layers = n_layers; A.B = B; A.V = V; A.utail_ld4 = utail_ld / 4;
+  A.n_layers = n_layers; A.B = B; A.V = V; A.utail_ld4 = utail_ld / 4; A.n_comb = P.n_comb;
   A.KP = g.KP; A.ldA = g.ldA; A.MP = g.MP;
   A.invV = 1.0f / V; A.momentum = momentum; A.eps = eps;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -855,8 +872,8 @@ extern "C" int hopmi_wn_stack_fwd_dt(const void* x0, const void* wimg, const flo
   switch (P.mt_max) {
 #define HOPMI_STK_CASE(MT_)                                                                                                          \
     case MT_:                                                                                                                        \
-      if (bf16) hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_, __bf16>), dim3(P.grid), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A);   \
-      else hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_, float>), dim3(P.grid), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A);       \
+      if (bf16) hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_, __bf16>), dim3(P.grid + P.n_comb), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A);   \
+      else hipExtLaunchKernelGGL((wn_stack_fwd_kernel<MT_, float>), dim3(P.grid + P.n_comb), dim3(STK_THREADS), P.lds, st, e0, e1, 0, A);       \
       break;
     HOPMI_STK_CASE(1) HOPMI_STK_CASE(2) HOPMI_STK_CASE(3) HOPMI_STK_CASE(4) HOPMI_STK_CASE(5)
 #undef HOPMI_STK_CASE
