@@ -71,6 +71,7 @@ SIGNATURES = {
     "hopmi_gemm_split_prepare": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hopmi_gemm_split": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gemm_split_ab": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "hopmi_gemm_split_ep": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "hopmi_gru_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_gru_fwd": (_I, [_VP] * 6 + [_I, _I, _I, _VP]),
     "hopmi_gru_fwd_dt": (_I, [_VP, _I] + [_VP] * 5 + [_I, _I, _I, _VP]),

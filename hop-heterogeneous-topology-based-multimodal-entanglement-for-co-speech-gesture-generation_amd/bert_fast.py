@@ -14,6 +14,8 @@ Dropout follows the module's train/eval state with the config's probabilities (t
 train mode).  If the module is not BERT-shaped (the reference also supports LLaMA, run_ted.py:133-175) `supports()`
 is False and the caller invokes the module itself.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -22,6 +24,8 @@ from . import ops
 
 # under bf16 autocast: the bf16-storage operators between the GEMMs (False: the fp32-storage operators + autocast's casts)
 BF16_STORAGE = True
+# the activation of BertIntermediate and its gradient as epilogues of the split GEMMs around them (False: launches of their own)
+FUSED_FFN = os.environ.get("HOPMI_FUSED_FFN", "1") != "0"
 # rows (tokens) from which the frozen linears go through hopmi_gemm_split
 SPLIT_MIN_ROWS = 1024
 
@@ -64,20 +68,38 @@ class FrozenBertEncoder:
     def _linear(self, key, x, weight, bias):
         """x W^T (+ bias) for one of the module's frozen linears: the library's fp32 GEMM, or -- ops.gemm_parts(2 | 3) --
         hopmi_gemm_split on images of W and W^T that are built once per weight version."""
+        imgs = self._images(key, x, weight)
+        if imgs is None:
+            return F.linear(x, weight, bias)
+        N, K = weight.shape
+        return ops.split_linear(x, imgs[0], imgs[1], bias, N, K, ops.GEMM_PARTS)
+
+    def _images(self, key, x, weight):
+        """Part images of a frozen weight and of its transpose (built once per weight version), or None where the linear
+        goes to the library instead."""
         parts = ops.GEMM_PARTS
         N, K = weight.shape
         # (below ~1 000 rows -- inference windows, tiny batches -- the 128 x 128 tiles leave the chip empty and the library's
         # small-M kernels win: a 34-row window forward took 2.4 ms with the split GEMMs against 1.7 ms without)
-        if (parts == 0 or torch.is_autocast_enabled() or x.numel() // K < SPLIT_MIN_ROWS or not ops.split_gemm_supported(N, K)
-                or not ops.split_gemm_supported(K, N)):
-            return F.linear(x, weight, bias)
+        if (parts == 0 or torch.is_autocast_enabled() or x.numel() // x.shape[-1] < SPLIT_MIN_ROWS
+                or not ops.split_gemm_supported(N, K) or not ops.split_gemm_supported(K, N)):
+            return None
         ver = (weight._version, weight.data_ptr(), parts)
         hit = self._img.get(key)
         if hit is None or hit[0] != ver:
             with torch.no_grad():
                 hit = (ver, ops.split_weight_image(weight, parts), ops.split_weight_image(weight.t().contiguous(), parts))
             self._img[key] = hit
-        return ops.split_linear(x, hit[1], hit[2], bias, N, K, parts)
+        return hit[1], hit[2]
+
+    def _ffn(self, i, lay, h):
+        """gelu(h W1^T + b1) W2^T of layer i (BertIntermediate + BertOutput.dense without its bias)."""
+        w1, w2 = lay.intermediate.dense.weight, lay.output.dense.weight
+        i1, i2 = self._images((i, "f1"), h, w1), self._images((i, "f2"), h, w2)
+        if FUSED_FFN and i1 is not None and i2 is not None:
+            return ops.split_ffn(h, i1[0], i1[1], lay.intermediate.dense.bias, i2[0], i2[1], w1.shape[0], w1.shape[1], ops.GEMM_PARTS)
+        f = ops.bias_gelu(self._linear((i, "f1"), h, w1, None), lay.intermediate.dense.bias)
+        return self._linear((i, "f2"), f, w2, None)
 
     def _bf16(self, key, weight, bias=None):
         """bf16 copies of a frozen weight (and bias), made once per weight version: under autocast the library would
@@ -157,8 +179,7 @@ class FrozenBertEncoder:
             # meet inside the backward kernel instead of in an add launch of their own)
             h, hr = ops.bias_dropout_residual_layernorm2(o, att.output.dense.bias, hr, att.output.LayerNorm.weight,
                                                          att.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
-            f = ops.bias_gelu(self._linear((i, "f1"), h, lay.intermediate.dense.weight, None), lay.intermediate.dense.bias)
-            o = self._linear((i, "f2"), f, lay.output.dense.weight, None)
+            o = self._ffn(i, lay, h)
             h, hr = ops.bias_dropout_residual_layernorm2(o, lay.output.dense.bias, hr, lay.output.LayerNorm.weight,
                                                          lay.output.LayerNorm.bias, cfg.layer_norm_eps, p_h, self._seed())
         return h

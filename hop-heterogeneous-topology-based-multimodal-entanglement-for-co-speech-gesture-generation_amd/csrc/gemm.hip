@@ -68,11 +68,26 @@ __global__ __launch_bounds__(256) void gemm_split_prepare_kernel(const float* __
 
 constexpr int GT = 512;                            // threads: 8 waves as 2 (M) x 4 (N)
 
+// Epilogue forms (hopmi_gemm_split_ep): the BertIntermediate activation and its derivative ride on the product that feeds /
+// follows them instead of a launch of their own that re-reads and re-writes the M x 3072 tensor.  The same expressions as
+// elementwise.hip's bias_gelu kernels on the same fp32 values: bit-identical to GEMM + hopmi_bias_gelu_fwd / _bwd.
+//   EP_BIAS       C = acc + bias
+//   EP_GELU       h = acc + bias;  C = gelu_erf(h);  C2 = h when asked for (the backward's operand)
+//   EP_GELU_GRAD  C = (acc + bias) * gelu_erf'(aux)            (aux = the h of the forward, same shape as C)
+enum { EP_BIAS = 0, EP_GELU = 1, EP_GELU_GRAD = 2 };
+__device__ __forceinline__ float gemm_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gemm_gelu_grad(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
 // BM = 64 halves the tile (8 waves of 32 x 32) for shapes whose 128-row tiling leaves CUs idle or quantises badly.
 template <int NP, bool DB, int BM>
 __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bimg,
                                                          const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
-                                                         int tiles_m, int tiles_n) {
+                                                         int tiles_m, int tiles_n, int ep, float* __restrict__ C2,
+                                                         const float* __restrict__ aux) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // [buffer 2][A: part NP x BM rows | B: part NP x 128 rows][GLD]
   __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
@@ -215,13 +230,22 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + (BM / 2) * wr + 16 * mi + 4 * q + r;
-        if (row < M) C[(size_t)row * N + col] = acc[mi][ni][r] + bv;
+        if (row < M) {
+          const size_t at = (size_t)row * N + col;
+          const float h = acc[mi][ni][r] + bv;
+          if (ep == EP_BIAS) C[at] = h;
+          else if (ep == EP_GELU) {
+            if (C2 != nullptr) C2[at] = h;
+            C[at] = gemm_gelu(h);
+          } else C[at] = h * gemm_gelu_grad(aux[at]);
+        }
       }
   }
 }
 
 template <int NP, bool DB, int BM>
-static void launch_gemm_variant(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
+static void launch_gemm_variant(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
+                                int ep, float* C2, const float* aux) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / GN;
   const size_t lds = (size_t)(DB ? 2 : 1) * NP * (BM + GN) * GLD * sizeof(__bf16);
   static bool attr_done = false;
@@ -234,7 +258,7 @@ static void launch_gemm_variant(const float* A, const void* Bimg, const float* b
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;                // every XCD gets the same number of slots; surplus ones return at once
   hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
-                     K, tiles_m, tiles_n);
+                     K, tiles_m, tiles_n, ep, C2, aux);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -368,13 +392,14 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
 // Also measured and dropped: 4 waves of 64 x 64 with two workgroups per CU (-8...-30 %), a second fragment register set read
 // one step ahead (-12...-30 %).
 template <int NP>
-static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
+static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
+                             int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr) {
   const int t128 = ((M + 127) / 128) * (N / GN);
   const int forced = env_int("HOPMI_GEMM_TILE", 0);       // diagnostics: 1 = 128/DB, 2 = 128/!DB, 3 = 64/!DB
   const int mode = (forced >= 1 && forced <= 3) ? forced : (t128 < 160 ? 3 : (t128 <= 256 ? 1 : 2));
-  if (mode == 1) launch_gemm_variant<NP, true, 128>(A, Bimg, bias, C, M, N, K, st);
-  else if (mode == 2) launch_gemm_variant<NP, false, 128>(A, Bimg, bias, C, M, N, K, st);
-  else launch_gemm_variant<NP, false, 64>(A, Bimg, bias, C, M, N, K, st);
+  if (mode == 1) launch_gemm_variant<NP, true, 128>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux);
+  else if (mode == 2) launch_gemm_variant<NP, false, 128>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux);
+  else launch_gemm_variant<NP, false, 64>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux);
   return check_launch("hopmi_gemm_split");
 }
 
@@ -428,4 +453,20 @@ extern "C" int hopmi_gemm_split(const float* A, const void* Bimage, const float*
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   return parts == 2 ? launch_gemm_split<2>(A, Bimage, bias, C, M, N, K, st) : launch_gemm_split<3>(A, Bimage, bias, C, M, N, K, st);
+}
+
+extern "C" int hopmi_gemm_split_ep(const float* A, const void* Bimage, const float* bias, float* C, float* C2, const float* aux, int M,
+                                   int N, int K, int parts, int epilogue, void* stream) {
+  if (!A || !Bimage || !C) { set_error("hopmi_gemm_split_ep: null pointer argument"); return HOPMI_EINVAL; }
+  if (M <= 0 || N <= 0 || K <= 0 || N % GN || K % GK || (parts != 2 && parts != 3)) {
+    set_error("hopmi_gemm_split_ep: need N %% 128 == 0, K %% 32 == 0, parts in {2, 3} (M=%d N=%d K=%d parts=%d)", M, N, K, parts);
+    return HOPMI_EINVAL;
+  }
+  if (epilogue < EP_BIAS || epilogue > EP_GELU_GRAD || (epilogue == EP_GELU_GRAD && !aux)) {
+    set_error("hopmi_gemm_split_ep: epilogue %d (0 bias, 1 gelu, 2 gelu gradient: needs aux)", epilogue);
+    return HOPMI_EINVAL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return parts == 2 ? launch_gemm_split<2>(A, Bimage, bias, C, M, N, K, st, epilogue, C2, aux)
+                    : launch_gemm_split<3>(A, Bimage, bias, C, M, N, K, st, epilogue, C2, aux);
 }

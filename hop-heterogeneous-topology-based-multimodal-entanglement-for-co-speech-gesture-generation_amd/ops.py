@@ -308,6 +308,51 @@ def split_linear(x, img_w, img_wt, bias, N, K, parts):
     return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
 
 
+def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None):
+    """hopmi_gemm_split_ep: epilogue 1 -> (gelu(h), h if keep else None) with h = a2d W^T + bias; 2 -> (a2d W^T) * gelu'(aux)."""
+    M = a2d.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
+    h = torch.empty_like(out) if (epilogue == 1 and keep) else None
+    L = _lib.lib()
+    _lib.check(_timed("gemm_split", 4 * (M * K + (3 if (h is not None or aux is not None) else 2) * M * N) + 2 * parts * N * K, 2 * M * N * K,
+                      lambda: L.hopmi_gemm_split_ep(a2d.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h), _ptr(aux), M, N, K,
+                                                    parts, epilogue, _stream())),
+               "hopmi_gemm_split_ep")
+    return out, h
+
+
+class _SplitFfnFn(torch.autograd.Function):
+    """BertIntermediate + the dense of BertOutput against FROZEN weights: o = gelu(x W1^T + b1) W2^T (the bias of the second
+    linear is added by the LayerNorm operator behind it).  The activation is the epilogue of the first product and its gradient
+    the epilogue of the backward's first product (hopmi_gemm_split_ep): the values of split_linear -> bias_gelu -> split_linear
+    bit for bit, without the two launches that re-read and re-write the M x 3072 tensor."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, img1, img1t, b1, img2, img2t, N1, K, parts):
+        x = _dev_f32(x, "x")
+        f, h = _split_gemm_ep(x.reshape(-1, K), img1, _dev_f32(b1.detach(), "bias"), N1, K, parts, 1, keep=ctx.needs_input_grad[0])
+        o = _split_gemm(f, img2, None, K, N1, parts)
+        ctx.save_for_backward(h)
+        ctx.imgs, ctx.dims = (img1t, img2t), (N1, K, parts)
+        return o.view(*x.shape[:-1], K)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, do):
+        (h,) = ctx.saved_tensors
+        img1t, img2t = ctx.imgs
+        N1, K, parts = ctx.dims
+        do = _dev_f32(do, "do")
+        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h)           # (dO W2) * gelu'(h)
+        dx = _split_gemm(dh, img1t, None, K, N1, parts)                                           # dH W1
+        return dx.view(*do.shape), None, None, None, None, None, None, None, None
+
+
+def split_ffn(x, img1, img1t, b1, img2, img2t, N1, K, parts):
+    return _SplitFfnFn.apply(x, img1, img1t, b1, img2, img2t, N1, K, parts)
+
+
 # ------------------------------------------------------- fused BERT epilogues (frozen LLM: no parameter grads)
 class _BiasGeluFn(torch.autograd.Function):
     @staticmethod

@@ -374,6 +374,14 @@ int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts, void* imag
 int hopmi_gemm_split(const float* A, const void* Bimage, const float* bias, float* C, int M, int N, int K, int parts,
                      void* stream);
 
+/* The same product with an activation epilogue (BertIntermediate, transformers modeling_bert.py: `intermediate_act_fn(dense(x))`,
+ * gelu = x/2 (1 + erf(x / sqrt 2)), and its gradient), so that the M x 3072 tensor is not re-read and re-written by a launch of its
+ * own.  epilogue 0: C = A.Bt^T + bias (= hopmi_gemm_split);  1: h = A.Bt^T + bias, C = gelu(h), C2 = h when C2 is not NULL (the
+ * backward's operand);  2: C = (A.Bt^T + bias) * gelu'(aux), aux [M][N] = the h of the forward.  Bit-identical to hopmi_gemm_split
+ * followed by hopmi_bias_gelu_fwd / _bwd (the same expressions on the same fp32 values). */
+int hopmi_gemm_split_ep(const float* A, const void* Bimage, const float* bias, float* C, float* C2, const float* aux, int M, int N,
+                        int K, int parts, int epilogue, void* stream);
+
 /* The same product with BOTH operands as part images (Aimage = hopmi_gemm_split_prepare(A, M, K, parts, ...), i.e.
  * [parts][M][K] bf16; a producer may also write that layout itself): nothing is split inside the kernel, every tile is staged
  * by LDS-DMA.  Same arithmetic (the same MFMA terms in the same order) as hopmi_gemm_split: results are bit-identical. */

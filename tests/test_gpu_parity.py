@@ -1498,6 +1498,41 @@ def test_gemm_split_vs_float64(M, N, K, parts, tol):
     assert torch.equal(y_ab, y.detach())
 
 
+@pytest.mark.parametrize("parts", [3, 2])
+@pytest.mark.parametrize("M", [4352, 1100])
+def test_split_ffn_equals_unfused_composition(M, parts):
+    """BertIntermediate + BertOutput.dense with the activation and its gradient as epilogues of the split GEMMs
+    (hopmi_gemm_split_ep) against split_linear -> bias_gelu -> split_linear: the same expressions on the same fp32 values,
+    so output and input gradient must agree BIT FOR BIT (ragged M included); and both against float64."""
+    from hopmi import ops
+    dev = _dev()
+    D, F4 = 768, 3072
+    g = torch.Generator().manual_seed(M + parts)
+    x = torch.randn(M, D, generator=g).to(dev)
+    w1 = (torch.randn(F4, D, generator=g) / D ** 0.5).to(dev)
+    b1 = (0.1 * torch.randn(F4, generator=g)).to(dev)
+    w2 = (torch.randn(D, F4, generator=g) / F4 ** 0.5).to(dev)
+    gy = torch.randn(M, D, generator=g).to(dev)
+    i1, i1t = ops.split_weight_image(w1, parts), ops.split_weight_image(w1.t().contiguous(), parts)
+    i2, i2t = ops.split_weight_image(w2, parts), ops.split_weight_image(w2.t().contiguous(), parts)
+    xa = x.clone().requires_grad_()
+    oa = ops.split_ffn(xa, i1, i1t, b1, i2, i2t, F4, D, parts)
+    oa.backward(gy)
+    xb = x.clone().requires_grad_()
+    ob = ops.split_linear(ops.bias_gelu(ops.split_linear(xb, i1, i1t, None, F4, D, parts), b1), i2, i2t, None, D, F4, parts)
+    ob.backward(gy)
+    assert torch.equal(oa, ob)
+    assert torch.equal(xa.grad, xb.grad)
+    with torch.no_grad():                                    # the no-grad forward keeps no pre-activation: same values
+        assert torch.equal(ops.split_ffn(x, i1, i1t, b1, i2, i2t, F4, D, parts), ob)
+    xd = x.double().requires_grad_()
+    od = torch.nn.functional.gelu(xd @ w1.double().t() + b1.double()) @ w2.double().t()
+    od.backward(gy.double())
+    tol = 4e-6 if parts == 3 else 3e-5
+    assert rel_err(oa.double(), od) <= tol
+    assert rel_err(xa.grad.double(), xd.grad) <= tol
+
+
 # ---- the three-term split-bf16 kernels against float64, next to plain fp32 torch ---------------------------------------------
 # hopmi_gemm_split carries operands as three bf16 numbers (six MFMA terms) and is fp32-EQUIVALENT (test above).  The WaveNet,
 # reprogramming-attention and GRU-recurrence kernels carry them as TWO (hi + lo, 16 significand bits) and sum three MFMA terms

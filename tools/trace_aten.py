@@ -22,6 +22,7 @@ def make_step(dev, dataset="TED", B=128, epoch=0):
                         synth.SpeakerVocab(1370)).float().to(dev)
     disc = hopmi.ConvDiscriminator(3 * V).to(dev)
     model.train(); disc.train()
+    hopmi.mixed_precision(os.environ.get("DTYPE") or None)     # DTYPE=bf16: configs[2] / [4]
     lr = 0.01
     g_opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr, betas=(0.5, 0.999), fused=True)
     d_opt = torch.optim.Adam(disc.parameters(), lr=lr * 0.1, betas=(0.5, 0.999), fused=True)
@@ -92,7 +93,8 @@ def main():
     if os.environ.get("SITES", "1") == "1":
         host_sites(run)
         return
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    shapes = os.environ.get("SHAPES", "0") == "1"    # group by input shapes instead (python stacks come back empty on this build)
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=shapes) as prof:
         for _ in range(steps):
             run()
         torch.cuda.synchronize()
@@ -106,6 +108,8 @@ def main():
             if "_amd/" in f or "hopmi" in f:
                 frame = f.split("/")[-1]
                 break
+        if shapes:
+            frame = str([tuple(x) if isinstance(x, (list, tuple)) else x for x in (ev.input_shapes or [])][:3])
         k = (ev.name, frame)
         agg[k][0] += 1
         agg[k][1] += t
