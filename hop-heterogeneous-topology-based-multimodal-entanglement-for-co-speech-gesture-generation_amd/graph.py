@@ -197,7 +197,15 @@ class GraphedTrainStep:
                 seen.add(id(t))
                 written.append(t)
         self._written = tuple(written)
+        # what a recording reads but no replay writes: the frozen parameters (the BERT, the word embeddings).  Tensors derived
+        # from them (bf16 copies, part images of the split GEMMs, the fused QKV weight) are built once, in an eager call, and
+        # a recording holds their addresses: if a frozen parameter is modified afterwards (load_state_dict, an in-place copy),
+        # the recordings are dropped and the step runs eagerly again before it is re-recorded -- see __call__
+        self._frozen = tuple(p for mod in (m, self.disc) for p in mod.parameters() if id(p) not in seen)
         self._built = True
+
+    def _frozen_versions(self):
+        return tuple(p._version for p in self._frozen)
 
     def _mark_written(self):
         """A replay updates parameters and buffers on the device behind torch's back: advance their version counters as
@@ -340,12 +348,19 @@ class GraphedTrainStep:
         key = (gan, torch.is_autocast_enabled(), _steps._MIXED, getattr(self.args, "mixed_precision", None)) + tuple(
             (tuple(t.shape), t.dtype) for t in batch)
         rec = self.records.get(key)
+        if rec is not None and rec["frozen"] != self._frozen_versions():
+            # a frozen parameter was modified behind the recordings: they replay tensors derived from the old values
+            self.records.clear()
+            self.eager_left.clear()
+            self._pool = torch.cuda.graph_pool_handle()          # (the old pool went with its last graph)
+            return self(epoch, *batch)
         if rec is None:
             if any(k[0] == gan for k in self.records):           # another batch shape of a recorded phase: eager
                 return self._eager(epoch, batch)
             if not self._built:
                 self._build(in_audio.device)
             rec = self.records[key] = self._capture(epoch, batch)
+            rec["frozen"] = self._frozen_versions()
         for dst, src in zip(rec["static"], batch):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
