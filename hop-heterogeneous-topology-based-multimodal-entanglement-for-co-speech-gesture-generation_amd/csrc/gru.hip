@@ -858,6 +858,54 @@ static void gru_prepare(void* ws, size_t ws_bytes, float* handoff, size_t n_floa
                      reinterpret_cast<u32x2*>(handoff), npairs);
 }
 
+// The two operands the backward of a layer needs besides what the forward saved, in ONE launch (they were a transpose copy, a
+// fill and two strided copies per layer): whhT[d][h][g] = whh[d][g][h] for the recurrence's backward (dh = dgh . W_hh reads W_hh
+// along g), and hprev[b][t][d][:] = the state in front of step t of direction d -- y shifted one step along the direction's
+// processing order, zero at its first step -- for dW_hh = sum dgh^T hprev.  Blocks [0, n_shift) shift, the rest transpose 32 x 32
+// tiles through LDS.
+__global__ __launch_bounds__(256) void gru_bwd_operands_kernel(const float* __restrict__ y, const float* __restrict__ whh,
+                                                               float* __restrict__ hprev, float* __restrict__ whhT, int B, int T, int H,
+                                                               int n_shift) {
+  __shared__ float tile[32][33];
+  const int bid = blockIdx.x;
+  if (bid < n_shift) {
+    const size_t n2 = (size_t)B * T * H;             // float2 elements of (B, T, 2, H)
+    const int H2 = H / 2;
+    for (size_t i = (size_t)bid * 256 + threadIdx.x; i < n2; i += (size_t)n_shift * 256) {
+      const int c = (int)(i % H2);
+      const size_t r = i / H2;                       // (b, t, d)
+      const int d = (int)(r & 1);
+      const size_t bt = r >> 1;
+      const int t = (int)(bt % T);
+      const bool live = d == 0 ? t > 0 : t + 1 < T;
+      float2 v = make_float2(0.f, 0.f);
+      if (live) v = reinterpret_cast<const float2*>(y + (d == 0 ? bt - 1 : bt + 1) * 2 * H + (size_t)d * H)[c];
+      reinterpret_cast<float2*>(hprev + bt * 2 * H + (size_t)d * H)[c] = v;
+    }
+    return;
+  }
+  // whh (2, 3H, H) -> whhT (2, H, 3H)
+  const int G = 3 * H, tg = (G + 31) / 32, th = (H + 31) / 32;
+  int tb = bid - n_shift;
+  const int d = tb / (tg * th);
+  tb -= d * tg * th;
+  const int g0 = (tb / th) * 32, h0 = (tb % th) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  const float* src = whh + (size_t)d * G * H;
+  float* dst = whhT + (size_t)d * G * H;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = g0 + ty + 8 * k, h = h0 + tx;
+    tile[ty + 8 * k][tx] = (g < G && h < H) ? src[(size_t)g * H + h] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int h = h0 + ty + 8 * k, g = g0 + tx;
+    if (h < H && g < G) dst[(size_t)h * G + g] = tile[tx][ty + 8 * k];
+  }
+}
+
 static int gru_validate(const void* const* ptrs, int n, int B, int T, int H) {
   for (int i = 0; i < n; ++i)
     if (!ptrs[i]) { set_error("hopmi_gru: null pointer argument #%d", i); return HOPMI_EINVAL; }
@@ -1069,6 +1117,17 @@ extern "C" int hopmi_gru_bwd_dt(const float* dy, const float* y, const float* ga
   if (dgi_dtype == 0) return gru_bwd_impl(dy, y, gates, whhT, static_cast<float*>(dgi), dgh, ws, ws2, B, T, H, stream);
   set_error("hopmi_gru_bwd_dt: dgi_dtype %d (0 = fp32, 1 = bf16)", dgi_dtype);
   return HOPMI_EINVAL;
+}
+
+extern "C" int hopmi_gru_bwd_operands(const float* y, const float* whh, float* hprev, float* whhT, int B, int T, int H, void* stream) {
+  const void* ptrs[] = {y, whh, hprev, whhT};
+  if (int e = gru_validate(ptrs, 4, B, T, H)) return e;
+  const size_t n2 = (size_t)B * T * H;
+  const int n_shift = (int)((n2 + 256 * 8 - 1) / (256 * 8) < 2048 ? (n2 + 256 * 8 - 1) / (256 * 8) : 2048);
+  const int n_tr = 2 * ((3 * H + 31) / 32) * ((H + 31) / 32);
+  hipLaunchKernelGGL(gru_bwd_operands_kernel, dim3(n_shift + n_tr), dim3(256), 0, static_cast<hipStream_t>(stream), y, whh, hprev, whhT,
+                     B, T, H, n_shift);
+  return check_launch("hopmi_gru_bwd_operands");
 }
 
 extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates, const float* whhT,

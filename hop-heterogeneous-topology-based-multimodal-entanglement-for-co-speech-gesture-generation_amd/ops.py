@@ -1254,7 +1254,11 @@ class _GruLayerFn(torch.autograd.Function):
             B, T, H2 = y.shape
             H = H2 // 2
             L, st = _lib.lib(), _stream()
-            whhT = whh.transpose(1, 2).contiguous()
+            # the recurrence's W_hh^T and the shifted states for dW_hh: one launch (was a transpose copy, a fill, two strided copies)
+            whhT = torch.empty(2, H, 3 * H, dtype=torch.float32, device=y.device)
+            hprev = torch.empty(B, T, 2, H, dtype=torch.float32, device=y.device)
+            _lib.check(L.hopmi_gru_bwd_operands(y.data_ptr(), whh.data_ptr(), hprev.data_ptr(), whhT.data_ptr(), B, T, H, st),
+                       "hopmi_gru_bwd_operands")
             dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.bfloat16 if ctx.typed else torch.float32, device=y.device)
             dgh = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
             ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
@@ -1270,10 +1274,6 @@ class _GruLayerFn(torch.autograd.Function):
                 raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
             # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
             # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
-            yv = y.view(B, T, 2, H)
-            hprev = torch.zeros_like(yv)
-            hprev[:, 1:, 0] = yv[:, :-1, 0]
-            hprev[:, :-1, 1] = yv[:, 1:, 1]
             dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
             dbhh = colsum(dgh.view(B * T, 6 * H)).view(2, 3 * H)
         return dgi, dwhh, dbhh

@@ -360,6 +360,11 @@ int hopmi_gru_fwd_dt(const void* gi, int gi_dtype, const float* whh, const float
 int hopmi_gru_bwd_dt(const float* dy, const float* y, const float* gates, const float* whhT, void* dgi, int dgi_dtype,
                      float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);
 
+/* The two operands of a layer's backward that are re-arrangements of forward tensors, in one launch: whhT (2,H,3H) = whh (2,3H,H)
+ * transposed per direction (the whhT argument of hopmi_gru_bwd), and hprev (B,T,2,H) = y shifted one step along each direction's
+ * processing order, zero at its first step (dW_hh = sum_{b,t} dgh^T hprev; multimodal_context_net.py:35 -> torch.nn.GRU backward). */
+int hopmi_gru_bwd_operands(const float* y, const float* whh, float* hprev, float* whhT, int B, int T, int H, void* stream);
+
 /* ---- fp32 GEMM against frozen weights on the bf16 matrix cores (the frozen BERT's linears, HOP.py:90-91,204 ->
  *      transformers BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput nn.Linear calls)
  *   C[M][N] = A[M][K] . Bt[N][K]^T (+ bias[N]);  A, C fp32 row-major.
