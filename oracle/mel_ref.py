@@ -4,14 +4,15 @@
     melspec     = librosa.feature.melspectrogram(y=audio_padded, sr=16000, n_fft=1024, hop_length=1096, power=2)
     log_melspec = librosa.power_to_db(melspec, ref=np.max).T
 
-PARITY PARTLY PINNED: librosa (pinned at 0.8.1 by the reference, requirements_HOP:35) is a third-party dependency that is
-neither under /root/reference nor importable in the build container, and the reference holds no fixture of this feature.
-This file restates the published librosa 0.8.1 definitions -- stft(center=True, pad_mode='reflect', window='hann' = scipy
-get_window('hann', 1024, fftbins=True), win_length = n_fft), filters.mel(htk=False, norm='slaney', fmin=0, fmax=sr/2),
-power_to_db(amin=1e-10, top_db=80.0) -- in float64 numpy; only tests import it.  What independent implementations in this
-container can pin is pinned by tests/test_mel_pin.py: the framing / window / reflect padding / FFT half (`stft_power`) against
-torch.stft and scipy's window, the dB stage (`power_to_db`) against its closed form.  The Slaney filter bank (`mel_basis`)
-remains UNPINNED by necessity: only its published structural properties are checked there.
+PARITY PINNED BY INDEPENDENT IMPLEMENTATIONS, NOT BY LIBROSA ITSELF: librosa (pinned at 0.8.1 by the reference,
+requirements_HOP:35) is a third-party dependency that is neither under /root/reference nor importable in the build container,
+and the reference holds no fixture of this feature.  This file restates the published librosa 0.8.1 definitions --
+stft(center=True, pad_mode='reflect', window='hann' = scipy get_window('hann', 1024, fftbins=True), win_length = n_fft),
+filters.mel(htk=False, norm='slaney', fmin=0, fmax=sr/2), power_to_db(amin=1e-10, top_db=80.0) -- in float64 numpy; only tests
+import it.  tests/test_mel_pin.py holds every stage against an implementation written by someone else that IS importable here:
+the framing / window / reflect padding / FFT half (`stft_power`) against torch.stft and scipy's window, the Slaney filter bank
+(`mel_basis`) against transformers.audio_utils.mel_filter_bank (Hugging Face's numpy implementation of librosa.filters.mel), the
+whole mel power against transformers.audio_utils.spectrogram, the dB stage (`power_to_db`) against its closed form.
 """
 import numpy as np
 

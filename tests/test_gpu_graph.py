@@ -674,8 +674,9 @@ def test_graphed_step_soak_interleaved_with_eager_work(epoch, monkeypatch):
 def test_logmel_vs_float64_restatement():
     """hopmi_logmel (GPU: reflect-padded framing, periodic Hann, radix-2 FFT in LDS, Slaney mel filters, power_to_db with
     ref = max and an 80 dB floor) against oracle/mel_ref.py, the float64 restatement of librosa 0.8.1's published
-    definitions of the reference's call (lmdb_data_loader.py:216-218).  PARITY UNPINNED for this row: librosa itself cannot
-    be imported in the build container, so no fixture from it exists.  Tolerance: 2e-2 dB absolute on the [-80, 0] dB
+    definitions of the reference's call (lmdb_data_loader.py:216-218).  librosa itself cannot be imported in the build container, so no
+    fixture from it exists: the restatement is pinned stage by stage against torch.stft, scipy and transformers.audio_utils
+    (tests/test_mel_pin.py).  Tolerance: 2e-2 dB absolute on the [-80, 0] dB
     range (fp32 FFT and log10), i.e. 2.5e-4 of the feature's range."""
     import numpy as np
     import hopmi
