@@ -49,6 +49,8 @@ def parse():
                          "(six MFMA terms: fp32-equivalent, default) or 2 parts (three terms: 2^-16-class products)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
     ap.add_argument("--tuned-table", default=None, help="another TunableOp table than the shipped one (A/B runs)")
+    ap.add_argument("--flat-exchange", action="store_true",
+                    help="N > 1 (or --rehearse-sync): one all-reduce behind the whole generator backward instead of the overlapped form")
     ap.add_argument("--rehearse-sync", action="store_true",
                     help="N=1 only: run the N>1 exchange path on a 1-rank RCCL group (overhead rehearsal)")
     ap.add_argument("--feed-host", action="store_true",
@@ -224,6 +226,7 @@ def main():
 
     graphed = hopmi.GraphedTrainStep(sargs, model, disc, g_opt, d_opt, accelerator=sync, eager_calls=1,
                                      grad_dtype=grad_dtype, enabled=not args.eager, force_exchange=args.rehearse_sync,
+                                     overlap=not args.flat_exchange,
                                      group=dist.group.WORLD if dist.is_initialized() else None)
 
     feeder, feed_times = None, []
@@ -333,8 +336,11 @@ def main():
                                 "host -> device copy and the log-mel kernels enqueued in front of the step)",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "exchange": None if world == 1 and not args.rehearse_sync else
-                                   "prototype rows of the mapping layer sharded over ranks (all-gather S, all-reduce dS), "
-                                   "one flat all-reduce of the other gradients per module, eager RCCL calls between graph launches",
+                                   "prototype rows of the mapping layer sharded over ranks (all-gather S, all-reduce dS), " +
+                                   ("one flat all-reduce of the other gradients per module" if args.flat_exchange else
+                                    "the generator's backward cut at the decoder input: the all-reduce of the first half's gradients "
+                                    "(decoder GRU, head) runs under the second half, one flat all-reduce for the rest and one for the discriminator") +
+                                   ", eager RCCL calls between graph launches",
                        "llm": "BERT-base geometry, 6 layers, random init, frozen",
                        "arithmetic": "per-kernel error against float64 next to plain fp32 torch: tests/test_gpu_parity.py::test_*_vs_float64 "
                                      "(three-term split-bf16 kernels: within K x the fp32 reference's own error, K stated per test)",

@@ -80,6 +80,37 @@ def all_reduce_mean(flat, group=None):
         flat.div_(dist.get_world_size(group))
 
 
+def all_reduce_mean_start(flat, group=None):
+    """The same all-reduce, started and left running (RCCL: on its own stream, behind what the current stream holds now);
+    returns what all_reduce_mean_finish needs."""
+    if dist.get_backend(group) == "nccl":
+        return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=True), None
+    return dist.all_reduce(flat, group=group, async_op=True), dist.get_world_size(group)
+
+
+def all_reduce_mean_finish(flat, pending):
+    work, div = pending
+    work.wait()                                   # (RCCL: the current stream waits; gloo: the host does)
+    if div is not None:
+        flat.div_(div)
+
+
+def _params_behind(tensors):
+    """ids of the leaf tensors (parameters) that the autograd graphs of `tensors` reach."""
+    seen, out = set(), set()
+    stack = [t.grad_fn for t in tensors if t is not None and t.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, "variable", None)
+        if var is not None:
+            out.add(id(var))
+        stack.extend(f for f, _ in fn.next_functions)
+    return out
+
+
 class _Capture:
     """Stands in for the `accelerator` of `train_llm` while its launches are being recorded, and owns the recording:
     a list of ("graph", CUDAGraph) / ("eager", callable) entries that a replay walks in order."""
@@ -92,6 +123,8 @@ class _Capture:
         self.graph = None
         self.fetch = None
         self.keep = []              # tensors the recording owns (flat exchange buffers, ...)
+        self.cuts = []              # (tensor, detached leaf) pairs of the graded forward (ops.cut_point), overlapped exchange only
+        self.early = None           # the first half of an overlapped exchange, between _exchange_early and _after_backward
 
     def begin(self):
         # debug: the hipGraph_t is kept behind the executable graph (node_census / dump_graphs)
@@ -130,20 +163,35 @@ class _Capture:
         self.cut(ev.record)                            # the replay's host side waits for this event only
         return host
 
+    def cut_leaf(self, t):
+        leaf = t.detach().requires_grad_()
+        self.cuts.append((t, leaf))
+        return leaf
+
     def backward(self, loss, only=None):
-        loss.backward()
         is_disc = only is not None and len(only) == 1 and only[0] is self.owner.disc
+        cuts, self.cuts = self.cuts, []
+        loss.backward()
+        if cuts and not is_disc:
+            # The backward above ended at the leaves the graded forward was cut at (decoder input, VAE outputs): the gradients of
+            # everything behind them are complete.  Their all-reduce is started and left running; the backward of everything in
+            # front of the leaves is recorded into the next segment and replays while that exchange is on the wire.
+            self.owner._exchange_early(self, [t for t, _ in cuts])
+            live = [(t, leaf.grad) for t, leaf in cuts if leaf.grad is not None]
+            torch.autograd.backward([t for t, _ in live], [g for _, g in live])
         self.owner._after_backward(self, is_disc)
 
 
 class GraphedTrainStep:
     def __init__(self, args, model, discriminator, model_optim, dis_optimizer, accelerator=None, group=None,
-                 eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False, debug=False):
+                 eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False, debug=False, overlap=True):
         """`accelerator`: what the eager calls hand to train_llm (a GradSync when more than one rank trains; default a
         plain backward).  `grad_dtype=torch.bfloat16` halves the bytes of the flat gradient exchanges (the sums still
         land in fp32 gradients).  `enabled=False` makes every call the eager step (for A/B runs).  `force_exchange` runs
         the collectives of the N > 1 recording on a 1-rank group too (rehearsal on a single-GPU box).  `debug=True` keeps
-        the recorded hipGraphs inspectable (`dump_graphs`)."""
+        the recorded hipGraphs inspectable (`dump_graphs`).  `overlap` (N > 1 only): the generator's backward is recorded in two
+        halves, cut at the decoder's input, and the all-reduce of the first half's gradients (decoder GRU, head) runs under the
+        second half (BERT, reprogramming attention, WaveNet, mapping layer); False: one all-reduce behind the whole backward."""
         self.args, self.model, self.disc = args, _steps._unwrap(model), _steps._unwrap(discriminator)
         self.g_opt, self.d_opt = model_optim, dis_optimizer
         self.group = group
@@ -156,6 +204,7 @@ class GraphedTrainStep:
         self.eager_calls = max(1, int(eager_calls))
         self.eager_left = {}                        # phase (gan flag) -> eager calls still to make before recording it
         self.grad_dtype = grad_dtype
+        self.overlap = bool(overlap)
         self.enabled = enabled
         self.debug = debug
         self.records = {}
@@ -229,21 +278,42 @@ class GraphedTrainStep:
             buf, per, grp = self._S_pad, self.per, self.group
             cap.cut(lambda: all_gather_rows(buf, per, grp))
 
+    def _pack(self, grads, extra=0):
+        n = sum(g.numel() for g in grads)
+        flat = torch.empty(n + extra, dtype=self.grad_dtype or torch.float32, device=grads[0].device)
+        views, off = [], 0
+        for g in grads:
+            views.append(flat[off:off + g.numel()].view(g.shape))
+            off += g.numel()
+        torch._foreach_copy_(views, grads)
+        return flat, views, n
+
+    def _exchange_early(self, cap, cut_tensors):
+        """First half of an overlapped exchange: the gradients that are complete when the backward has reached the cut (the
+        parameters the graphs in front of the cut do NOT reach) go into a flat buffer whose all-reduce is started between two graph
+        launches and finished in _after_backward, behind the rest of the backward."""
+        late = _params_behind(cut_tensors)
+        early = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None and id(p) not in late]
+        if not early:
+            return
+        grads = [p.grad for p in early]
+        flat, views, _ = self._pack(grads)
+        cap.keep.append(flat)
+        pending, grp = {}, self.group
+        cap.cut(lambda: pending.__setitem__("w", all_reduce_mean_start(flat, grp)))
+        cap.early = dict(ids={id(p) for p in early}, grads=grads, views=views, flat=flat, pending=pending)
+
     def _after_backward(self, cap, is_disc):
         """Called with the gradients of one module freshly produced: exchange them (world > 1), then -- for the
         generator -- turn dS into this rank's rows of the mapping layer's gradients."""
         module = self.disc if is_disc else self.model
+        early, cap.early = (None, None) if is_disc else (cap.early, None)
         if self.exchange:
-            grads = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None]
+            grads = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None
+                     and (early is None or id(p) not in early["ids"])]
             if not is_disc and self._has_proto and self._S.grad is not None:
                 grads.append(self._S.grad)
-            n = sum(g.numel() for g in grads)
-            flat = torch.empty(n + 1, dtype=self.grad_dtype or torch.float32, device=grads[0].device)
-            views, off = [], 0
-            for g in grads:
-                views.append(flat[off:off + g.numel()].view(g.shape))
-                off += g.numel()
-            torch._foreach_copy_(views, grads)
+            flat, views, n = self._pack(grads, extra=1)
             # one more element: this rank's persistent-GRU status words so far in the replay.  A hand-off time-out on one rank
             # then shows up in EVERY rank's next loss fetch, so all ranks raise at the same step instead of the healthy ones
             # waiting in the next collective for a rank that has stopped.
@@ -251,7 +321,12 @@ class GraphedTrainStep:
             flat[n:].copy_((torch.stack(words).sum() if words else torch.zeros((), device=flat.device)).reshape(1))
             cap.keep.append(flat)
             grp = self.group
-            cap.cut(lambda: all_reduce_mean(flat, grp))
+            if early is None:
+                cap.cut(lambda: all_reduce_mean(flat, grp))
+            else:
+                e_flat, e_pending = early["flat"], early["pending"]
+                cap.cut(lambda: (all_reduce_mean_finish(e_flat, e_pending.pop("w")), all_reduce_mean(flat, grp)))
+                torch._foreach_copy_(early["grads"], early["views"])
             torch._foreach_copy_(grads, views)
             self._peer_status.add_(flat[n].float())
         if not is_disc and self._has_proto:
@@ -298,12 +373,13 @@ class GraphedTrainStep:
         self._stream.wait_stream(cur)
         amp_factory = lambda: _steps._amp(self.args, static[3])
         m = self.model
-        prev_sink, prev_cap, prev_seed = _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV
+        prev_sink, prev_cap, prev_seed, prev_cut = _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV, _ops.CUT_HOOK
         _ops.deferred_status()                                   # pending eager launches are not this recording's
         gc.collect()
         torch.cuda.synchronize(dev)
         with torch.cuda.stream(self._stream), _ops.no_timer():
             _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV = cap.status, cap, self._seed_word
+            _ops.CUT_HOOK = cap.cut_leaf if (self.exchange and self.overlap) else None
             if self._has_proto:
                 m._proto_S = self._S
                 self._S.grad = None
@@ -328,7 +404,7 @@ class GraphedTrainStep:
                 finally:
                     cap.end()
             finally:
-                _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV = prev_sink, prev_cap, prev_seed
+                _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV, _ops.CUT_HOOK = prev_sink, prev_cap, prev_seed, prev_cut
                 m._proto_S = None
         cur.wait_stream(self._stream)
         if cap.fetch is None:

@@ -334,7 +334,9 @@ class Model(nn.Module):
         parts = [pre, beat if self.use_gwnet else audio_feature, dec_out]
         if z_context is not None:
             parts.append(z_context.unsqueeze(1).expand(B, 34, z_context.shape[1]))
-        dec_in = torch.cat(parts, dim=2).to(torch.float32).contiguous()
+        # (ops.cut_point: the identity, except under a recording with an overlapped gradient exchange -- the decoder's input and
+        # the two VAE outputs the KLD term reads are where the backward is cut in two)
+        dec_in = ops.cut_point(torch.cat(parts, dim=2).to(torch.float32).contiguous())
         dec_out = ops.gru_bidirectional(dec_in, self.gru)                       # HOP.py:248 (h0 = 0)
         dec_out = dec_out[:, :, :self.hidden_size] + dec_out[:, :, self.hidden_size:]
-        return self.out(dec_out), z_context, z_mu, z_logvar
+        return self.out(dec_out), z_context, ops.cut_point(z_mu), ops.cut_point(z_logvar)

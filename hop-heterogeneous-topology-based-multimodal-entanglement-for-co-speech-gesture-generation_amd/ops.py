@@ -222,6 +222,21 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
     return _GcnFn.apply(x, A1, A2, Wm, bm, prep)
 
 
+# ------------------------------------------------------- leaf cut of the recorded backward (graph.GraphedTrainStep)
+CUT_HOOK = None     # while a step with an overlapped gradient exchange is being recorded: tensor -> detached leaf
+
+
+def cut_point(t):
+    """Identity -- except while hopmi.GraphedTrainStep records a step whose gradient exchange is overlapped with the backward:
+    there the tensor is replaced by a detached leaf, so that the backward of everything behind this point (decoder GRU, head,
+    losses) ends here, its gradients can be exchanged, and the backward of everything in front of it continues from the leaf's
+    gradient while that exchange is on the wire (graph._Capture.backward)."""
+    h = CUT_HOOK
+    if h is None or t is None or not torch.is_grad_enabled() or not t.requires_grad:
+        return t
+    return h(t)
+
+
 # ------------------------------------------------------- frozen-weight linears on split-bf16 MFMA (hopmi_gemm_split)
 GEMM_PARTS = 3      # 3: six-term split (fp32-equivalent, default);  2: three-term split (2^-16 class);  0: library fp32 GEMM (hipBLASLt)
 

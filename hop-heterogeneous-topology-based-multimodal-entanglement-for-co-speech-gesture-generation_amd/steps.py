@@ -204,7 +204,7 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
                 speaker = args.z_type == "speaker"
                 if FUSED_LOSSES:
                     # train_llm.py:46-79: huber, diversity regulariser, KLD and their weighted sum, fused (ops.hop_losses)
-                    loss, vals = _ops.hop_losses(outputs, target_dir_vec, out_rand.float(), z_context.float(), z_rand.float(),
+                    loss, vals = _ops.hop_losses(outputs, target_dir_vec, out_rand.float(), z_context.detach().float(), z_rand.float(),
                                                  z_mu.float() if speaker else None, z_logvar.float() if speaker else None,
                                                  args.loss_regression_weight, args.loss_reg_weight, args.loss_kld_weight)
                     huber_loss, div_reg, kld = vals[0], vals[1], (vals[2] if speaker else None)

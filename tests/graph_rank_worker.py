@@ -53,7 +53,9 @@ def main():
     args = step_args(9)
     sync1 = GradSync([m1, d1], bucket_mb=0.25)
     sync2 = GradSync([m2, d2], bucket_mb=0.25)
-    graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, accelerator=sync2, eager_calls=1, group=dist.group.WORLD)
+    # argv[3]: "flat" = one all-reduce behind the whole generator backward; default: the overlapped form (backward cut at the decoder input)
+    overlap = not (len(sys.argv) > 3 and sys.argv[3] == "flat")
+    graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, accelerator=sync2, eager_calls=1, group=dist.group.WORLD, overlap=overlap)
     # a status word this worker controls, recorded as if a persistent GRU launch of the backward had produced it (there are
     # none here: shared device): set on ONE rank at the end, it must stop EVERY rank at the same call
     fake_status = torch.zeros((), dtype=torch.int32, device=dev)

@@ -346,15 +346,19 @@ def test_graphed_step_dropout_advances(monkeypatch):
     assert len(set(losses[1:])) >= 4, losses
 
 
-@pytest.mark.parametrize("epoch,order", [(0, "sequential"), (11, "sequential"), (0, "interleaved"), (11, "interleaved")])
-def test_graphed_exchange_two_ranks_one_gpu(epoch, order):
+@pytest.mark.parametrize("epoch,order,exchange", [(0, "sequential", "overlap"), (11, "sequential", "overlap"), (0, "interleaved", "overlap"),
+                                                  (11, "interleaved", "overlap"), (0, "sequential", "flat")])
+def test_graphed_exchange_two_ranks_one_gpu(epoch, order, exchange):
     """The N > 1 recording (prototype rows sharded over ranks, S all-gathered, dS + the other gradients all-reduced by
     eager collectives between graph launches) with two ranks sharing cuda:0 over gloo, against the hook-driven GradSync
     exchange under steps.train_llm on copies of the same models: same losses every step, same parameters after
     unshard(), and identical replicas across the ranks (tests/graph_rank_worker.py).  `order`: the two paths one after the
     other, or an eager step of the other model copy queued between every two replays (the order in which round 2 saw a wrong
     gradient).  Then the sequence replay / unshard() / replay / short batch through the eager step / replay / unshard():
-    every replay shards the mapping layer again, the eager step and unshard() must notice, the replicas stay identical."""
+    every replay shards the mapping layer again, the eager step and unshard() must notice, the replicas stay identical.
+    `exchange`: "overlap" = the generator's backward recorded in two halves, cut at the decoder's input, the first half's
+    all-reduce started between two graph launches and finished behind the second half (the default for N > 1); "flat" = one
+    all-reduce behind the whole backward."""
     import json
     import os
     import subprocess
@@ -362,7 +366,8 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch, order):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + epoch + (50 if order == "interleaved" else 0)), os.path.join(root, "tests", "graph_rank_worker.py"), str(epoch), order]
+           "--master-port", str(29600 + epoch + (50 if order == "interleaved" else 0) + (100 if exchange == "flat" else 0)),
+           os.path.join(root, "tests", "graph_rank_worker.py"), str(epoch), order, exchange]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     dec = json.JSONDecoder()          # (the two ranks' lines can arrive glued together)
@@ -370,7 +375,7 @@ def test_graphed_exchange_two_ranks_one_gpu(epoch, order):
     assert len(rows) == 2, r.stdout[-2000:]
     for row in rows:
         assert row["sharded"] and row["own"] in ([0, 750], [750, 1500]), row
-        assert "eager" in row["n_plan"] and row["n_plan"].count("graph") >= 4, row["n_plan"]
+        assert "eager" in row["n_plan"] and row["n_plan"].count("graph") >= (5 if exchange == "overlap" else 4), row["n_plan"]
         assert row["stale_before_unshard"] > 1e-4                       # the other rank's rows really were not updated here
         for a, b in zip(row["losses_eager"], row["losses_graph"]):
             assert sorted(a) == sorted(b)
