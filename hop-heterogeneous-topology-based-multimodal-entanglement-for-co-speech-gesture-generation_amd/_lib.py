@@ -67,6 +67,8 @@ SIGNATURES = {
     "hopmi_bias_dropout_residual_layernorm_bwd_dt": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
     "hopmi_bert_attn_fwd_dt": (_I, [_VP, _VP, _I, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
     "hopmi_bert_attn_bwd_dt": (_I, [_VP, _VP, _VP, _I, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
+    "hopmi_bn_cl_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float, ctypes.c_float, _I, _VP]),
+    "hopmi_bn_cl_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hopmi_gemm_split_image_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_gemm_split_prepare": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hopmi_gemm_split": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),

@@ -172,6 +172,123 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// BatchNorm1d of the discriminator's pre_conv (multimodal_context_net.py:226-234) on channels-last rows x [M = B*T][C <= 64]:
+// training-mode batch statistics over the M rows, running-statistics update, affine map -- and its backward -- as ONE launch
+// each.  The tensors are tiny (M = 4096 rows of 8 or 16 channels): as tensor operations the layer was ~12 launches forward and
+// ~15 backward at the launch floor; here one workgroup walks the 256 KB twice.  Fixed summation order (thread-strided rows, then
+// the row groups in index order, in double): bitwise reproducible.
+constexpr int BN_T = 1024;
+
+__global__ __launch_bounds__(BN_T) void bn_cl_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, float* __restrict__ y, float* __restrict__ save,
+                                                         int M, int C, float eps, float momentum, int training) {
+  __shared__ double red[2][BN_T];
+  __shared__ float sc_sh[2][64];
+  const int tid = threadIdx.x, R = BN_T / C, r = tid / C, c = tid - r * C;
+  const bool live = r < R;
+  if (training) {
+    double s1 = 0.0, s2 = 0.0;
+    if (live)
+      for (int m0 = r; m0 < M; m0 += 8 * R) {       // 8 rows in flight per thread (one workgroup: latency, not bandwidth)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (m0 + u * R < M) ? x[(size_t)(m0 + u * R) * C + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += (double)v[u]; s2 += (double)v[u] * (double)v[u]; }
+      }
+    red[0][tid] = s1;
+    red[1][tid] = s2;
+    __syncthreads();
+    if (tid < C) {
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < R; ++k) { a += red[0][k * C + tid]; b += red[1][k * C + tid]; }
+      const double mean = a / M;
+      double var = b / M - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float scale = gamma[tid] * rstd;
+      sc_sh[0][tid] = scale;
+      sc_sh[1][tid] = beta[tid] - (float)mean * scale;
+      if (save != nullptr) { save[tid] = (float)mean; save[C + tid] = rstd; }
+      if (rmean != nullptr) {
+        rmean[tid] = (1.f - momentum) * rmean[tid] + momentum * (float)mean;
+        rvar[tid] = (1.f - momentum) * rvar[tid] + momentum * (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+      }
+    }
+  } else if (tid < C) {
+    const float scale = gamma[tid] * rsqrtf(rvar[tid] + eps);
+    sc_sh[0][tid] = scale;
+    sc_sh[1][tid] = beta[tid] - rmean[tid] * scale;
+  }
+  __syncthreads();
+  if (y != nullptr && live) {
+    const float scale = sc_sh[0][c], shift = sc_sh[1][c];
+    for (int m0 = r; m0 < M; m0 += 8 * R) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (m0 + u * R < M) ? x[(size_t)(m0 + u * R) * C + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (m0 + u * R < M) y[(size_t)(m0 + u * R) * C + c] = v[u] * scale + shift;
+    }
+  }
+}
+
+// dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)),  dgamma = sum dy xhat,  dbeta = sum dy   (xhat = (x - mean) rstd)
+__global__ __launch_bounds__(BN_T) void bn_cl_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ gamma, const float* __restrict__ save,
+                                                         float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         int M, int C) {
+  __shared__ double red[2][BN_T];
+  __shared__ float coef[3][64];
+  const int tid = threadIdx.x, R = BN_T / C, r = tid / C, c = tid - r * C;
+  const bool live = r < R;
+  const float mean = live ? save[c] : 0.f, rstd = live ? save[C + c] : 0.f;
+  double s1 = 0.0, s2 = 0.0;
+  if (live)
+    for (int m0 = r; m0 < M; m0 += 8 * R) {
+      float g[8], v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool in = m0 + u * R < M;
+        g[u] = in ? dy[(size_t)(m0 + u * R) * C + c] : 0.f;
+        v[u] = in ? x[(size_t)(m0 + u * R) * C + c] : mean;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += (double)g[u]; s2 += (double)g[u] * (double)((v[u] - mean) * rstd); }
+    }
+  red[0][tid] = s1;
+  red[1][tid] = s2;
+  __syncthreads();
+  if (tid < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < R; ++k) { a += red[0][k * C + tid]; b += red[1][k * C + tid]; }
+    dbeta[tid] = (float)a;
+    dgamma[tid] = (float)b;
+    coef[0][tid] = gamma[tid] * save[C + tid];
+    coef[1][tid] = (float)(a / M);
+    coef[2][tid] = (float)(b / M);
+  }
+  __syncthreads();
+  if (dx != nullptr && live) {
+    const float k0 = coef[0][c], k1 = coef[1][c], k2 = coef[2][c];
+    for (int m0 = r; m0 < M; m0 += 8 * R) {
+      float g[8], v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool in = m0 + u * R < M;
+        g[u] = in ? dy[(size_t)(m0 + u * R) * C + c] : 0.f;
+        v[u] = in ? x[(size_t)(m0 + u * R) * C + c] : mean;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (m0 + u * R < M) dx[(size_t)(m0 + u * R) * C + c] = k0 * (g[u] - k1 - (v[u] - mean) * rstd * k2);
+    }
+  }
+}
+
 static int ew_check(int M, int N, const char* what) {
   if (M <= 0 || N <= 0 || (N & 3)) { set_error("%s: need M > 0, N > 0, N %% 4 == 0 (M=%d N=%d)", what, M, N); return HOPMI_EINVAL; }
   return HOPMI_OK;
@@ -376,4 +493,26 @@ extern "C" int hopmi_colsum(const void* x, int dtype, int M, int N, float* out, 
   }
   if (nchunk > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, nchunk, N, out);
   return check_launch("hopmi_colsum");
+}
+
+
+extern "C" int hopmi_bn_cl_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               float* y, float* save_mean_rstd, int M, int C, float eps, float momentum, int training, void* stream) {
+  if (M <= 0 || C <= 0 || C > 64) { set_error("hopmi_bn_cl_fwd: need M > 0 and 0 < C <= 64 (M=%d C=%d)", M, C); return HOPMI_EINVAL; }
+  if (!x || !gamma || !beta || (!training && (!running_mean || !running_var))) {
+    set_error("hopmi_bn_cl_fwd: null pointer argument");
+    return HOPMI_EINVAL;
+  }
+  hipLaunchKernelGGL(bn_cl_fwd_kernel, dim3(1), dim3(BN_T), 0, static_cast<hipStream_t>(stream), x, gamma, beta, running_mean,
+                     running_var, y, save_mean_rstd, M, C, eps, momentum, training);
+  return check_launch("hopmi_bn_cl_fwd");
+}
+
+extern "C" int hopmi_bn_cl_bwd(const float* x, const float* dy, const float* gamma, const float* save_mean_rstd, float* dx,
+                               float* dgamma, float* dbeta, int M, int C, void* stream) {
+  if (M <= 0 || C <= 0 || C > 64) { set_error("hopmi_bn_cl_bwd: need M > 0 and 0 < C <= 64 (M=%d C=%d)", M, C); return HOPMI_EINVAL; }
+  if (!x || !dy || !gamma || !save_mean_rstd || !dgamma || !dbeta) { set_error("hopmi_bn_cl_bwd: null pointer argument"); return HOPMI_EINVAL; }
+  hipLaunchKernelGGL(bn_cl_bwd_kernel, dim3(1), dim3(BN_T), 0, static_cast<hipStream_t>(stream), x, dy, gamma, save_mean_rstd, dx, dgamma,
+                     dbeta, M, C);
+  return check_launch("hopmi_bn_cl_bwd");
 }

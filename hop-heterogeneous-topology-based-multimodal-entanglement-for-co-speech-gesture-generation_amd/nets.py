@@ -177,21 +177,9 @@ class ConvDiscriminator(nn.Module):
 
     @staticmethod
     def _bn_cl(x, bn, training):
-        """BatchNorm1d on channels-last x (B,T,C), torch semantics (batch stats over B and T)."""
-        x = x.float()
-        if training:
-            # (statistics over the rows of the transposed copy: the library's reduction over the OUTER dimensions of a
-            # (4096, 16) tensor takes 45 us, over the inner dimension of (16, 4096) a fifth of that)
-            var, mean = torch.var_mean(x.reshape(-1, x.shape[-1]).t().contiguous(), dim=1, unbiased=False)
-            with torch.no_grad():
-                n = x.shape[0] * x.shape[1]
-                bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
-                bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
-                bn.num_batches_tracked += 1
-        else:
-            mean, var = bn.running_mean, bn.running_var
-        scale = bn.weight * torch.rsqrt(var + bn.eps)
-        return x * scale + (bn.bias - mean * scale)
+        """BatchNorm1d on channels-last x (B,T,C), torch semantics (batch stats over B and T): one launch forward, one backward
+        (ops.batch_norm_cl; as tensor operations the layer was ~12 + ~15 launches at the launch floor, on 256 KB of data)."""
+        return ops.batch_norm_cl(x, bn, training)
 
     def _pre_conv_cl(self, poses):
         """pre_conv (multimodal_context_net.py:226-234) without leaving the (B,T,C) layout; LeakyReLU(True)
@@ -208,7 +196,7 @@ class ConvDiscriminator(nn.Module):
         if not self.training:
             return
         x = self._bn_cl(self._conv3_cl(poses.detach(), self.pre_conv[0]), self.pre_conv[1], True)
-        self._bn_cl(self._conv3_cl(x, self.pre_conv[3]), self.pre_conv[4], True)
+        ops.batch_norm_cl_statistics(self._conv3_cl(x, self.pre_conv[3]), self.pre_conv[4])
 
     def forward(self, poses, in_text=None):
         # GEMM-shaped convs + the hand-written GRU recurrence (same cell as the decoder); like the generator this only

