@@ -198,11 +198,24 @@ class ConvDiscriminator(nn.Module):
         x = self._bn_cl(self._conv3_cl(poses.detach(), self.pre_conv[0]), self.pre_conv[1], True)
         ops.batch_norm_cl_statistics(self._conv3_cl(x, self.pre_conv[3]), self.pre_conv[4])
 
+    def _score(self, feat):
+        """Everything behind pre_conv (multimodal_context_net.py:255-268): per sample, nothing couples the batch."""
+        output = ops.gru_bidirectional(feat, self.gru, self.gru.dropout, self.training)
+        output = output[:, :, :self.hidden_size] + output[:, :, self.hidden_size:]
+        output = self.out(output.contiguous().view(-1, output.shape[2])).view(feat.shape[0], -1)
+        return torch.sigmoid(self.out2(output))
+
     def forward(self, poses, in_text=None):
         # GEMM-shaped convs + the hand-written GRU recurrence (same cell as the decoder); like the generator this only
         # runs on a ROCm device (ops.gru_bidirectional raises for host tensors: no second, stock-torch path)
-        feat = self._pre_conv_cl(poses)
-        output = ops.gru_bidirectional(feat, self.gru, self.gru.dropout, self.training)
-        output = output[:, :, :self.hidden_size] + output[:, :, self.hidden_size:]
-        output = self.out(output.contiguous().view(-1, output.shape[2])).view(poses.shape[0], -1)
-        return torch.sigmoid(self.out2(output))
+        return self._score(self._pre_conv_cl(poses))
+
+    def forward_pair(self, poses_a, poses_b, in_text=None):
+        """(D(poses_a), D(poses_b)) as the discriminator step scores the real and the generated batch (train_llm.py:25-26,
+        train_gan.py:40-41): pre_conv -- whose BatchNorm layers take their statistics per call -- runs on each batch on its own, in
+        that order; the GRU and the two linears behind it, which treat every sample on its own, run ONCE on both batches side by
+        side.  Same scores; half the recurrence launches of the step, and every parameter behind pre_conv is used once in the
+        backward instead of twice (no gradient fan-in adds)."""
+        fa, fb = self._pre_conv_cl(poses_a), self._pre_conv_cl(poses_b)
+        s = self._score(torch.cat([fa, fb], dim=0))
+        return s[:fa.shape[0]], s[fa.shape[0]:]

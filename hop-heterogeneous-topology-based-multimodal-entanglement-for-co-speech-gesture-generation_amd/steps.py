@@ -19,6 +19,8 @@ fetched with one asynchronous device->host copy that is started before the gener
 """
 import contextlib
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -163,6 +165,8 @@ class _LossFetch:
 ELIDE_UNUSED_SCORE = True
 # the loss recipe of train_llm.py:46-79 as one fused op (ops.hop_losses) instead of ~75 tensor operations
 FUSED_LOSSES = True
+# discriminator step: the per-sample part of the discriminator (GRU, linears) once on the real and the generated batch side by side
+PAIRED_DISCRIMINATOR = os.environ.get("HOPMI_PAIRED_D", "1") != "0"
 
 
 def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,
@@ -176,8 +180,13 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
             with _amp(args, target_dir_vec):
                 with torch.no_grad():                                          # only used detached (:24)
                     outputs, *_ = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
-                dis_real = discriminator(add_noise(target_dir_vec), text_token_padded)
-                dis_fake = discriminator(add_noise(outputs.detach().float()), text_token_padded)
+                real, fake = add_noise(target_dir_vec), add_noise(outputs.detach().float())
+                pair = getattr(_unwrap(discriminator), "forward_pair", None) if PAIRED_DISCRIMINATOR else None
+                if pair is not None:                                           # (nets.ConvDiscriminator: same scores, see there)
+                    dis_real, dis_fake = pair(real, fake, text_token_padded)
+                else:
+                    dis_real = discriminator(real, text_token_padded)
+                    dis_fake = discriminator(fake, text_token_padded)
                 dis_error = torch.sum(-torch.mean(torch.log(dis_real.float() + 1e-8) + torch.log(1 - dis_fake.float() + 1e-8)))
             _backward(accelerator, dis_error, discriminator)
             dis_optimizer.step()
