@@ -39,7 +39,8 @@ def main():
     # move every element of them by +-lr per step on rounding noise, a random walk that differs between the two exchange paths
     # and, through the forward, perturbs every other gradient by per cent within a few steps (tools/probes/grad_sensitivity.py).
     # They are frozen here so that the comparison measures the exchange paths, not that walk.
-    noise = lambda n: n.endswith("mlp.mlp.bias") or n in ("pre_conv.0.bias", "pre_conv.3.bias") or n.endswith("key_projection.bias")
+    # (pre_conv.1.bias: the shift of the first BatchNorm, which the next conv turns into a per-channel constant in front of the second)
+    noise = lambda n: n.endswith("mlp.mlp.bias") or n in ("pre_conv.0.bias", "pre_conv.1.bias", "pre_conv.3.bias") or n.endswith("key_projection.bias")
     for mod in (m1, d1):
         for n, p in mod.named_parameters():
             if noise(n):
@@ -168,6 +169,7 @@ def main():
                                         short_was_eager=short_was_eager, replica_spread2=spread2,
                                         worst2_max=max(v[0] for v in worst2.values()),
                                         worst2_mean=max(v[1] for k, v in worst2.items() if not noise(k)),
+                                        top2_mean=sorted(((round(v[1], 7), k) for k, v in worst2.items() if not noise(k)), reverse=True)[:6],
                                         top_mean=sorted(((round(v[1], 7), k) for k, v in worst.items() if not noise(k)), reverse=True)[:6])),
           flush=True)
     dist.barrier()
