@@ -18,6 +18,29 @@ from . import ops
 DILATIONS = (1, 2, 1, 2, 1, 2, 1, 2)            # gwnet.py:98-121 with blocks=4, layers=2
 
 
+class _SkipPack(torch.autograd.Function):
+    """The eight skip convs' weights side by side (256, 8 x 64) and their biases summed, as the one K = 512 GEMM of `_tail`
+    reads them.  As tensor operations (cat / stack + sum) the backward hands every parameter a strided or expanded view of the
+    packed gradient, which autograd then copies one launch at a time (16 launches); here the packed weight gradient is brought
+    into layer-major order once and the bias gradient replicated once, and the parameters receive contiguous views."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        n = len(params) // 2
+        ctx.n = n
+        ws = torch.cat([w.flatten(1) for w in params[:n]], 1)
+        bs = torch.stack(params[n:]).sum(0)
+        return ws, bs
+
+    @staticmethod
+    def backward(ctx, dws, dbs):
+        n = ctx.n
+        O = dws.shape[0]
+        dw = dws.reshape(O, n, -1).permute(1, 0, 2).contiguous()                      # (n, 256, 64): one copy
+        db = dbs.unsqueeze(0).expand(n, O).contiguous()                               # (n, 256): one copy
+        return (*[g.reshape(O, -1, 1, 1) for g in dw.unbind(0)], *db.unbind(0))
+
+
 class _WaveNetStackFn(torch.autograd.Function):
     """The 8 fused WaveNet layers, training mode, differentiable: x0 (B,T,V,64) start-conv output ->
     (B,4,V,512) skip tails.  Forward = 8 hopmi_wn_layer_fwd calls (BatchNorm batch statistics, running
@@ -305,8 +328,7 @@ class gwnet(nn.Module):
 
     def _tail(self, tails):
         """skip 1x1 convs summed over layers (one K=512 GEMM), relu, end convs: gwnet.py:209-220,240-246."""
-        ws = torch.cat([c.weight.flatten(1) for c in self.skip_convs], 1)               # (256, 8*64)
-        bs = torch.stack([c.bias for c in self.skip_convs]).sum(0)
+        ws, bs = _SkipPack.apply(*[c.weight for c in self.skip_convs], *[c.bias for c in self.skip_convs])   # (256, 8*64), (256,)
         s = F.relu(ops.linear(tails, ws, bs))
         s = F.relu(ops.linear(s, self.end_conv_1.weight.flatten(1), self.end_conv_1.bias))
         return ops.linear(s, self.end_conv_2.weight.flatten(1), self.end_conv_2.bias)
