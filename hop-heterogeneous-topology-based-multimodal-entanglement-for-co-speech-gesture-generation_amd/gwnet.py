@@ -132,7 +132,12 @@ class _WaveNetStackFn(torch.autograd.Function):
             P0n, P1n, coef = r["P0"], r["P1"], r["coef_prev"]
         # gradient w.r.t. x0: tap 0 lands on frame t, tap 1 (+ residual) on frame t + d of layer 0
         d0 = DILATIONS[0]
-        dx0 = F.pad(P0n, (0, 0, 0, 0, 0, d0)) + F.pad(P1n, (0, 0, 0, 0, d0, 0))
+        if P0n.shape[1] >= d0:
+            # (the same sums as the two padded tensors added, without the two fills and two copies of the padding: one add on
+            # the frames both taps reach, one concatenation)
+            dx0 = torch.cat([P0n[:, :d0], P0n[:, d0:] + P1n[:, :P1n.shape[1] - d0], P1n[:, P1n.shape[1] - d0:]], dim=1)
+        else:
+            dx0 = F.pad(P0n, (0, 0, 0, 0, 0, d0)) + F.pad(P1n, (0, 0, 0, 0, d0, 0))
         flat = [t for tup in g_tcn for t in tup] + [t for tup in g_mlp for t in tup] + [t for tup in g_aff for t in tup]
         return (dx0, dA1, dA2, None, None, None, None, *flat)
 
