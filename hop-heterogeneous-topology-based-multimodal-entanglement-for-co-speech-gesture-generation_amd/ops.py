@@ -3,6 +3,8 @@
 Every op requires ROCm device tensors and the built libhopmi.so; there is deliberately
 no eager / CPU implementation here (the CPU oracle lives in oracle/, test-only).
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -300,6 +302,7 @@ def cut_point(t):
 
 
 # ------------------------------------------------------- frozen-weight linears on split-bf16 MFMA (hopmi_gemm_split)
+CAST_CACHE_ENABLED = __import__("os").environ.get("HOPMI_CAST_CACHE", "1") != "0"
 GEMM_PARTS = 3      # 3: six-term split (fp32-equivalent, default);  2: three-term split (2^-16 class);  0: library fp32 GEMM (hipBLASLt)
 
 
@@ -622,15 +625,34 @@ def _mm_f32(a, b):
     return torch.mm(a, b, out_dtype=torch.float32) if _MM_F32_OUT else (a @ b).float()
 
 
+_CAST_CACHE = {}    # id(parameter) -> (weak reference, version, dtype, cast copy)
+
+
+def _cast_param(w, dt):
+    """`w.to(dt)` for an operand of `_LinearFn` under autocast.  A step runs every trainable linear in two forwards (the graded one
+    and the no-grad one of the diversity regulariser) between two optimizer steps: for an nn.Parameter -- an object that outlives
+    the call, so its identity + version counter say whether the copy is current -- the second forward reuses the first one's
+    copy.  Anything else (a temporary such as a packed weight: ids and versions of temporaries repeat) is cast on the spot."""
+    if not CAST_CACHE_ENABLED or not isinstance(w, torch.nn.Parameter):
+        return w.to(dt)
+    hit = _CAST_CACHE.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == dt:
+        return hit[3]
+    c = w.detach().to(dt)
+    _CAST_CACHE[id(w)] = (weakref.ref(w), w._version, dt, c)
+    return c
+
+
 class _LinearFn(torch.autograd.Function):
     """torch.nn.functional.linear whose backward takes the bias gradient with hopmi_colsum (the library's column reduction
     is the slowest piece of a trainable linear layer's backward here).  Under autocast the operands are cast as
     F.linear's autocast rule does and both gradient GEMMs run in that type; the results are handed back in the
     parameters' types (HOPMI_MM_F32=1: the weight gradient straight from the GEMM's fp32 accumulators, no rounding to bf16 and
     no cast launch -- 0.9 % slower on the bf16 step with the library's default kernel selection, so not the default).
-    (Tried and dropped in round 3: persistent bf16 shadows of the parameters, re-cast in one multi-tensor copy per step -- no
-    measurable gain on the bf16 step, and a cache keyed on storage is wrong for temporaries such as gwnet's concatenated skip
-    weights, whose address the allocator recycles.)"""
+    (Round 3: a cast of an nn.Parameter operand is reused by the step's second forward, `_cast_param` below: -0.04 ms on the bf16
+    step.  Tried and dropped: persistent bf16 shadows of all parameters, re-cast in one multi-tensor copy per step -- no measurable
+    gain, and a cache keyed on storage is wrong for temporaries such as gwnet's packed skip weights, whose address the allocator
+    recycles.)"""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -639,8 +661,8 @@ class _LinearFn(torch.autograd.Function):
         if amp:
             dt = torch.get_autocast_dtype("cuda")
             xc = x if x.dtype == dt else x.to(dt)
-            wc = w if w.dtype == dt else w.to(dt)
-            bc = b if (b is None or b.dtype == dt) else b.to(dt)
+            wc = w if w.dtype == dt else _cast_param(w, dt)
+            bc = b if (b is None or b.dtype == dt) else _cast_param(b, dt)
         with torch.autocast("cuda", enabled=False):
             y = torch.nn.functional.linear(xc.reshape(-1, xc.shape[-1]), wc, bc)
         ctx.save_for_backward(xc, wc)
