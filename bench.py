@@ -320,9 +320,15 @@ def main():
                                       "2 generator forwards (the graded one + the no-grad forward of the diversity regulariser, "
                                       "train_llm.py:58) + 1 backward + Adam on 65.7 M parameters")
                                    + "; inside one step the batch-independent prototype branch (mapping layer, K/V projections) and the "
-                                     "dropout-free audio branch (beat MLP, gwnet: 8 fused-layer launches) are computed ONCE and reused by the "
+                                     "dropout-free audio branch (beat MLP, gwnet: one persistent launch for the 8 fused layers) are computed ONCE and reused by the "
                                      "step's other forwards, whose BatchNorm running-statistics update is replayed on the same partial "
                                      "sums (bit-identical to recomputing, tests/test_gpu_parity.py::test_step_cache_audio_branch_equals_recompute)"
+                                   + ("; in the discriminator step the discriminator's per-sample part (GRU, linears) runs once on the real and "
+                                      "the generated batch side by side (pre_conv with its per-call BatchNorm statistics separately); in the "
+                                      "generator step the discriminator's own parameter gradients, which train_llm.py never uses (only "
+                                      "model_optim steps; the next discriminator step starts with zero_grad), are not computed (bit-identical "
+                                      "losses, parameters and buffers, tests/test_gpu_parity.py::test_train_llm_unused_discriminator_grads_elision)"
+                                      if gan else "")
                                    + ("" if gan else "; the discriminator score that train_llm.py:43-44 computes in every epoch and :81 never "
                                       "uses before epoch 11 is not computed, only its lasting effect (the BatchNorm statistics update of the "
                                       "discriminator's pre_conv) is (bit-identical losses, parameters and buffers, "

@@ -1354,6 +1354,7 @@ class _GruLayerFn(torch.autograd.Function):
             H = H2 // 2
             L, st = _lib.lib(), _stream()
             # the recurrence's W_hh^T and the shifted states for dW_hh: one launch (was a transpose copy, a fill, two strided copies)
+            want_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             whhT = torch.empty(2, H, 3 * H, dtype=torch.float32, device=y.device)
             hprev = torch.empty(B, T, 2, H, dtype=torch.float32, device=y.device)
             _lib.check(L.hopmi_gru_bwd_operands(y.data_ptr(), whh.data_ptr(), hprev.data_ptr(), whhT.data_ptr(), B, T, H, st),
@@ -1373,6 +1374,8 @@ class _GruLayerFn(torch.autograd.Function):
                 raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
             # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
             # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
+            if not want_dw:                    # (frozen recurrent weights, e.g. the discriminator inside the generator's step)
+                return dgi, None, None
             dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
             dbhh = colsum(dgh.view(B * T, 6 * H)).view(2, 3 * H)
         return dgi, dwhh, dbhh

@@ -165,8 +165,33 @@ class _LossFetch:
 ELIDE_UNUSED_SCORE = True
 # the loss recipe of train_llm.py:46-79 as one fused op (ops.hop_losses) instead of ~75 tensor operations
 FUSED_LOSSES = True
+# generator step of the GAN phase: the discriminator's PARAMETER gradients are not computed.  train_llm.py:43,85 back-propagates
+# gen_error through the discriminator into the generator; the gradients that pass leaves in the discriminator's own parameters
+# on the way are never used -- only model_optim steps (:86), and the next discriminator step begins with dis_optimizer.zero_grad()
+# (:17).  Same losses, same parameters and buffers of both networks after every step (bitwise: the data gradient does not depend
+# on them; tests/test_gpu_parity.py::test_train_llm_unused_discriminator_grads_elision); what differs is the content of
+# discriminator.parameters()[i].grad between the two optimizers' steps: the discriminator step's gradients instead of their sum
+# with the generator step's.
+ELIDE_UNUSED_D_GRADS = os.environ.get("HOPMI_ELIDE_D_GRADS", "1") != "0"
 # discriminator step: the per-sample part of the discriminator (GRU, linears) once on the real and the generated batch side by side
 PAIRED_DISCRIMINATOR = os.environ.get("HOPMI_PAIRED_D", "1") != "0"
+
+
+class _params_take_no_grad:
+    """Within the block, `module`'s parameters do not require a gradient: a forward recorded here back-propagates to its inputs
+    only (autograd decides at forward time what a backward will compute)."""
+
+    def __init__(self, module, active=True):
+        self.ps = [p for p in module.parameters() if p.requires_grad] if active else []
+
+    def __enter__(self):
+        for p in self.ps:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.ps:
+            p.requires_grad_(True)
+        return False
 
 
 def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices,
@@ -195,7 +220,8 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
         with _amp(args, target_dir_vec):
             outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
             if epoch > 10 or not ELIDE_UNUSED_SCORE:
-                dis_output = discriminator(outputs, text_token_padded)
+                with _params_take_no_grad(discriminator, epoch > 10 and ELIDE_UNUSED_D_GRADS):
+                    dis_output = discriminator(outputs, text_token_padded)
                 gen_error = -torch.mean(torch.log(dis_output.float() + 1e-8))
             else:
                 # train_llm.py:43-44 scores the output here in every epoch, and :81 leaves gen_error out of the loss and of

@@ -1042,6 +1042,44 @@ def test_train_llm_unused_score_elision(monkeypatch):
     assert not torch.equal(da["pre_conv.1.running_mean"], torch.zeros_like(da["pre_conv.1.running_mean"]))
 
 
+def test_train_llm_unused_discriminator_grads_elision(monkeypatch):
+    """GAN phase: train_llm.py:43,85 back-propagates gen_error through the discriminator into the generator; what that leaves in
+    the discriminator's own parameter gradients is never used (only model_optim steps, :86; the next discriminator step starts
+    with dis_optimizer.zero_grad(), :17).  steps.train_llm does not compute them: three consecutive GAN-phase steps with and
+    without the elision return the same loss dicts and leave every parameter and buffer of both networks bit-identical; and the
+    elision really removes something (the discriminator's gradients behind the step are the discriminator step's alone)."""
+    import hopmi
+    from hopmi import steps
+    from oracle import fill
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    V = 9
+    monkeypatch.setattr(steps, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
+    monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))
+    out = []
+    for elide in (True, False):
+        monkeypatch.setattr(steps, "ELIDE_UNUSED_D_GRADS", elide)
+        m, bcfg = _make_model(V, dev)
+        d = hopmi.ConvDiscriminator(3 * V)
+        d.gru.dropout = 0.0
+        fill.fill_state_(d, salt=1)
+        d.to(dev)
+        m.train(); d.train()
+        g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+        d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        inp = _inputs(V, bcfg, dev)
+        torch.manual_seed(777)
+        rets = [hopmi.train_llm(step_args(V), 11, inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"],
+                                inp["vid_indices"], m, d, g_opt, d_opt, Accel()) for _ in range(3)]
+        assert all(p.requires_grad for p in d.parameters())
+        out.append((rets, {k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in d.state_dict().items()},
+                    {n: p.grad.clone() for n, p in d.named_parameters()}))
+    (ra, ma, da, ga), (rb, mb, db, gb) = out
+    assert ra == rb
+    assert all(torch.equal(ma[k], mb[k]) for k in ma) and all(torch.equal(da[k], db[k]) for k in da)
+    assert any(not torch.equal(ga[n], gb[n]) for n in ga)          # without the elision the generator step adds into them
+
+
 _FULL = {}      # (V, B, epoch) -> the oracle's full-size step (loss dict, outputs, post-step state), computed once per session
 
 
