@@ -206,7 +206,10 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
                 with torch.no_grad():                                          # only used detached (:24)
                     outputs, *_ = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
                 real, fake = add_noise(target_dir_vec), add_noise(outputs.detach().float())
-                pair = getattr(_unwrap(discriminator), "forward_pair", None) if PAIRED_DISCRIMINATOR else None
+                # (a wrapped discriminator -- DistributedDataParallel, accelerate -- is called through its wrapper only: the wrapper's
+                # forward is what arms its gradient synchronisation)
+                plain = _unwrap(discriminator) is discriminator
+                pair = getattr(discriminator, "forward_pair", None) if (PAIRED_DISCRIMINATOR and plain) else None
                 if pair is not None:                                           # (nets.ConvDiscriminator: same scores, see there)
                     dis_real, dis_fake = pair(real, fake, text_token_padded)
                 else:
@@ -220,7 +223,8 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
         with _amp(args, target_dir_vec):
             outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
             if epoch > 10 or not ELIDE_UNUSED_SCORE:
-                with _params_take_no_grad(discriminator, epoch > 10 and ELIDE_UNUSED_D_GRADS):
+                # (not under a wrapper that counts on a gradient for every parameter of every forward it has seen, see above)
+                with _params_take_no_grad(discriminator, epoch > 10 and ELIDE_UNUSED_D_GRADS and _unwrap(discriminator) is discriminator):
                     dis_output = discriminator(outputs, text_token_padded)
                 gen_error = -torch.mean(torch.log(dis_output.float() + 1e-8))
             else:
