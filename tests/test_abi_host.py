@@ -120,3 +120,25 @@ def test_host_switches_without_a_device():
             hopmi.mixed_precision("fp8")
     finally:
         hopmi.mixed_precision(prev)
+
+
+def test_skip_pack_gradients_equal_cat_stack_composition():
+    """gwnet._SkipPack (the eight skip convs' weights side by side, biases summed, through one autograd function) against the
+    tensor-operation recipe it replaces (torch.cat / torch.stack + sum): same packed tensors, same gradients for every
+    parameter, bit for bit (pure torch: runs on the host)."""
+    import torch
+    import importlib
+    import hopmi  # noqa: F401
+    gwnet = importlib.import_module("hopmi.gwnet")              # (the package exports the class under the same name)
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(256, 64, 1, 1, generator=g, requires_grad=True) for _ in range(8)]
+    bs = [torch.randn(256, generator=g, requires_grad=True) for _ in range(8)]
+    gw, gb = torch.randn(256, 512, generator=g), torch.randn(256, generator=g)
+    pw, pb = gwnet._SkipPack.apply(*ws, *bs)
+    rw = torch.cat([w.flatten(1) for w in ws], 1)
+    rb = torch.stack(bs).sum(0)
+    assert torch.equal(pw, rw) and torch.equal(pb, rb)
+    got = torch.autograd.grad([pw, pb], ws + bs, [gw, gb])
+    want = torch.autograd.grad([rw, rb], ws + bs, [gw, gb])
+    for a, b, p in zip(got, want, ws + bs):
+        assert a.shape == p.shape and a.is_contiguous() and torch.equal(a, b)
