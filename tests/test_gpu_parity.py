@@ -1553,6 +1553,29 @@ def test_gemm_split_vs_float64(M, N, K, parts, tol):
     assert torch.equal(y_ab, y.detach())
 
 
+@pytest.mark.parametrize("B,T,H", [(128, 34, 350), (5, 28, 64), (3, 1, 6), (130, 9, 18)])
+def test_gru_backward_operands_one_launch(B, T, H):
+    """hopmi_gru_bwd_operands: W_hh^T per direction and the shifted states of a layer's backward (h_prev of step t: y one step
+    earlier in the forward direction, one step later in the reverse direction, zero at each direction's first step) against the
+    tensor operations they replace -- bit for bit (copies)."""
+    import ctypes
+    from hopmi import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + T + H)
+    y = torch.randn(B, T, 2 * H, generator=g).to(dev)
+    whh = torch.randn(2, 3 * H, H, generator=g).to(dev)
+    hprev = torch.full((B, T, 2, H), float("nan"), device=dev)
+    whhT = torch.full((2, H, 3 * H), float("nan"), device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().hopmi_gru_bwd_operands(y.data_ptr(), whh.data_ptr(), hprev.data_ptr(), whhT.data_ptr(), B, T, H, st), "operands")
+    yv = y.view(B, T, 2, H)
+    want = torch.zeros_like(yv)
+    want[:, 1:, 0] = yv[:, :-1, 0]
+    want[:, :-1, 1] = yv[:, 1:, 1]
+    assert torch.equal(hprev, want)
+    assert torch.equal(whhT, whh.transpose(1, 2).contiguous())
+
+
 @pytest.mark.parametrize("B,T,C", [(128, 32, 16), (64, 30, 8), (3, 5, 7), (2, 1, 64), (128, 32, 48)])
 def test_batch_norm_channels_last_vs_torch_float64(B, T, C):
     """ops.batch_norm_cl (hopmi_bn_cl_fwd / _bwd: the discriminator's BatchNorm1d layers, multimodal_context_net.py:226-234, on
