@@ -109,7 +109,7 @@ def cpu_baseline(args, V):
     return out
 
 
-def roofline(ks, V, B, n_kernel_steps):
+def roofline(ks, V, B, n_kernel_steps, dtype="fp32"):
     """The roofline object from the kernel region's event timings.  The graded kernel is the fused WaveNet forward: as ONE
     persistent launch per training forward (hopmi_wn_stack_fwd: 8 layers incl. the BatchNorm statistics exchange) when the
     run used it, else the per-layer launches (hopmi_wn_layer_fwd)."""
@@ -124,7 +124,7 @@ def roofline(ks, V, B, n_kernel_steps):
     try:
         with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_traffic.json")) as f:
             t = json.load(f)
-        if t.get("V") == V and t.get("B") == B:
+        if t.get("V") == V and t.get("B") == B and dtype == "fp32":     # (the PMC passes ran the fp32 configuration)
             traffic = t["kernels"][name]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         traffic = None
@@ -359,7 +359,7 @@ def main():
                        "losses": last},
         }
         if ks is not None:
-            out["roofline"] = roofline(ks, V, B, args.kernel_steps)
+            out["roofline"] = roofline(ks, V, B, args.kernel_steps, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V)
         print(json.dumps(out), flush=True)
