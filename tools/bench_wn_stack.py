@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--stamps", action="store_true")
     ap.add_argument("--build-stamps", action="store_true")
     ap.add_argument("--lib", default=None, help="alternative libhopmi.so (timing experiments)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="storage type of x0, the saved y_l and the skip tails")
     a = ap.parse_args()
     if a.build_stamps:
         build_stamps()
@@ -58,12 +59,13 @@ def main():
     torch.manual_seed(0)
     m = hopmi.gwnet(None, a.V, dropout=0, supports=None, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=173, out_dim=173,
                     residual_channels=64, dilation_channels=64, skip_channels=256, end_channels=512).to(dev).train()
-    x0 = torch.randn(a.B, 16, a.V, 64, device=dev)
+    sdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    x0 = torch.randn(a.B, 16, a.V, 64, device=dev).to(sdt)
     A1, A2 = m.adjacency()
     A1, A2 = A1.detach(), A2.detach()
     prep = ops.gcn_prepare(A1, A2)
     wimg = m._weight_images()
-    tails = torch.empty(a.B, 4, a.V, 512, device=dev)
+    tails = torch.empty(a.B, 4, a.V, 512, device=dev, dtype=sdt)
     tcn_b = [(m.filter_convs[i].bias.detach(), m.gate_convs[i].bias.detach()) for i in range(8)]
     mlp_b = [m.gconv[i].mlp.mlp.bias.detach() for i in range(8)]
     bns = list(m.bn)
@@ -78,7 +80,7 @@ def main():
     print(f"V={a.V} B={a.B}: persistent grid {grid}")
     nbytes, flops, T = 0, 0, 16
     for l, d in enumerate(DIL):
-        nbytes += 4 * 64 * a.V * (a.B * T + (a.B * (T - d) if l < 7 else 0) + 4 * a.B)
+        nbytes += (2 if a.dtype == "bf16" else 4) * 64 * a.V * (a.B * T + (a.B * (T - d) if l < 7 else 0) + 4 * a.B)
         flops += a.B * (T - d) * a.V * (2 * 2 * 2 * 64 * 64 + 2 * 192 * 64 + 4 * 64 * a.V)
         T -= d
     stack = lambda: ops.wn_stack_fwd(x0, wimg, tcn_b, prep, mlp_b, bns, tails, DIL)
