@@ -44,9 +44,10 @@ def parse():
                     help="fp32 = the headline configuration (configs[1]); bf16 = configs 2/4 (bf16 GEMMs + bf16 gradient exchange)")
     ap.add_argument("--eager", action="store_true", help="time steps.train_llm itself instead of its recorded hipGraphs")
     ap.add_argument("--kernel-steps", type=int, default=6, help="instrumented eager steps for the roofline object (0 = none)")
-    ap.add_argument("--bert-gemm", default="split3", choices=["library", "split3", "split2"],
-                    help="the frozen BERT's linears: the library's fp32 GEMM, or hopmi_gemm_split with 3 bf16 parts per operand "
-                         "(six MFMA terms: fp32-equivalent, default) or 2 parts (three terms: 2^-16-class products)")
+    ap.add_argument("--bert-gemm", default="f16x2", choices=["library", "f16x2", "split3", "split2"],
+                    help="the frozen BERT's linears: the library's fp32 GEMM; hopmi_gemm_f16x2 (two scaled fp16 parts per operand, "
+                         "three MFMA terms: fp32-equivalent, default); hopmi_gemm_split with 3 bf16 parts per operand (six MFMA terms: "
+                         "fp32-equivalent) or 2 parts (three terms: 2^-16-class products)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
     ap.add_argument("--tuned-table", default=None, help="another TunableOp table than the shipped one (A/B runs)")
     ap.add_argument("--flat-exchange", action="store_true",
@@ -203,7 +204,7 @@ def main():
     V = 9 if args.dataset == "TED" else 42
     B = args.batch
     hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
-    hopmi.gemm_parts({"library": 0, "split3": 3, "split2": 2}[args.bert_gemm])      # (fp32 mode only: bf16 mode autocasts)
+    hopmi.gemm_parts({"library": 0, "f16x2": 16, "split3": 3, "split2": 2}[args.bert_gemm])      # (fp32 mode only: bf16 mode autocasts)
     tuned = (not args.no_tuned_gemms) and hopmi.use_tuned_gemms(args.tuned_table)      # (the table holds fp32 and bf16 shapes)
     torch.manual_seed(0)                                       # identical replicas
     model = hopmi.Model(synth.model_configs(args.dataset), synth.build_bert(6), synth.SyntheticTokenizer(),
@@ -352,6 +353,8 @@ def main():
                                      "(three-term split-bf16 kernels: within K x the fp32 reference's own error, K stated per test)",
                        "bert_gemm": ("library bf16 GEMMs (autocast)" if args.dtype != "fp32" else
                                      {"library": "library fp32 GEMMs (hipBLASLt)",
+                                      "f16x2": "hopmi_gemm_f16x2, 2 power-of-two-scaled fp16 parts per operand, 3 MFMA terms: fp32-equivalent "
+                                               "(error vs float64 equal to the library's fp32 GEMM, tests/test_gpu_parity.py::test_gemm_split_vs_float64)",
                                       "split3": "hopmi_gemm_split, 3 bf16 parts per operand, 6 MFMA terms: fp32-equivalent (error vs float64 "
                                                 "equal to the library's fp32 GEMM, tools/bench_gemm.py)",
                                       "split2": "hopmi_gemm_split, 2 bf16 parts per operand, 3 MFMA terms (2^-16-class products)"}[args.bert_gemm]),

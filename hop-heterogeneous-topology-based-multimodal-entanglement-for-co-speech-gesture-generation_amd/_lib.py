@@ -18,6 +18,8 @@ SIGNATURES = {
     "hopmi_version": (ctypes.c_char_p, []),
     "hopmi_last_error": (ctypes.c_char_p, []),
     "hopmi_reload_env": (None, []),
+    "hopmi_stream_capture_status": (_I, [_VP, ctypes.POINTER(ctypes.c_int)]),
+    "hopmi_stream_capture_abandon": (_I, [_VP]),
     "hopmi_gcn_prep_floats": (ctypes.c_size_t, [_I]),
     "hopmi_gcn_prepare": (_I, [_VP, _VP, _VP, _I, _VP]),
     "hopmi_gcn_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
@@ -73,6 +75,8 @@ SIGNATURES = {
     "hopmi_gemm_split_prepare": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hopmi_gemm_split": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gemm_split_ab": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "hopmi_row_scales": (_I, [_VP, _I, _I, _VP, _VP]),
+    "hopmi_gemm_f16x2": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gemm_split_ep": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "hopmi_gru_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_gru_fwd": (_I, [_VP] * 6 + [_I, _I, _I, _VP]),

@@ -58,3 +58,36 @@ extern "C" void hopmi_reload_env(void) {
   std::lock_guard<std::mutex> lk(hopmi::g_env_mu);
   hopmi::g_env_n.store(0, std::memory_order_release);
 }
+
+// ---- stream-capture hygiene (hopmi/graph.py): look before ending a capture that an exception interrupted
+extern "C" int hopmi_stream_capture_status(void* stream, int* status) {
+  if (!status) return HOPMI_EINVAL;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    // a query on an invalidated capture may itself be answered with the invalidation error: that IS the answer
+    if (e == hipErrorStreamCaptureInvalidated) { *status = 2; return HOPMI_OK; }
+    hopmi::set_error("hipStreamIsCapturing: %s", hipGetErrorString(e));
+    return HOPMI_ELAUNCH;
+  }
+  *status = st == hipStreamCaptureStatusActive ? 1 : st == hipStreamCaptureStatusInvalidated ? 2 : 0;
+  return HOPMI_OK;
+}
+
+extern "C" int hopmi_stream_capture_abandon(void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &g);
+  (void)hipGetLastError();                       // (an invalidated capture answers with its error: expected, not sticky)
+  if (g) (void)hipGraphDestroy(g);
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipError_t q = hipStreamIsCapturing(s, &st);
+  (void)hipGetLastError();
+  if (q != hipSuccess || st != hipStreamCaptureStatusNone) {
+    hopmi::set_error("hipStreamEndCapture: %s; the stream is still in capture mode (%s)", hipGetErrorString(e),
+                     q != hipSuccess ? hipGetErrorString(q) : st == hipStreamCaptureStatusActive ? "active" : "invalidated");
+    return HOPMI_ELAUNCH;
+  }
+  return HOPMI_OK;
+}

@@ -20,6 +20,8 @@
 // of one XCD walk one panel of A against consecutive panels of B, so both stay in that XCD's L2.
 #include "bf16_dev.h"
 
+#include <cstdint>
+
 namespace hopmi {
 
 #ifdef HOPMI_STAMPS
@@ -54,6 +56,106 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NP]
   }
 }
 
+// ---- the fp16 hi/lo form (round 4): TWO parts per operand, THREE terms, fp32-equivalent ------------------------------------
+// x s = h + l with h = fp16(x s), l = fp16(x s - h): 11 + 11 significand bits, |x s - h - l| <= 2^-22 |x s|; the product is taken as
+// h_a h_b + h_a l_b + l_a h_b (the dropped l_a l_b is <= 2^-22 |a b|) on v_mfma_f32_16x16x32_f16 (the bf16 instruction's rate; the
+// 22-bit products are exact in the fp32 accumulator).  Per product that is a few 2^-23 -- below what the fp32 ACCUMULATION of a
+// K >= 128 dot product leaves, measured: the same error against float64 as the six-term bf16 form and the library's fp32 GEMM
+// (tests/test_gpu_parity.py::test_gemm_split_vs_float64) at HALF the matrix instructions.  fp16 has 5 exponent bits, so every operand
+// is scaled by a power of two s (exact) that puts its largest magnitude in [2^14, 2^15): the lo part of every element within 2^-17
+// of the maximum is a normal fp16 number; smaller elements carry an absolute error <= 2^-39 of the maximum.  The weights' scale is
+// found when their image is prepared (frozen: once; one scale per tensor); the activations get one scale PER ROW (an output
+// element only ever sees one row of A, so rows of very different magnitude -- gradient rows -- do not share a window), written by
+// hopmi_row_scales (one wave per row) or by whichever kernel produced A.  The epilogue multiplies the accumulators by
+// 2^-(s_a[row] + s_b) (exact).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// two (already scaled) floats -> packed fp16 hi pair, packed fp16 lo pair (round to nearest even; x - hi is exact in fp32)
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned (&out)[2]) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 hi = {(_Float16)a, (_Float16)b};
+  const h2 lo = {(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1])};
+  out[0] = __builtin_bit_cast(unsigned, hi);
+  out[1] = __builtin_bit_cast(unsigned, lo);
+}
+constexpr int F16_PARTS = 16;                      // the `parts` code of this form at the C ABI ("two fp16 parts")
+constexpr int AMAX_N = 256;                        // per-block maxima of hopmi_absmax_partials
+// power-of-two scale for a tensor whose largest magnitude has the bits `m` (sign cleared): max * s in [2^14, 2^15); 1 for an
+// all-zero / subnormal / non-finite tensor (a NaN or infinity then travels through the products as itself)
+__device__ __forceinline__ unsigned scale_bits_for_max(unsigned m) {
+  const int e = (int)(m >> 23);
+  const int sb = (e == 0 || e == 255) ? 127 : min(268 - e, 250);
+  return (unsigned)sb << 23;
+}
+__device__ __forceinline__ float inv_scale(unsigned scale_bits) { return __uint_as_float((254u << 23) - scale_bits); }
+// max over part[0 .. 255] (as sign-cleared bit patterns), by all threads of a block of >= 256 threads; `sh` = 16 words of LDS
+__device__ __forceinline__ unsigned block_amax(const float* __restrict__ part, unsigned* sh) {
+  unsigned v = threadIdx.x < AMAX_N ? (__float_as_uint(part[threadIdx.x]) & 0x7fffffffu) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned m = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = max(m, sh[w]);
+  __syncthreads();
+  return m;
+}
+
+// per-block maxima of |x| over a grid-stride share (n % 4 == 0): part[blockIdx.x], AMAX_N blocks
+__global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ part) {
+  __shared__ unsigned sh[4];
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)AMAX_N * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+        max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = __uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+}
+
+// per-row power-of-two scales of A [M][K] (K % 4 == 0): out[row] = s, out[M + row] = 1 / s; one wave per row
+__global__ __launch_bounds__(256) void row_scales_kernel(const float* __restrict__ A, int M, int K, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float4* src = reinterpret_cast<const float4*>(A + (size_t)row * K);
+  unsigned m = 0;
+  for (int i = lane; i < K / 4; i += 64) {
+    const float4 v = src[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+        max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if (lane == 0) {
+    const unsigned sb = scale_bits_for_max(m);
+    out[row] = __uint_as_float(sb);
+    out[M + row] = inv_scale(sb);
+  }
+}
+
+// weights -> scaled fp16 hi / lo images [2][N][K] + trailer {AMAX_N partial maxima (written by absmax_partials_kernel before
+// this launch), scale, 1 / scale}
+__global__ __launch_bounds__(256) void gemm_split_prepare_f16_kernel(const float* __restrict__ W, size_t n, unsigned* __restrict__ img,
+                                                                     float* __restrict__ trailer) {
+  __shared__ unsigned sh[16];
+  const unsigned sb = scale_bits_for_max(block_amax(trailer, sh));
+  const float s = __uint_as_float(sb);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { trailer[AMAX_N] = s; trailer[AMAX_N + 1] = inv_scale(sb); }
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // pair index
+  if (2 * i >= n) return;
+  const float2 v = reinterpret_cast<const float2*>(W)[i];
+  unsigned parts[2];
+  split_pair_f16(v.x * s, v.y * s, parts);
+  img[i] = parts[0];
+  img[n / 2 + i] = parts[1];
+}
+
 // weights -> NP bf16 part images [NP][N][K] (row-major, the MFMA B-operand's 8 consecutive k are contiguous)
 template <int NP>
 __global__ __launch_bounds__(256) void gemm_split_prepare_kernel(const float* __restrict__ W, size_t n, unsigned* __restrict__ img) {
@@ -83,11 +185,12 @@ __device__ __forceinline__ float gemm_gelu_grad(float v) {
 }
 
 // BM = 64 halves the tile (8 waves of 32 x 32) for shapes whose 128-row tiling leaves CUs idle or quantises badly.
-template <int NP, bool DB, int BM>
+template <int NP, bool DB, int BM, bool F16 = false>
 __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bimg,
                                                          const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                          int tiles_m, int tiles_n, int ep, float* __restrict__ C2,
-                                                         const float* __restrict__ aux) {
+                                                         const float* __restrict__ aux, const float* __restrict__ a_rows) {
+  static_assert(!F16 || NP == 2, "the fp16 form carries two parts");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // [buffer 2][A: part NP x BM rows | B: part NP x 128 rows][GLD]
   __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
@@ -108,6 +211,8 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   if (idx >= per + (xcd < rem ? 1 : 0)) return;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * GN;
+  // fp16 form: the weights' inverse scale from their image's trailer (the activations' per-row scales: a_rows[row], a_rows[M + row])
+  const float out_scale_b = F16 ? reinterpret_cast<const float*>(Bimg + (size_t)NP * N * K)[AMAX_N + 1] : 1.f;
 
   // staging maps.  B (128 rows x 64 bytes per part): thread t moves 16 bytes of row (t >> 2), k = 8 (t & 3) .. +7.
   // A (BM rows x 128 bytes): BM = 128: the 32 bytes of row (t >> 2) at k = 8 (t & 3); BM = 64: 16 bytes of row (t >> 3) at
@@ -117,6 +222,7 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   const int arow = (BM == 128) ? (tid >> 2) : (tid >> 3);
   const int acol = (BM == 128) ? 8 * (tid & 3) : 4 * (tid & 7);
   const float* a_src = A + (size_t)min(m0 + arow, M - 1) * K + acol;
+  const float sa = F16 ? a_rows[min(m0 + arow, M - 1)] : 1.f;
   const __bf16* b_src = Bimg + (size_t)(n0 + brow) * K + 8 * bq;
   const size_t b_part = (size_t)N * K;
   const int a_off = arow * GLD + acol, b_off = brow * GLD + 8 * bq;
@@ -135,8 +241,13 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
     unsigned parts[2 * AF4][NP];
 #pragma unroll
     for (int i = 0; i < AF4; ++i) {
-      split_pair<NP>(a_st[i].x, a_st[i].y, parts[2 * i]);
-      split_pair<NP>(a_st[i].z, a_st[i].w, parts[2 * i + 1]);
+      if constexpr (F16) {
+        split_pair_f16(a_st[i].x * sa, a_st[i].y * sa, parts[2 * i]);
+        split_pair_f16(a_st[i].z * sa, a_st[i].w * sa, parts[2 * i + 1]);
+      } else {
+        split_pair<NP>(a_st[i].x, a_st[i].y, parts[2 * i]);
+        split_pair<NP>(a_st[i].z, a_st[i].w, parts[2 * i + 1]);
+      }
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -186,7 +297,7 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
 #pragma unroll
         for (int s = NP - 1; s >= 0; --s)
 #pragma unroll
-          for (int i = 0; i <= s; ++i) c = mfma_bf16(af[mi][i], bf[s - i], c);
+          for (int i = 0; i <= s; ++i) c = F16 ? mfma_f16(af[mi][i], bf[s - i], c) : mfma_bf16(af[mi][i], bf[s - i], c);
         acc[mi][ni] = c;
       }
     }
@@ -232,7 +343,7 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
         const int row = m0 + (BM / 2) * wr + 16 * mi + 4 * q + r;
         if (row < M) {
           const size_t at = (size_t)row * N + col;
-          const float h = acc[mi][ni][r] + bv;
+          const float h = F16 ? acc[mi][ni][r] * a_rows[M + row] * out_scale_b + bv : acc[mi][ni][r] + bv;
           if (ep == EP_BIAS) C[at] = h;
           else if (ep == EP_GELU) {
             if (C2 != nullptr) C2[at] = h;
@@ -243,22 +354,22 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   }
 }
 
-template <int NP, bool DB, int BM>
+template <int NP, bool DB, int BM, bool F16 = false>
 static void launch_gemm_variant(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
-                                int ep, float* C2, const float* aux) {
+                                int ep, float* C2, const float* aux, const float* a_rows = nullptr) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / GN;
   const size_t lds = (size_t)(DB ? 2 : 1) * NP * (BM + GN) * GLD * sizeof(__bf16);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, DB, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, DB, BM, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;                // every XCD gets the same number of slots; surplus ones return at once
-  hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
-                     K, tiles_m, tiles_n, ep, C2, aux);
+  hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM, F16>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
+                     K, tiles_m, tiles_n, ep, C2, aux, a_rows);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -391,15 +502,15 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
 // (N = 768 at M = 2176: 102 tiles -> 204; 38 -> 29.5 us, 129 -> 103 us; at 204+ tiles the 64-row form loses 5-15 %).
 // Also measured and dropped: 4 waves of 64 x 64 with two workgroups per CU (-8...-30 %), a second fragment register set read
 // one step ahead (-12...-30 %).
-template <int NP>
+template <int NP, bool F16 = false>
 static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
-                             int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr) {
+                             int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr, const float* a_rows = nullptr) {
   const int t128 = ((M + 127) / 128) * (N / GN);
   const int forced = env_int("HOPMI_GEMM_TILE", 0);       // diagnostics: 1 = 128/DB, 2 = 128/!DB, 3 = 64/!DB
   const int mode = (forced >= 1 && forced <= 3) ? forced : (t128 < 160 ? 3 : (t128 <= 256 ? 1 : 2));
-  if (mode == 1) launch_gemm_variant<NP, true, 128>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux);
-  else if (mode == 2) launch_gemm_variant<NP, false, 128>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux);
-  else launch_gemm_variant<NP, false, 64>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux);
+  if (mode == 1) launch_gemm_variant<NP, true, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
+  else if (mode == 2) launch_gemm_variant<NP, false, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
+  else launch_gemm_variant<NP, false, 64, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
   return check_launch("hopmi_gemm_split");
 }
 
@@ -414,17 +525,51 @@ extern "C" int hopmi_debug_set_stamps_gemm(long long* p) {
 #endif
 
 extern "C" size_t hopmi_gemm_split_image_bytes(int N, int K, int parts) {
+  if (N > 0 && K > 0 && parts == F16_PARTS) return (size_t)2 * N * K * sizeof(_Float16) + (AMAX_N + 4) * sizeof(float);
   return (N > 0 && K > 0 && (parts == 2 || parts == 3)) ? (size_t)parts * N * K * sizeof(__bf16) : 0;
 }
 
+extern "C" int hopmi_row_scales(const float* A, int M, int K, float* scales, void* stream) {
+  if (!A || !scales || M <= 0 || K <= 0 || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) {
+    set_error("hopmi_row_scales: need A (16-byte aligned), scales [2 M] and K %% 4 == 0 (M=%d K=%d)", M, K);
+    return HOPMI_EINVAL;
+  }
+  hipLaunchKernelGGL(row_scales_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), A, M, K, scales);
+  return check_launch("hopmi_row_scales");
+}
+
+extern "C" int hopmi_gemm_f16x2(const float* A, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
+                                const float* aux, int M, int N, int K, int epilogue, void* stream) {
+  if (!A || !a_scales || !Bimage || !C) { set_error("hopmi_gemm_f16x2: null pointer argument"); return HOPMI_EINVAL; }
+  if (M <= 0 || N <= 0 || K <= 0 || N % GN || K % GK) {
+    set_error("hopmi_gemm_f16x2: need N %% 128 == 0, K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+    return HOPMI_EINVAL;
+  }
+  if (epilogue < EP_BIAS || epilogue > EP_GELU_GRAD || (epilogue == EP_GELU_GRAD && !aux)) {
+    set_error("hopmi_gemm_f16x2: epilogue %d (0 bias, 1 gelu, 2 gelu gradient: needs aux)", epilogue);
+    return HOPMI_EINVAL;
+  }
+  return launch_gemm_split<2, true>(A, Bimage, bias, C, M, N, K, static_cast<hipStream_t>(stream), epilogue, C2, aux, a_scales);
+}
+
 extern "C" int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts, void* image, void* stream) {
-  if (!W || !image || N <= 0 || K <= 0 || (K & 1) || (parts != 2 && parts != 3)) {
-    set_error("hopmi_gemm_split_prepare: need W, image, even K and parts in {2, 3} (N=%d K=%d parts=%d)", N, K, parts);
+  if (!W || !image || N <= 0 || K <= 0 || (K & 1) || (parts != 2 && parts != 3 && parts != F16_PARTS)) {
+    set_error("hopmi_gemm_split_prepare: need W, image, even K and parts in {2, 3, 16} (N=%d K=%d parts=%d)", N, K, parts);
     return HOPMI_EINVAL;
   }
   const size_t n = (size_t)N * K;
   const unsigned grid = (unsigned)((n / 2 + 255) / 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (parts == F16_PARTS) {
+    if ((n & 3) || (reinterpret_cast<uintptr_t>(W) & 15)) {
+      set_error("hopmi_gemm_split_prepare: the fp16 form needs N K %% 4 == 0 and a 16-byte aligned W");
+      return HOPMI_EINVAL;
+    }
+    float* trailer = reinterpret_cast<float*>(static_cast<unsigned char*>(image) + 2 * n * sizeof(_Float16));
+    hipLaunchKernelGGL(absmax_partials_kernel, dim3(AMAX_N), dim3(256), 0, st, W, n / 4, trailer);
+    hipLaunchKernelGGL(gemm_split_prepare_f16_kernel, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image), trailer);
+    return check_launch("hopmi_gemm_split_prepare");
+  }
   if (parts == 2) hipLaunchKernelGGL(gemm_split_prepare_kernel<2>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
   else hipLaunchKernelGGL(gemm_split_prepare_kernel<3>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
   return check_launch("hopmi_gemm_split_prepare");

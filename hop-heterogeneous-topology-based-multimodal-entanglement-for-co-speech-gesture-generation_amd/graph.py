@@ -460,7 +460,7 @@ class GraphedTrainStep:
         import ctypes
         if not self.debug:
             raise RuntimeError("hopmi GraphedTrainStep.node_census: construct with debug=True")
-        hip = ctypes.CDLL("libamdhip64.so")
+        hip = ctypes.CDLL(_loaded_hip_runtime())          # the runtime torch's graphs belong to, not whatever a bare soname finds
         hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
         hip.hipGraphNodeGetType.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record",
@@ -522,13 +522,23 @@ class GraphedTrainStep:
         tensors = [m.mapping_layer.weight, m.mapping_layer.bias]
         for p in (m.mapping_layer.weight, m.mapping_layer.bias):
             st = self.g_opt.state.get(p, {})
-            tensors += [st[k] for k in ("exp_avg", "exp_avg_sq") if k in st]
+            tensors += [st[k] for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq") if k in st]
         for t in tensors:
             pad = torch.zeros((self.per * self.world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             pad[:n].copy_(t)
             all_gather_rows(pad, self.per, self.group)
             t.copy_(pad[:n])
         self.sharded = False
+
+
+def _loaded_hip_runtime():
+    """Path of the libamdhip64 this process has mapped (torch ships its own copy; a second runtime must never be loaded)."""
+    with open("/proc/self/maps") as f:
+        for line in f:
+            path = line.rsplit(" ", 1)[-1].strip()
+            if "libamdhip64" in path.rsplit("/", 1)[-1]:
+                return path
+    raise RuntimeError("hopmi: no libamdhip64 is mapped in this process")
 
 
 class _PlainBackward:

@@ -262,10 +262,19 @@ def batch_norm_cl(x, bn, training):
     statistics advanced, num_batches_tracked counted) or the running-statistics map, fp32."""
     x = x.float()
     C = x.shape[-1]
+    if not (bn.affine and bn.track_running_stats and bn.momentum is not None and bn.running_mean is not None and C <= 64 and x.is_cuda):
+        # what the kernels do not cover (no affine parameters, no running statistics, cumulative-average momentum, > 64 channels):
+        # the module itself on the (B, C, T) view
+        return bn(x.transpose(1, 2)).transpose(1, 2)
     if training:
         with torch.no_grad():
             bn.num_batches_tracked += 1
         return _BnClFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum))
+    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad):
+        # the running-statistics map with a gradient (an eval-mode discriminator in front of a generator loss): plain tensor
+        # operations, autograd gives dx = dy * scale and the affine parameters' gradients
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        return x * scale + (bn.bias - bn.running_mean * scale)
     y = torch.empty_like(x)
     _lib.check(_lib.lib().hopmi_bn_cl_fwd(_dev_f32(x, "x").data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                                           bn.running_var.data_ptr(), y.data_ptr(), None, x.numel() // C, C, float(bn.eps), 0.0, 0, _stream()),
@@ -303,18 +312,22 @@ def cut_point(t):
 
 # ------------------------------------------------------- frozen-weight linears on split-bf16 MFMA (hopmi_gemm_split)
 CAST_CACHE_ENABLED = __import__("os").environ.get("HOPMI_CAST_CACHE", "1") != "0"
-GEMM_PARTS = 3      # 3: six-term split (fp32-equivalent, default);  2: three-term split (2^-16 class);  0: library fp32 GEMM (hipBLASLt)
+F16_PARTS = 16      # the `parts` code of the fp16 hi/lo form (two scaled fp16 parts per operand, three MFMA terms, fp32-equivalent)
+# 16: fp16 hi/lo, three terms (fp32-equivalent, default since round 4);  3: six-term bf16 split (fp32-equivalent);
+# 2: three-term bf16 split (2^-16 class);  0: library fp32 GEMM (hipBLASLt)
+GEMM_PARTS = int(__import__("os").environ.get("HOPMI_GEMM_PARTS", "16"))
 
 
 def gemm_parts(parts=None):
-    """Select how the frozen BERT's linears are computed (bert_fast): 0 = the library's fp32 GEMM, 3 = hopmi_gemm_split
-    with three bf16 parts per operand (six MFMA terms, fp32-equivalent), 2 = two parts (three terms).  Returns the
-    previous setting; `None` only reads it."""
+    """Select how the frozen BERT's linears are computed (bert_fast): 0 = the library's fp32 GEMM, 16 = hopmi_gemm_f16x2 (two
+    scaled fp16 parts per operand, three MFMA terms, fp32-equivalent), 3 = hopmi_gemm_split with three bf16 parts per operand
+    (six MFMA terms, fp32-equivalent), 2 = two bf16 parts (three terms, 2^-16-class products).  Returns the previous setting;
+    `None` only reads it."""
     global GEMM_PARTS
     prev = GEMM_PARTS
     if parts is not None:
-        if parts not in (0, 2, 3):
-            raise ValueError("hopmi gemm_parts: 0 (library fp32), 2 or 3")
+        if parts not in (0, 2, 3, F16_PARTS):
+            raise ValueError("hopmi gemm_parts: 0 (library fp32), 2, 3 or 16 (fp16 hi/lo)")
         GEMM_PARTS = parts
     return prev
 
@@ -336,7 +349,17 @@ def split_gemm_supported(N: int, K: int) -> bool:
     return N % 128 == 0 and K % 32 == 0
 
 
-def _split_gemm(a2d, img, bias, N, K, parts):
+def row_scales(a2d):
+    """Per-row power-of-two scales [2][M] of a2d (hopmi_row_scales): the A operand's scales of hopmi_gemm_f16x2."""
+    M, K = a2d.shape
+    sc = torch.empty(2, M, dtype=torch.float32, device=a2d.device)
+    _lib.check(_lib.lib().hopmi_row_scales(a2d.data_ptr(), M, K, sc.data_ptr(), _stream()), "hopmi_row_scales")
+    return sc
+
+
+def _split_gemm(a2d, img, bias, N, K, parts, a_part=None):
+    if parts == F16_PARTS:
+        return _split_gemm_ep(a2d, img, bias, N, K, parts, 0, a_part=a_part)[0]
     M = a2d.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
     L = _lib.lib()
@@ -388,12 +411,21 @@ def split_linear(x, img_w, img_wt, bias, N, K, parts):
     return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
 
 
-def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None):
-    """hopmi_gemm_split_ep: epilogue 1 -> (gelu(h), h if keep else None) with h = a2d W^T + bias; 2 -> (a2d W^T) * gelu'(aux)."""
+def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None):
+    """hopmi_gemm_split_ep / hopmi_gemm_f16x2: epilogue 0 -> a2d W^T + bias; 1 -> (gelu(h), h if keep else None) with
+    h = a2d W^T + bias; 2 -> (a2d W^T) * gelu'(aux).  `a_part`: the fp16 form's per-row scales of a2d (row_scales) when the caller has them."""
     M = a2d.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
     h = torch.empty_like(out) if (epilogue == 1 and keep) else None
     L = _lib.lib()
+    if parts == F16_PARTS:
+        if a_part is None:
+            a_part = row_scales(a2d)
+        _lib.check(_timed("gemm_split", 4 * (M * K + (3 if (h is not None or aux is not None) else 2) * M * N) + 4 * N * K, 2 * M * N * K,
+                          lambda: L.hopmi_gemm_f16x2(a2d.data_ptr(), a_part.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h),
+                                                     _ptr(aux), M, N, K, epilogue, _stream())),
+                   "hopmi_gemm_f16x2")
+        return out, h
     _lib.check(_timed("gemm_split", 4 * (M * K + (3 if (h is not None or aux is not None) else 2) * M * N) + 2 * parts * N * K, 2 * M * N * K,
                       lambda: L.hopmi_gemm_split_ep(a2d.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h), _ptr(aux), M, N, K,
                                                     parts, epilogue, _stream())),
@@ -628,6 +660,13 @@ def _mm_f32(a, b):
 _CAST_CACHE = {}    # id(parameter) -> (weak reference, version, dtype, cast copy)
 
 
+def cast_cache_reset():
+    """Forget every cached cast.  graph.GraphedTrainStep calls this right before it starts recording a step and right after: a copy
+    made by an eager call lives in the eager allocator pool, and a recording that was served that copy would bake its address in
+    without recording the cast (stale or freed memory on every replay); a copy made while recording lives in the graph's pool."""
+    _CAST_CACHE.clear()
+
+
 def _cast_param(w, dt):
     """`w.to(dt)` for an operand of `_LinearFn` under autocast.  A step runs every trainable linear in two forwards (the graded one
     and the no-grad one of the diversity regulariser) between two optimizer steps: for an nn.Parameter -- an object that outlives
@@ -635,11 +674,13 @@ def _cast_param(w, dt):
     copy.  Anything else (a temporary such as a packed weight: ids and versions of temporaries repeat) is cast on the spot."""
     if not CAST_CACHE_ENABLED or not isinstance(w, torch.nn.Parameter):
         return w.to(dt)
+    cap = w.is_cuda and torch.cuda.is_current_stream_capturing()
     hit = _CAST_CACHE.get(id(w))
-    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == dt:
+    # (a hit must come from the same side of a recording as the lookup: entry[4] says whether the copy was made under capture)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == dt and hit[4] == cap:
         return hit[3]
     c = w.detach().to(dt)
-    _CAST_CACHE[id(w)] = (weakref.ref(w), w._version, dt, c)
+    _CAST_CACHE[id(w)] = (weakref.ref(w), w._version, dt, c, cap)
     return c
 
 
@@ -1127,6 +1168,16 @@ WN_BF16_STORAGE = True
 
 _STACK_WS = {}       # (device index, stream, geometry) -> workspace of the persistent stack kernel (counters zero between launches)
 STACK_ENABLED = True  # False: the training forward runs as per-layer launches (A/B runs, HOPMI_WN_STACK=0)
+
+
+def stack_ws_prepare(from_stream: int, to_stream: int):
+    """Give `to_stream` (a raw stream handle) a zeroed workspace for every stack geometry `from_stream` has used: the eager
+    warm-up calls of a training step run on the current stream, its recording on another one, and a workspace first seen under
+    capture would be allocated and ZERO-FILLED by a recorded launch (2 MB of writes and a sequence-number reset on every replay)."""
+    for key in [k for k in _STACK_WS if k[1] == from_stream]:
+        new = (key[0], to_stream) + key[2:]
+        if new not in _STACK_WS:
+            _STACK_WS[new] = torch.zeros_like(_STACK_WS[key])
 
 
 def wn_stack_supported(B: int, T_in: int, V: int, dilations) -> int:

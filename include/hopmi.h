@@ -40,6 +40,16 @@ const char* hopmi_last_error(void);
  * process; this forgets the cached values so that the next call reads them again (used by the sweep probes). */
 void hopmi_reload_env(void);
 
+/* Stream-capture hygiene for the recorded training step (hopmi/graph.py; the step being recorded is the reference's
+ * train_eval/train_llm.py:9-98).  An exception raised while a step is being recorded leaves `stream` inside a capture; whether
+ * that capture can still be ended depends on its state, which the caller must look at BEFORE walking into hipStreamEndCapture:
+ *   hopmi_stream_capture_status: *status = 0 not capturing, 1 capture active (healthy), 2 capture invalidated by an illegal call.
+ *   hopmi_stream_capture_abandon: ends whatever capture `stream` is in and destroys the graph it yields, if any; returns 0 when
+ *     the stream is out of capture mode afterwards (also when the runtime reports the capture as invalidated, which is the
+ *     expected answer for state 2), HOPMI_ELAUNCH otherwise.  Neither call launches or allocates anything. */
+int hopmi_stream_capture_status(void* stream, int* status);
+int hopmi_stream_capture_abandon(void* stream);
+
 /* Measurement hook: the next hopmi_wn_layer_fwd call of this host thread records the two hipEvent_t EXACTLY around its
  * layer kernel (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps, what a profiler's
  * kernel trace reports), then the hook clears itself.  Pass NULLs to clear.  bench.py uses it for the live roofline. */
@@ -397,6 +407,17 @@ int hopmi_gemm_split(const float* A, const void* Bimage, const float* bias, floa
  * followed by hopmi_bias_gelu_fwd / _bwd (the same expressions on the same fp32 values). */
 int hopmi_gemm_split_ep(const float* A, const void* Bimage, const float* bias, float* C, float* C2, const float* aux, int M, int N,
                         int K, int parts, int epilogue, void* stream);
+
+/* The fp16 hi/lo form of the same product (round 4): every operand carried as TWO scaled fp16 numbers, THREE MFMA terms
+ * (hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_f16), fp32-equivalent like the six-term bf16 form at half the matrix work
+ * (csrc/gemm.hip).  hopmi_gemm_split_prepare / _image_bytes take parts = 16 for the weight image of this form (hi and lo images of
+ * W 2^s + a trailer holding s: one power-of-two scale per weight tensor).  The activations carry one power-of-two scale PER ROW:
+ * a_scales [2][M] = {s_row, 1 / s_row}, written by hopmi_row_scales(A, M, K, a_scales) -- or by whichever kernel produced A.
+ * epilogue / C2 / aux as hopmi_gemm_split_ep.  Replaces the same reference arithmetic: the HF BERT linears behind
+ * model/HOP.py:204 (built at run_ted.py:177-195). */
+int hopmi_row_scales(const float* A, int M, int K, float* scales, void* stream);
+int hopmi_gemm_f16x2(const float* A, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
+                     const float* aux, int M, int N, int K, int epilogue, void* stream);
 
 /* The same product with BOTH operands as part images (Aimage = hopmi_gemm_split_prepare(A, M, K, parts, ...), i.e.
  * [parts][M][K] bf16; a producer may also write that layout itself): nothing is split inside the kernel, every tile is staged
