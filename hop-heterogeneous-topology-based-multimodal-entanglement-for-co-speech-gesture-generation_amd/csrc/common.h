@@ -29,4 +29,29 @@ int env_int(const char* name, int dflt);   // cached environment knob (api.hip)
 
 inline int ceil_to(int x, int m) { return (x + m - 1) / m * m; }
 
+// ---- operand scales of the fp16 hi/lo GEMM form (gemm.hip; also written by the kernels that produce its A operand)
+// power-of-two scale for a row / tensor whose largest magnitude has the bits `m` (sign cleared): max * s in [2^14, 2^15); 1 for an
+// all-zero / subnormal / non-finite one (a NaN or infinity then travels through the products as itself)
+__device__ __forceinline__ unsigned scale_bits_for_max(unsigned m) {
+  const int e = (int)(m >> 23);
+  const int sb = (e == 0 || e == 255) ? 127 : min(268 - e, 250);
+  return (unsigned)sb << 23;
+}
+__device__ __forceinline__ float inv_scale(unsigned scale_bits) { return __uint_as_float((254u << 23) - scale_bits); }
+__device__ __forceinline__ unsigned abs_bits_max4(unsigned m, float4 v) {
+  return max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+             max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+}
+// lane 0 of a wave that has reduced `m` over the row writes the row's scale pair: scales[row] = s, scales[M + row] = 1 / s
+__device__ __forceinline__ void store_row_scale(float* __restrict__ scales, int M, int row, unsigned m) {
+  const unsigned sb = scale_bits_for_max(m);
+  scales[row] = __uint_as_float(sb);
+  scales[M + row] = inv_scale(sb);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  return m;
+}
+
 }  // namespace hopmi

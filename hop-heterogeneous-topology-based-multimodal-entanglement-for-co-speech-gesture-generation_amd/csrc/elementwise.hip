@@ -68,11 +68,13 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
                                                                    T* __restrict__ out_t,
                                                                    float* __restrict__ xhat, float* __restrict__ rstd_out, int M,
                                                                    int D, int res_rows, float eps, unsigned drop_thresh,
-                                                                   float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+                                                                   float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev,
+                                                                   float* __restrict__ row_scales) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
+  unsigned amax = 0;                            // max |out| of the row (row_scales: the next GEMM's fp16-form operand scale)
   float4 z[LN_MAX4];
   float s = 0.f;
 #pragma unroll
@@ -115,9 +117,14 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
       reinterpret_cast<float4*>(out)[(size_t)row * D4 + c4] = o;
       if (out_t != nullptr) st4(out_t + ((size_t)row * D4 + c4) * 4, o);
       if (xhat != nullptr) reinterpret_cast<float4*>(xhat)[(size_t)row * D4 + c4] = h;
+      amax = abs_bits_max4(amax, o);
     }
   }
   if (rstd_out != nullptr && lane == 0) rstd_out[row] = rstd;
+  if (row_scales != nullptr) {
+    amax = wave_max_u32(amax);
+    if (lane == 0) store_row_scale(row_scales, M, row, amax);
+  }
 }
 
 // dz = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)), dxh = dout * gamma ; dres = dz ; dx = dz o dropout mask
@@ -127,11 +134,13 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
                                                                    const float* __restrict__ xhat,
                                                                    const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                                    T* __restrict__ dx, float* __restrict__ dres, int M, int D,
-                                                                   unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+                                                                   unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev,
+                                                                   float* __restrict__ row_scales) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
+  unsigned amax = 0;                            // max |dx| of the row (row_scales: the next GEMM's fp16-form operand scale)
   float4 dh[LN_MAX4], xh[LN_MAX4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -168,7 +177,12 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
         dz.w = ew_hash(seed, row, col + 3) >= drop_thresh ? dz.w * drop_scale : 0.f;
       }
       st4(dx + ((size_t)row * D4 + c4) * 4, dz);
+      amax = abs_bits_max4(amax, dz);
     }
+  }
+  if (row_scales != nullptr) {
+    amax = wave_max_u32(amax);
+    if (lane == 0) store_row_scale(row_scales, M, row, amax);
   }
 }
 
@@ -413,10 +427,10 @@ extern "C" int hopmi_bias_gelu_bwd(const float* x, const float* bias, const floa
   return hopmi_bias_gelu_bwd_dt(x, bias, dy, dx, M, N, HOPMI_F32, stream);
 }
 
-extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const float* bias, const float* res, int res_rows,
+extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_rs(const void* x, const float* bias, const float* res, int res_rows,
                                                             const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
-                                                            float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
-                                                            const unsigned* seed_dev, int dtype, void* stream) {
+                                                            float* rstd, float* row_scales, int M, int D, float eps, float p_drop,
+                                                            unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_fwd")) return e;
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_fwd_dt", dtype)) return e;
   if (!x || !bias || !res || !gamma || !beta || !out) { set_error("hopmi_bias_dropout_residual_layernorm_fwd: null pointer argument"); return HOPMI_EINVAL; }
@@ -429,16 +443,24 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == HOPMI_BF16)
     hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const __bf16*>(x), bias, res,
-                       gamma, beta, out, static_cast<__bf16*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev);
+                       gamma, beta, out, static_cast<__bf16*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales);
   else
     hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const float*>(x), bias, res,
-                       gamma, beta, out, static_cast<float*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev);
+                       gamma, beta, out, static_cast<float*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales);
   return check_launch("hopmi_bias_dropout_residual_layernorm_fwd");
 }
 
-extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
-                                                            const float* gamma, void* dx, float* dres, int M, int D, float p_drop,
-                                                            unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
+extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const float* bias, const float* res, int res_rows,
+                                                            const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
+                                                            float* rstd, int M, int D, float eps, float p_drop, unsigned seed,
+                                                            const unsigned* seed_dev, int dtype, void* stream) {
+  return hopmi_bias_dropout_residual_layernorm_fwd_rs(x, bias, res, res_rows, gamma, beta, out, out_t, xhat, rstd, nullptr, M, D, eps, p_drop,
+                                                      seed, seed_dev, dtype, stream);
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                            const float* gamma, void* dx, float* dres, float* row_scales, int M, int D,
+                                                            float p_drop, unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_bwd_dt", dtype)) return e;
   if (!dout || !xhat || !rstd || !gamma || !dx || !dres) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: null pointer argument"); return HOPMI_EINVAL; }
@@ -448,11 +470,18 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == HOPMI_BF16)
     hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const __bf16*>(dout_t), xhat,
-                       rstd, gamma, static_cast<__bf16*>(dx), dres, M, D, thresh, dscale, seed, seed_dev);
+                       rstd, gamma, static_cast<__bf16*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales);
   else
     hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const float*>(dout_t), xhat,
-                       rstd, gamma, static_cast<float*>(dx), dres, M, D, thresh, dscale, seed, seed_dev);
+                       rstd, gamma, static_cast<float*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales);
   return check_launch("hopmi_bias_dropout_residual_layernorm_bwd");
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                            const float* gamma, void* dx, float* dres, int M, int D, float p_drop,
+                                                            unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
+  return hopmi_bias_dropout_residual_layernorm_bwd_rs(dout, dout_t, xhat, rstd, gamma, dx, dres, nullptr, M, D, p_drop, seed, seed_dev, dtype,
+                                                      stream);
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_fwd(const float* x, const float* bias, const float* res, int res_rows,

@@ -82,14 +82,6 @@ __device__ __forceinline__ void split_pair_f16(float a, float b, unsigned (&out)
 }
 constexpr int F16_PARTS = 16;                      // the `parts` code of this form at the C ABI ("two fp16 parts")
 constexpr int AMAX_N = 256;                        // per-block maxima of hopmi_absmax_partials
-// power-of-two scale for a tensor whose largest magnitude has the bits `m` (sign cleared): max * s in [2^14, 2^15); 1 for an
-// all-zero / subnormal / non-finite tensor (a NaN or infinity then travels through the products as itself)
-__device__ __forceinline__ unsigned scale_bits_for_max(unsigned m) {
-  const int e = (int)(m >> 23);
-  const int sb = (e == 0 || e == 255) ? 127 : min(268 - e, 250);
-  return (unsigned)sb << 23;
-}
-__device__ __forceinline__ float inv_scale(unsigned scale_bits) { return __uint_as_float((254u << 23) - scale_bits); }
 // max over part[0 .. 255] (as sign-cleared bit patterns), by all threads of a block of >= 256 threads; `sh` = 16 words of LDS
 __device__ __forceinline__ unsigned block_amax(const float* __restrict__ part, unsigned* sh) {
   unsigned v = threadIdx.x < AMAX_N ? (__float_as_uint(part[threadIdx.x]) & 0x7fffffffu) : 0u;
@@ -125,18 +117,9 @@ __global__ __launch_bounds__(256) void row_scales_kernel(const float* __restrict
   if (row >= M) return;
   const float4* src = reinterpret_cast<const float4*>(A + (size_t)row * K);
   unsigned m = 0;
-  for (int i = lane; i < K / 4; i += 64) {
-    const float4 v = src[i];
-    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
-        max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if (lane == 0) {
-    const unsigned sb = scale_bits_for_max(m);
-    out[row] = __uint_as_float(sb);
-    out[M + row] = inv_scale(sb);
-  }
+  for (int i = lane; i < K / 4; i += 64) m = abs_bits_max4(m, src[i]);
+  m = wave_max_u32(m);
+  if (lane == 0) store_row_scale(out, M, row, m);
 }
 
 // weights -> scaled fp16 hi / lo images [2][N][K] + trailer {AMAX_N partial maxima (written by absmax_partials_kernel before

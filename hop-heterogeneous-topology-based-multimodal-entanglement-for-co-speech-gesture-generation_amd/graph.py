@@ -35,6 +35,8 @@ from . import ops as _ops
 from . import steps as _steps
 
 _STEP_INC = 0x9E3779B1            # added to ops.SEED_DEV at the head of every replay
+EXIT_CAPTURE_FAILED = 86          # exit code when no device work is possible after a failed recording (see _recording_failed)
+_GRAVEYARD = []                   # (graph, stream) of abandoned captures: kept for the life of the process
 
 
 def shard_rows(n_rows: int, rank: int, world: int):
@@ -208,6 +210,7 @@ class GraphedTrainStep:
         self.enabled = enabled
         self.debug = debug
         self.records = {}
+        self.broken = None                          # why recording was given up (an exception while recording), else None
         self.n_eager = self.n_replay = 0            # calls served by steps.train_llm itself / by a replay
         self.sharded = False
         self._pool = None
@@ -375,6 +378,16 @@ class GraphedTrainStep:
         m = self.model
         prev_sink, prev_cap, prev_seed, prev_cut = _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV, _ops.CUT_HOOK
         _ops.deferred_status()                                   # pending eager launches are not this recording's
+        # nothing of the eager calls may be served to, or kept alive across, the recording: cached operand casts live in the eager
+        # allocator pool (a recording handed one would bake its address in without recording the cast); gradient tensors of the
+        # eager step would be accumulated into instead of being allocated from the graph's pool; the stack kernel's workspace of
+        # the eager calls' stream gets a twin for the recording's stream now (allocated under capture it would be zero-filled by
+        # a recorded launch on every replay)
+        _ops.cast_cache_reset()
+        _ops.stack_ws_prepare(cur.cuda_stream, self._stream.cuda_stream)
+        for mod in (m, self.disc):
+            for p in mod.parameters():
+                p.grad = None
         gc.collect()
         torch.cuda.synchronize(dev)
         with torch.cuda.stream(self._stream), _ops.no_timer():
@@ -392,24 +405,81 @@ class GraphedTrainStep:
                     if cap.status:
                         self._bwd_status.copy_(torch.stack([w.float().reshape(()) for w in cap.status]).sum())
                         cap.status.clear()
-                except BaseException:
-                    # ending a capture that an exception interrupted can bring the process down inside the runtime (seen:
-                    # SIGSEGV in hipStreamEndCapture): say what happened first
-                    import sys
-                    import traceback
-                    print("hopmi GraphedTrainStep: exception while recording the step:", file=sys.stderr)
-                    traceback.print_exc()
-                    sys.stderr.flush()
+                except BaseException as exc:
+                    self._recording_failed(cap, exc)
                     raise
-                finally:
+                else:
                     cap.end()
             finally:
                 _ops.STATUS_SINK, _steps._CAPTURE, _ops.SEED_DEV, _ops.CUT_HOOK = prev_sink, prev_cap, prev_seed, prev_cut
                 m._proto_S = None
+                _ops.cast_cache_reset()                          # (copies made while recording live in the graph's pool)
         cur.wait_stream(self._stream)
         if cap.fetch is None:
             raise RuntimeError("hopmi GraphedTrainStep: the recorded step never fetched its losses")
         return dict(cap=cap, static=static, terms=cap.fetch.terms, n_vals=len(cap.fetch.terms) + 1)
+
+    def _recording_failed(self, cap, exc):
+        """An exception interrupted a recording: `self._stream` is still inside a stream capture.  Measured on this runtime
+        (tools/probes/capture_failure_probe.py, gpurun_out/capture_probe.log): a capture LEFT OPEN aborts the process at
+        interpreter exit (SIGABRT out of the graph object's destructor); a healthy capture (a Python-level error, and most illegal
+        calls, which this runtime refuses without invalidating the capture) ends the ordinary way; an INVALIDATED one (e.g. a
+        device-wide synchronize under capture) makes hipStreamEndCapture answer with the invalidation error and the stream keeps
+        REPORTING that state -- but the process goes on working (fresh allocations, GEMMs, syncs, a second capture on a new
+        stream).  So: look first (hopmi_stream_capture_status); healthy -> capture_end(), graph dropped; otherwise the capture is
+        ended by hopmi_stream_capture_abandon whatever it answers, the allocator is taken off the graph's pool by hand, torch's
+        graph object -- which still believes it is capturing -- is parked for the life of the process, and the stream is replaced.
+        Either way this object stops recording (`enabled = False`: every later call is the eager step, `broken` says why) and the
+        caller gets the original exception.  Last, a round trip of ordinary device work proves the process can still train; if
+        THAT fails it says so in one line and exits with EXIT_CAPTURE_FAILED (never a re-exec)."""
+        import ctypes
+        import os
+        import sys
+        import traceback
+        from . import _lib
+        print("hopmi GraphedTrainStep: exception while recording the step:", file=sys.stderr)
+        traceback.print_exception(type(exc), exc, exc.__traceback__, file=sys.stderr)
+        self.enabled = False
+        self.records.clear()
+        self.broken = f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}"
+        L = _lib.lib()
+        st = ctypes.c_int(-1)
+        handle = self._stream.cuda_stream
+        rc = L.hopmi_stream_capture_status(handle, ctypes.byref(st))
+        how = {0: "not capturing", 1: "active", 2: "invalidated"}.get(st.value, f"unknown ({rc})")
+        ended = rc == 0 and st.value == 0
+        if rc == 0 and st.value == 1 and cap.graph is not None:
+            try:
+                cap.graph.capture_end()                      # healthy: the ordinary end; the graph is dropped with `cap`
+                ended = True
+            except BaseException as e2:                      # noqa: BLE001
+                print(f"hopmi GraphedTrainStep: capture_end after the failure raised {type(e2).__name__}: {e2}", file=sys.stderr)
+        if not ended:
+            _GRAVEYARD.append((cap.graph, self._stream))     # (their destructors must not run against a capture they do not own any more)
+            if L.hopmi_stream_capture_abandon(handle) != 0:
+                print(f"hopmi GraphedTrainStep: {L.hopmi_last_error().decode()}", file=sys.stderr)
+            dev = torch.cuda.current_device()
+            for fn in (torch._C._cuda_endAllocateToPool, torch._C._cuda_releasePool):
+                try:
+                    fn(dev, self._pool)
+                except Exception as e3:                       # noqa: BLE001  (the pool was never begun / already handed back)
+                    print(f"hopmi GraphedTrainStep: {fn.__name__}: {e3}", file=sys.stderr)
+            self._stream = torch.cuda.Stream(device=dev)
+        cap.graph = None
+        self._pool = torch.cuda.graph_pool_handle()
+        try:                                                  # can this process still issue device work?  (on the caller's stream)
+            with torch.cuda.stream(torch.cuda.default_stream()):
+                probe = torch.empty(1 << 20, dtype=torch.float32, device="cuda").fill_(1.0)
+                alive = float(probe.sum().item()) == float(1 << 20)
+        except Exception as e4:                               # noqa: BLE001
+            alive = False
+            print(f"hopmi GraphedTrainStep: device work after the failed recording raised {type(e4).__name__}: {e4}", file=sys.stderr)
+        if not alive:
+            print(f"hopmi GraphedTrainStep: FATAL: no device work is possible after the failed recording (capture was {how}; "
+                  f"{self.broken}) -- exiting with code {EXIT_CAPTURE_FAILED}", file=sys.stderr, flush=True)
+            os._exit(EXIT_CAPTURE_FAILED)
+        print(f"hopmi GraphedTrainStep: recording abandoned (capture was {how}); this object runs the eager step from now on: {self.broken}",
+              file=sys.stderr, flush=True)
 
     # -- call --------------------------------------------------------------------------------------------------------
     def __call__(self, epoch, in_audio, log_melspec, text_token_padded, target_dir_vec, vid_indices):

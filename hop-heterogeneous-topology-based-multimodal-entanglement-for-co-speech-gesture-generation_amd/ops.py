@@ -357,6 +357,27 @@ def row_scales(a2d):
     return sc
 
 
+def _attach_rs(t, sc):
+    """Remember the fp16-form row scales `sc` ([2][M]) of tensor `t` ON the tensor object, with what identifies the values they
+    were taken from (storage address, version counter): the kernel that produced `t` had its rows in registers, and the GEMM that
+    consumes `t` (possibly on the other side of an autograd edge: the Python object travels) asks `_take_rs`."""
+    t._hopmi_rs = (sc, t.data_ptr(), t._version)
+
+
+def _take_rs(t, M):
+    """The row scales attached to `t` if they still describe it, else None (the consumer then runs hopmi_row_scales itself)."""
+    hit = getattr(t, "_hopmi_rs", None)
+    if hit is None:
+        return None
+    sc, ptr, ver = hit
+    if ptr != t.data_ptr() or ver != t._version or tuple(sc.shape) != (2, M) or sc.device != t.device:
+        return None
+    return sc
+
+
+RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"     # row scales from the producing kernels (0: always a pass of their own)
+
+
 def _split_gemm(a2d, img, bias, N, K, parts, a_part=None):
     if parts == F16_PARTS:
         return _split_gemm_ep(a2d, img, bias, N, K, parts, 0, a_part=a_part)[0]
@@ -395,7 +416,8 @@ class _SplitLinearFn(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, img_w, img_wt, bias, N, K, parts):
         x = _dev_f32(x, "x")
-        y = _split_gemm(x.reshape(-1, K), img_w, None if bias is None else _dev_f32(bias.detach(), "bias"), N, K, parts)
+        rs = _take_rs(x, x.numel() // K) if parts == F16_PARTS else None
+        y = _split_gemm(x.reshape(-1, K), img_w, None if bias is None else _dev_f32(bias.detach(), "bias"), N, K, parts, a_part=rs)
         ctx.img_wt, ctx.N, ctx.K, ctx.parts = img_wt, N, K, parts
         return y.view(*x.shape[:-1], N)
 
@@ -403,7 +425,8 @@ class _SplitLinearFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         dy = _dev_f32(dy, "dy")
-        dx = _split_gemm(dy.reshape(-1, ctx.N), ctx.img_wt, None, ctx.K, ctx.N, ctx.parts)      # dX = dY . W = dY . (W^T)^T
+        rs = _take_rs(dy, dy.numel() // ctx.N) if ctx.parts == F16_PARTS else None
+        dx = _split_gemm(dy.reshape(-1, ctx.N), ctx.img_wt, None, ctx.K, ctx.N, ctx.parts, a_part=rs)      # dX = dY . W = dY . (W^T)^T
         return dx.view(*dy.shape[:-1], ctx.K), None, None, None, None, None, None
 
 
@@ -443,7 +466,8 @@ class _SplitFfnFn(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, img1, img1t, b1, img2, img2t, N1, K, parts):
         x = _dev_f32(x, "x")
-        f, h = _split_gemm_ep(x.reshape(-1, K), img1, _dev_f32(b1.detach(), "bias"), N1, K, parts, 1, keep=ctx.needs_input_grad[0])
+        rs = _take_rs(x, x.numel() // K) if parts == F16_PARTS else None
+        f, h = _split_gemm_ep(x.reshape(-1, K), img1, _dev_f32(b1.detach(), "bias"), N1, K, parts, 1, keep=ctx.needs_input_grad[0], a_part=rs)
         o = _split_gemm(f, img2, None, K, N1, parts)
         ctx.save_for_backward(h)
         ctx.imgs, ctx.dims = (img1t, img2t), (N1, K, parts)
@@ -456,7 +480,8 @@ class _SplitFfnFn(torch.autograd.Function):
         img1t, img2t = ctx.imgs
         N1, K, parts = ctx.dims
         do = _dev_f32(do, "do")
-        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h)           # (dO W2) * gelu'(h)
+        rs = _take_rs(do, do.numel() // K) if parts == F16_PARTS else None
+        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h, a_part=rs)           # (dO W2) * gelu'(h)
         dx = _split_gemm(dh, img1t, None, K, N1, parts)                                           # dH W1
         return dx.view(*do.shape), None, None, None, None, None, None, None, None
 
@@ -563,20 +588,25 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         xhat = torch.empty_like(x) if need else None
         rstd = torch.empty(M, dtype=torch.float32, device=x.device) if need else None
         L, st, sp = _lib.lib(), _stream(), _seed_ptr()
+        # the fp16-form GEMMs behind this operator take their A operand's row scales from here (the rows are in registers)
+        ctx.rs = RS_FUSED and GEMM_PARTS == F16_PARTS
+        sc = torch.empty(2, M, dtype=torch.float32, device=x.device) if ctx.rs else None
         _lib.check(_timed("bias_drop_res_ln_fwd", 4 * x.numel() * (4 if need else 3), 0,
-                          lambda: L.hopmi_bias_dropout_residual_layernorm_fwd(
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_fwd_rs(
                               x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
-                              out.data_ptr(), _ptr(xhat), _ptr(rstd), M, D, float(eps), float(p_drop), int(seed) & _M32, sp, st)),
+                              out.data_ptr(), None, _ptr(xhat), _ptr(rstd), _ptr(sc), M, D, float(eps), float(p_drop), int(seed) & _M32, sp, 0, st)),
                    "hopmi_bias_dropout_residual_layernorm_fwd")
         if need:
             ctx.save_for_backward(xhat, rstd, gamma)
         ctx.p_drop, ctx.seed, ctx.res_shape, ctx.x_rows, ctx.sp = float(p_drop), int(seed) & _M32, res.shape, M, sp
         ctx.set_materialize_grads(False)
-        return out, out.detach()
+        if sc is not None:
+            ctx.mark_non_differentiable(sc)
+        return out, out.detach(), sc
 
     @staticmethod
     @_bwd32
-    def backward(ctx, dout, dout2):
+    def backward(ctx, dout, dout2, _dsc=None):
         xhat, rstd, gamma = ctx.saved_tensors
         if dout is None:
             dout, dout2 = dout2, None
@@ -588,11 +618,14 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         M = ctx.x_rows
         dx, dres = torch.empty_like(xhat), torch.empty_like(xhat)
         L, st = _lib.lib(), _stream()
+        sc = torch.empty(2, M, dtype=torch.float32, device=dx.device) if ctx.rs else None      # dx feeds the backward's next GEMM
         _lib.check(_timed("bias_drop_res_ln_bwd", (16 if d2 is None else 20) * xhat.numel(), 0,
-                          lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_dt(
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_rs(
                               dout.data_ptr(), _ptr(d2), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                              dres.data_ptr(), M, D, ctx.p_drop, ctx.seed, ctx.sp, 0, st)),
+                              dres.data_ptr(), _ptr(sc), M, D, ctx.p_drop, ctx.seed, ctx.sp, 0, st)),
                    "hopmi_bias_dropout_residual_layernorm_bwd_dt")
+        if sc is not None:
+            _attach_rs(dx, sc)
         if tuple(ctx.res_shape) != tuple(dres.shape):            # broadcast residual (e.g. position embeddings)
             dres = dres.view(-1, *ctx.res_shape).sum(0)
         return dx, None, dres, None, None, None, None, None
@@ -600,7 +633,10 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
 
 def bias_dropout_residual_layernorm2(x, bias, res, gamma, beta, eps, p_drop=0.0, seed=0):
     """(out, out again on the same storage): see _BiasDropResLn2Fn."""
-    return _BiasDropResLn2Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
+    out, out2, sc = _BiasDropResLn2Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
+    if sc is not None:
+        _attach_rs(out, sc)
+    return out, out2
 
 
 # ---- bf16-storage forms of the frozen BERT's epilogue / attention operators (dtype argument of the `_dt` entry points) ------
@@ -1178,6 +1214,12 @@ def stack_ws_prepare(from_stream: int, to_stream: int):
         new = (key[0], to_stream) + key[2:]
         if new not in _STACK_WS:
             _STACK_WS[new] = torch.zeros_like(_STACK_WS[key])
+
+
+def stack_ws_forget():
+    """Drop every stack workspace (after a launch raised its status word: the word is sticky and the launch sequence number was
+    not advanced, so the old workspaces must not serve another launch)."""
+    _STACK_WS.clear()
 
 
 def wn_stack_supported(B: int, T_in: int, V: int, dilations) -> int:

@@ -143,8 +143,11 @@ class _LossFetch:
         that is exactly 0.0 is left out."""
         vals = list(vals)
         if has_status and vals.pop() != 0.0:
-            raise RuntimeError("hopmi: a persistent GRU kernel timed out waiting for a hand-off; "
-                               "set HOPMI_GRU_PERSISTENT=0 to use per-time-step launches")
+            # (the stack kernel's status word is sticky and its launch sequence number was not advanced by the launch that timed
+            # out: its workspaces are dead -- the next launch gets fresh, zeroed ones)
+            _ops.stack_ws_forget()
+            raise RuntimeError("hopmi: a persistent kernel (GRU recurrence / WaveNet stack) timed out waiting for a hand-off; "
+                               "set HOPMI_GRU_PERSISTENT=0 to use per-step / per-layer launches")
         ret = {}
         for (k, wgt), v in zip(terms, vals):
             if k in ("KLD", "DIV_REG") and v == 0.0:

@@ -309,6 +309,16 @@ int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const float* bia
 int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
                                                  const float* gamma, void* dx, float* dres, int M, int D, float p_drop,
                                                  unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
+/* The same two operators also emitting the fp16-form GEMM operand scales of what they hand to the next GEMM (hopmi_gemm_f16x2's
+ * a_scales [2][M] of `out` / of `dx`; row_scales NULL = the _dt forms): the rows are in registers here, a hopmi_row_scales pass over
+ * them afterwards costs a launch and a re-read. */
+int hopmi_bias_dropout_residual_layernorm_fwd_rs(const void* x, const float* bias, const float* res, int res_rows,
+                                                 const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
+                                                 float* rstd, float* row_scales, int M, int D, float eps, float p_drop, unsigned seed,
+                                                 const unsigned* seed_dev, int dtype, void* stream);
+int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                 const float* gamma, void* dx, float* dres, float* row_scales, int M, int D, float p_drop,
+                                                 unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
 int hopmi_bert_attn_fwd_dt(const void* qkv, void* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev,
                            int dtype, void* stream);
 int hopmi_bert_attn_bwd_dt(const void* qkv, const void* d_out, void* dqkv, int B, int L, int H, float p_drop, unsigned seed,

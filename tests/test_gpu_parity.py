@@ -1122,21 +1122,27 @@ class _FullGolden:
         return 2.0 * 2.0 * eps_out * cond + RTOL, cond
 
     def check_params(self, sd, dsd, tag, rtol, n_steps, gan, big=4_000_000):
-        """Post-step checksums of every trainable tensor up to `big` elements (and the mapping layer's weight): `rtol` of the abs-sum;
-        the absolute slack (n_steps sign-undetermined Adam steps of lr on every element) ONLY for the tensors whose gradient is
-        analytically zero (zero_grad_param: both sides hold rounding noise there, which Adam turns into +-lr steps)."""
+        """Post-step checksums of every trainable tensor up to `big` elements (and the mapping layer's weight): `rtol` of the abs-sum,
+        plus an absolute slack counted in Adam steps: Adam turns a gradient into a +-lr step whatever its size, so an element whose
+        gradient is at rounding level may step the other way on the two sides (2 lr apart per step).  For the tensors whose gradient
+        is ANALYTICALLY zero (zero_grad_param: both sides hold rounding noise) that is every element; for all others at most one
+        element or 3 % of the elements, whichever is more -- a missed, doubled or mis-scaled update of even a 64-element bias moves
+        all of its elements by lr and fails (64 lr against an allowance of 4 lr)."""
         from oracle.golden_util import checksum, checksum_close, zero_grad_param
+
+        def slack(name, numel, lr):
+            flips = numel if zero_grad_param(name) else max(1.0, 0.03 * numel)
+            return n_steps * 2.0 * lr * flips
+
         for n, want in self.g_cs[tag].items():
             if sd[n].numel() > big and n != "mapping_layer.weight":
                 continue
-            atol = n_steps * 2e-3 * sd[n].numel() if zero_grad_param(n) else 0.0
             got = checksum(sd[n])
-            assert checksum_close(got, want, rtol, atol), (n, got, want)
+            assert checksum_close(got, want, rtol, slack(n, sd[n].numel(), 1e-3)), (n, got, want)
         if gan:
             for n, want in self.d_cs[tag].items():
-                atol = n_steps * 2e-4 * dsd[n].numel() if zero_grad_param(n) else 0.0
                 got = checksum(dsd[n])
-                assert checksum_close(got, want, rtol, atol), (n, got, want)
+                assert checksum_close(got, want, rtol, slack(n, dsd[n].numel(), 1e-4)), (n, got, want)
 
 
 def _full_golden(V, B, epoch):
@@ -1542,63 +1548,16 @@ def test_checkpoint_load_and_generate_long_vs_reference(golden, tmp_path):
     assert not m.training
 
 
-def test_gradsync_on_rccl_single_rank_group(monkeypatch):
+def test_gradsync_on_rccl_single_rank_group():
     """The bucketed all-reduce path (autograd hooks, RCCL stream hand-offs, copy-back) on the real device with a
-    1-rank RCCL group: two train_llm steps (epoch 11: discriminator + generator backward) must leave exactly the
+    1-rank RCCL group: train_llm steps (epoch 11: discriminator + generator backward) must leave exactly the
     parameters of a run without the exchange (mean over one rank = identity) up to summation order.  The N > 1
-    arithmetic is covered by the world-size-2 gloo test."""
-    import copy
+    arithmetic is covered by the world-size-2 gloo test.  Runs in a child process (tests/rccl_single_rank_worker.py): a test
+    that opens an RCCL group does not share a process with the rest of the suite."""
     import os
-    import torch.distributed as dist
-    import hopmi
-    from hopmi import steps
-    from hopmi.parallel import GradSync
-    from oracle import fill
-    from oracle.golden_util import Accel, step_args
-    dev = _dev()
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        m1, bcfg = _make_model(9, dev)
-        d1 = hopmi.ConvDiscriminator(27)
-        d1.gru.dropout = 0.0
-        fill.fill_state_(d1, salt=1)
-        d1.to(dev)
-        m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
-        inp = _inputs(9, bcfg, dev)
-        monkeypatch.setattr(steps, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
-        monkeypatch.setattr(steps, "_randperm", lambda n, device: torch.randperm(n).to(device))
-
-        def run(m, d, acc):
-            m.train(); d.train()
-            g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
-            d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
-            torch.manual_seed(5)
-            for _ in range(3):
-                ret = hopmi.train_llm(step_args(9), 11, inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"],
-                                      inp["vid_indices"], m, d, g_opt, d_opt, acc)
-            return ret
-
-        sync = GradSync([m1, d1], bucket_mb=0.25, force=True)
-        assert sync.active
-        r1 = run(m1, d1, sync)
-        r2 = run(m2, d2, Accel())
-        assert sync.bytes_reduced > 0 and len(sync.groups[0].buckets) > 1
-        # (not bitwise: under the exchange the GRU backward runs as per-time-step launches, whose partial sums are added
-        # in another order than the persistent kernel's; 3 Adam steps of 1e-3 amplify that on analytically-zero gradients)
-        assert sorted(r1) == sorted(r2)
-        for k in r1:
-            assert abs(r1[k] - r2[k]) <= 1e-4 * max(abs(r2[k]), 1e-6), (k, r1[k], r2[k])
-        for (n, a), (_, b) in zip(list(m1.named_parameters()) + list(d1.named_parameters()),
-                                  list(m2.named_parameters()) + list(d2.named_parameters())):
-            # an element whose gradient is at rounding level may step the other way: <= 2 lr per step for few elements
-            # (for every element of the analytically-zero-gradient biases, DESIGN.md 2)
-            diff = (a - b).abs()
-            assert diff.max().item() <= 6.5e-3, (n, diff.max().item())
-            assert _zero_grad_param(n) or diff.mean().item() <= 5e-5, (n, diff.mean().item())
-    finally:
-        dist.destroy_process_group()
+    from conftest import ROOT, run_isolated
+    r = run_isolated([os.path.join(ROOT, "tests", "rccl_single_rank_worker.py")], timeout=300, env={"MASTER_PORT": "29533"})
+    assert r.returncode == 0 and "RCCL_WORKER_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_native_library_is_loaded():
@@ -1644,6 +1603,52 @@ def test_gemm_split_vs_float64(M, N, K, xs, gs, parts, tol):
     # both operands as part images, tiles staged by LDS-DMA (hopmi_gemm_split_ab): the same terms in the same order
     y_ab = ops._split_gemm_ab(ops.split_rows_image(x.detach(), parts), M, ops.split_weight_image(w, parts), b, N, K, parts)
     assert torch.equal(y_ab, y.detach())
+
+
+def test_row_scales_from_the_layernorm_kernels_equal_a_pass_of_their_own(monkeypatch):
+    """The fp16-form GEMMs take their A operand's per-row scales from the kernel that produced it where that kernel had the rows
+    in registers (bias + dropout + residual + LayerNorm forward: its output; backward: dx).  Checked: the scales attached to the
+    tensors equal hopmi_row_scales on the same tensors bit for bit, they reach the consuming GEMM on BOTH sides of the autograd
+    edge (forward: split_linear's input; backward: the gradient object handed to the GEMM's backward), a modified tensor's stale
+    scales are refused, and with the fusion off the results are identical."""
+    from hopmi import ops
+    dev = _dev()
+    monkeypatch.setattr(ops, "GEMM_PARTS", 16)
+    g = torch.Generator().manual_seed(11)
+    M, D, N = 260, 768, 256
+    x = torch.randn(M, D, generator=g).to(dev).requires_grad_()
+    res = torch.randn(M, D, generator=g).to(dev)
+    bias, gamma, beta = (torch.randn(D, generator=g).to(dev) for _ in range(3))
+    w = (torch.randn(N, D, generator=g) / D ** 0.5).to(dev)
+    img, imgt = ops.split_weight_image(w, 16), ops.split_weight_image(w.t().contiguous(), 16)
+    gy = (torch.randn(M, N, generator=g) * 1e-3).to(dev)
+    passes = []
+    real = ops.row_scales
+    monkeypatch.setattr(ops, "row_scales", lambda a: (passes.append(tuple(a.shape)), real(a))[1])
+
+    def run(fused):
+        monkeypatch.setattr(ops, "RS_FUSED", fused)
+        passes.clear()
+        seen = []
+        xx = x.detach().clone().requires_grad_()
+        xx.register_hook(lambda gr: seen.append(gr))
+        h, hr = ops.bias_dropout_residual_layernorm2(xx, bias, res, gamma, beta, 1e-12, 0.1, 77)
+        att = ops._take_rs(h, M)
+        y = ops.split_linear(h, img, imgt, None, N, D, 16)
+        (y * gy).sum().backward()
+        return h.detach(), att, y.detach(), xx.grad.clone(), seen[0], list(passes)
+
+    h1, att1, y1, gx1, dx1, n1 = run(True)
+    assert att1 is not None and torch.equal(att1, real(h1))
+    assert ops._take_rs(dx1, M) is not None and torch.equal(ops._take_rs(dx1, M), real(dx1))
+    assert n1 == [(M, N)]                 # the forward GEMM took the attached scales; only dY (not LayerNorm-made) needed a pass
+    h0, att0, y0, gx0, dx0, n0 = run(False)
+    assert att0 is None and n0 == [(M, D), (M, N)]
+    assert torch.equal(h1, h0) and torch.equal(y1, y0) and torch.equal(gx1, gx0)
+    h1.add_(1.0)                          # (a tensor modified after the scales were taken: refused)
+    ops._attach_rs(h1, att1)
+    h1.mul_(2.0)
+    assert ops._take_rs(h1, M) is None
 
 
 def test_gemm_f16x2_special_values():

@@ -29,6 +29,7 @@ def child(scenario, strategy):
     import ctypes
     dev = torch.device("cuda:0")
     x = torch.randn(1024, 1024, device=dev)
+    (x @ x).sum().item()                  # (the GEMM library initialises itself in its first call: not under capture)
     L.hopmi_noop_launch(None)
     torch.cuda.synchronize()
     s = torch.cuda.Stream()
