@@ -81,35 +81,12 @@ __device__ __forceinline__ void split_pair_f16(float a, float b, unsigned (&out)
   out[1] = __builtin_bit_cast(unsigned, lo);
 }
 constexpr int F16_PARTS = 16;                      // the `parts` code of this form at the C ABI ("two fp16 parts")
-constexpr int AMAX_N = 256;                        // per-block maxima of hopmi_absmax_partials
-// max over part[0 .. 255] (as sign-cleared bit patterns), by all threads of a block of >= 256 threads; `sh` = 16 words of LDS
-__device__ __forceinline__ unsigned block_amax(const float* __restrict__ part, unsigned* sh) {
-  unsigned v = threadIdx.x < AMAX_N ? (__float_as_uint(part[threadIdx.x]) & 0x7fffffffu) : 0u;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  unsigned m = 0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = max(m, sh[w]);
-  __syncthreads();
-  return m;
-}
-
-// per-block maxima of |x| over a grid-stride share (n % 4 == 0): part[blockIdx.x], AMAX_N blocks
-__global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ part) {
-  __shared__ unsigned sh[4];
-  unsigned m = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)AMAX_N * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
-        max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = __uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3])));
-}
+// Image of a [N][K] weight for this form: hi and lo fp16 images [2][Np][Kp], Np = N rounded up to the 128-column tile, Kp = K rounded
+// up to the 32-wide k-step (pad rows / columns are zero: the kernel reads them unguarded), then Np floats: 1 / s_n, the inverse of
+// row n's power-of-two scale (every output column has its own: weight rows -- and the columns of W that become the rows of the
+// W^T image -- may differ by orders of magnitude).
+__host__ __device__ inline int f16_np(int N) { return (N + GN - 1) / GN * GN; }
+__host__ __device__ inline int f16_kp(int K) { return (K + GK - 1) / GK * GK; }
 
 // per-row power-of-two scales of A [M][K] (K % 4 == 0): out[row] = s, out[M + row] = 1 / s; one wave per row
 __global__ __launch_bounds__(256) void row_scales_kernel(const float* __restrict__ A, int M, int K, float* __restrict__ out) {
@@ -122,21 +99,37 @@ __global__ __launch_bounds__(256) void row_scales_kernel(const float* __restrict
   if (lane == 0) store_row_scale(out, M, row, m);
 }
 
-// weights -> scaled fp16 hi / lo images [2][N][K] + trailer {AMAX_N partial maxima (written by absmax_partials_kernel before
-// this launch), scale, 1 / scale}
-__global__ __launch_bounds__(256) void gemm_split_prepare_f16_kernel(const float* __restrict__ W, size_t n, unsigned* __restrict__ img,
-                                                                     float* __restrict__ trailer) {
-  __shared__ unsigned sh[16];
-  const unsigned sb = scale_bits_for_max(block_amax(trailer, sh));
-  const float s = __uint_as_float(sb);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { trailer[AMAX_N] = s; trailer[AMAX_N + 1] = inv_scale(sb); }
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // pair index
-  if (2 * i >= n) return;
-  const float2 v = reinterpret_cast<const float2*>(W)[i];
-  unsigned parts[2];
-  split_pair_f16(v.x * s, v.y * s, parts);
-  img[i] = parts[0];
-  img[n / 2 + i] = parts[1];
+// W [N][K] (row-major, K % 2 == 0) -> its image: one wave per image row n < Np (two passes over the row: maximum, then split)
+__global__ __launch_bounds__(256) void f16_prepare_rows_kernel(const float* __restrict__ W, int N, int K, int Np, int Kp,
+                                                               unsigned* __restrict__ img, float* __restrict__ inv_out) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= Np) return;
+  unsigned* hi = img + (size_t)n * (Kp / 2);
+  unsigned* lo = img + (size_t)Np * (Kp / 2) + (size_t)n * (Kp / 2);
+  if (n >= N) {
+    for (int i = lane; i < Kp / 2; i += 64) { hi[i] = 0u; lo[i] = 0u; }
+    if (lane == 0) inv_out[n] = 1.f;
+    return;
+  }
+  const float2* src = reinterpret_cast<const float2*>(W + (size_t)n * K);
+  unsigned m = 0;
+  for (int i = lane; i < K / 2; i += 64) {
+    const float2 v = src[i];
+    m = max(m, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu));
+  }
+  m = wave_max_u32(m);
+  const unsigned sb = scale_bits_for_max(m);
+  const float sc = __uint_as_float(sb);
+  if (lane == 0) inv_out[n] = inv_scale(sb);
+  for (int i = lane; i < Kp / 2; i += 64) {
+    unsigned parts[2] = {0u, 0u};
+    if (i < K / 2) {
+      const float2 v = src[i];
+      split_pair_f16(v.x * sc, v.y * sc, parts);
+    }
+    hi[i] = parts[0];
+    lo[i] = parts[1];
+  }
 }
 
 // weights -> NP bf16 part images [NP][N][K] (row-major, the MFMA B-operand's 8 consecutive k are contiguous)
@@ -168,7 +161,7 @@ __device__ __forceinline__ float gemm_gelu_grad(float v) {
 }
 
 // BM = 64 halves the tile (8 waves of 32 x 32) for shapes whose 128-row tiling leaves CUs idle or quantises badly.
-template <int NP, bool DB, int BM, bool F16 = false>
+template <int NP, bool DB, int BM, bool F16 = false, bool RAGGED = false>
 __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bimg,
                                                          const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                          int tiles_m, int tiles_n, int ep, float* __restrict__ C2,
@@ -194,8 +187,10 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   if (idx >= per + (xcd < rem ? 1 : 0)) return;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * GN;
-  // fp16 form: the weights' inverse scale from their image's trailer (the activations' per-row scales: a_rows[row], a_rows[M + row])
-  const float out_scale_b = F16 ? reinterpret_cast<const float*>(Bimg + (size_t)NP * N * K)[AMAX_N + 1] : 1.f;
+  // fp16 form: N and K are the LOGICAL extents; the weight image is padded to Np x Kp (zeros) and carries Np inverse row scales
+  // behind the two part images; the activations' per-row scales are a_rows[row] (s) and a_rows[M + row] (1 / s)
+  const int Np = F16 ? f16_np(N) : N, Kp = F16 ? f16_kp(K) : K;
+  const float* inv_b = reinterpret_cast<const float*>(Bimg + (size_t)NP * Np * Kp);
 
   // staging maps.  B (128 rows x 64 bytes per part): thread t moves 16 bytes of row (t >> 2), k = 8 (t & 3) .. +7.
   // A (BM rows x 128 bytes): BM = 128: the 32 bytes of row (t >> 2) at k = 8 (t & 3); BM = 64: 16 bytes of row (t >> 3) at
@@ -206,15 +201,19 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   const int acol = (BM == 128) ? 8 * (tid & 3) : 4 * (tid & 7);
   const float* a_src = A + (size_t)min(m0 + arow, M - 1) * K + acol;
   const float sa = F16 ? a_rows[min(m0 + arow, M - 1)] : 1.f;
-  const __bf16* b_src = Bimg + (size_t)(n0 + brow) * K + 8 * bq;
-  const size_t b_part = (size_t)N * K;
+  const __bf16* b_src = Bimg + (size_t)(n0 + brow) * Kp + 8 * bq;
+  const size_t b_part = (size_t)Np * Kp;
   const int a_off = arow * GLD + acol, b_off = brow * GLD + 8 * bq;
 
   float4 a_st[AF4];
   u32x4 b_st[NP];
   auto issue = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < AF4; ++i) a_st[i] = reinterpret_cast<const float4*>(a_src + k0)[i];
+    for (int i = 0; i < AF4; ++i) {
+      // (fp16 form: K may end inside the last k-step -- the image's pad columns are zero, the activations' must not be read)
+      if (RAGGED && k0 + acol + 4 * i >= K) a_st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      else a_st[i] = reinterpret_cast<const float4*>(a_src + k0)[i];
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) b_st[p] = *reinterpret_cast<const u32x4*>(b_src + p * b_part + k0);
   };
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / GK;
+  const int nk = Kp / GK;
   issue(0);
   commit(0);
   __syncthreads();
@@ -318,7 +317,9 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + 32 * wc + 16 * ni + n;
+    if (F16 && col >= N) continue;                   // (pad columns of the last column tile)
     const float bv = bias != nullptr ? bias[col] : 0.f;
+    const float out_scale_b = F16 ? inv_b[col] : 1.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -337,21 +338,21 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   }
 }
 
-template <int NP, bool DB, int BM, bool F16 = false>
+template <int NP, bool DB, int BM, bool F16 = false, bool RAGGED = false>
 static void launch_gemm_variant(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
                                 int ep, float* C2, const float* aux, const float* a_rows = nullptr) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = N / GN;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + GN - 1) / GN;
   const size_t lds = (size_t)(DB ? 2 : 1) * NP * (BM + GN) * GLD * sizeof(__bf16);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, DB, BM, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<NP, DB, BM, F16, RAGGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;                // every XCD gets the same number of slots; surplus ones return at once
-  hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM, F16>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
+  hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM, F16, RAGGED>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
                      K, tiles_m, tiles_n, ep, C2, aux, a_rows);
 }
 
@@ -488,9 +489,15 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
 template <int NP, bool F16 = false>
 static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
                              int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr, const float* a_rows = nullptr) {
-  const int t128 = ((M + 127) / 128) * (N / GN);
+  const int t128 = ((M + 127) / 128) * ((N + GN - 1) / GN);
   const int forced = env_int("HOPMI_GEMM_TILE", 0);       // diagnostics: 1 = 128/DB, 2 = 128/!DB, 3 = 64/!DB
   const int mode = (forced >= 1 && forced <= 3) ? forced : (t128 < 160 ? 3 : (t128 <= 256 ? 1 : 2));
+  if (F16 && (K % GK) != 0) {                             // K ends inside the last k-step: the guarded A loads
+    if (mode == 1) launch_gemm_variant<NP, true, 128, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
+    else if (mode == 2) launch_gemm_variant<NP, false, 128, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
+    else launch_gemm_variant<NP, false, 64, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
+    return check_launch("hopmi_gemm_split");
+  }
   if (mode == 1) launch_gemm_variant<NP, true, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
   else if (mode == 2) launch_gemm_variant<NP, false, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
   else launch_gemm_variant<NP, false, 64, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
@@ -507,8 +514,25 @@ extern "C" int hopmi_debug_set_stamps_gemm(long long* p) {
 }
 #endif
 
+extern "C" size_t hopmi_gemm_f16x2_image_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (size_t)2 * f16_np(N) * f16_kp(K) * sizeof(_Float16) + (size_t)f16_np(N) * sizeof(float);
+}
+
+extern "C" int hopmi_gemm_f16x2_prepare(const float* W, int N, int K, void* image, void* stream) {
+  if (!W || !image || N <= 0 || K <= 0 || (K & 1) || (reinterpret_cast<uintptr_t>(W) & 7)) {
+    set_error("hopmi_gemm_f16x2_prepare: need W [N][K] (8-byte aligned), image, even K (N=%d K=%d)", N, K);
+    return HOPMI_EINVAL;
+  }
+  const int Np = f16_np(N), Kp = f16_kp(K);
+  float* inv = reinterpret_cast<float*>(static_cast<unsigned char*>(image) + (size_t)2 * Np * Kp * sizeof(_Float16));
+  hipLaunchKernelGGL(f16_prepare_rows_kernel, dim3((Np + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), W, N, K, Np, Kp,
+                     static_cast<unsigned*>(image), inv);
+  return check_launch("hopmi_gemm_f16x2_prepare");
+}
+
 extern "C" size_t hopmi_gemm_split_image_bytes(int N, int K, int parts) {
-  if (N > 0 && K > 0 && parts == F16_PARTS) return (size_t)2 * N * K * sizeof(_Float16) + (AMAX_N + 4) * sizeof(float);
+  if (N > 0 && K > 0 && parts == F16_PARTS) return hopmi_gemm_f16x2_image_bytes(N, K);
   return (N > 0 && K > 0 && (parts == 2 || parts == 3)) ? (size_t)parts * N * K * sizeof(__bf16) : 0;
 }
 
@@ -524,8 +548,8 @@ extern "C" int hopmi_row_scales(const float* A, int M, int K, float* scales, voi
 extern "C" int hopmi_gemm_f16x2(const float* A, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
                                 const float* aux, int M, int N, int K, int epilogue, void* stream) {
   if (!A || !a_scales || !Bimage || !C) { set_error("hopmi_gemm_f16x2: null pointer argument"); return HOPMI_EINVAL; }
-  if (M <= 0 || N <= 0 || K <= 0 || N % GN || K % GK) {
-    set_error("hopmi_gemm_f16x2: need N %% 128 == 0, K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) {
+    set_error("hopmi_gemm_f16x2: need K %% 4 == 0 and a 16-byte aligned A (M=%d N=%d K=%d)", M, N, K);
     return HOPMI_EINVAL;
   }
   if (epilogue < EP_BIAS || epilogue > EP_GELU_GRAD || (epilogue == EP_GELU_GRAD && !aux)) {
@@ -543,16 +567,7 @@ extern "C" int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts,
   const size_t n = (size_t)N * K;
   const unsigned grid = (unsigned)((n / 2 + 255) / 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (parts == F16_PARTS) {
-    if ((n & 3) || (reinterpret_cast<uintptr_t>(W) & 15)) {
-      set_error("hopmi_gemm_split_prepare: the fp16 form needs N K %% 4 == 0 and a 16-byte aligned W");
-      return HOPMI_EINVAL;
-    }
-    float* trailer = reinterpret_cast<float*>(static_cast<unsigned char*>(image) + 2 * n * sizeof(_Float16));
-    hipLaunchKernelGGL(absmax_partials_kernel, dim3(AMAX_N), dim3(256), 0, st, W, n / 4, trailer);
-    hipLaunchKernelGGL(gemm_split_prepare_f16_kernel, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image), trailer);
-    return check_launch("hopmi_gemm_split_prepare");
-  }
+  if (parts == F16_PARTS) return hopmi_gemm_f16x2_prepare(W, N, K, image, stream);
   if (parts == 2) hipLaunchKernelGGL(gemm_split_prepare_kernel<2>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
   else hipLaunchKernelGGL(gemm_split_prepare_kernel<3>, dim3(grid), dim3(256), 0, st, W, n, static_cast<unsigned*>(image));
   return check_launch("hopmi_gemm_split_prepare");

@@ -346,6 +346,8 @@ def split_weight_image(w: torch.Tensor, parts: int) -> torch.Tensor:
 
 
 def split_gemm_supported(N: int, K: int) -> bool:
+    if GEMM_PARTS == F16_PARTS:                      # (the fp16 form pads its weight image to whole tiles)
+        return K % 4 == 0 and N % 2 == 0
     return N % 128 == 0 and K % 32 == 0
 
 
@@ -701,6 +703,7 @@ def cast_cache_reset():
     made by an eager call lives in the eager allocator pool, and a recording that was served that copy would bake its address in
     without recording the cast (stale or freed memory on every replay); a copy made while recording lives in the graph's pool."""
     _CAST_CACHE.clear()
+    _F16_IMG.clear()
 
 
 def _cast_param(w, dt):
@@ -772,8 +775,103 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
-def linear(x, w, b=None):
-    """F.linear(x, w, b); with a bias that needs a gradient, through _LinearFn."""
+# ---- trainable linears on the fp16 hi/lo GEMM form (fp32 mode) --------------------------------------------------------------
+# The generator's own nn.Linear layers and GRU input projections (HOP.py:118,130-134,166-167,259-265) are fp32 library GEMMs at
+# 100-130 TFLOP/s; hopmi_gemm_f16x2 computes the same products fp32-equivalently at ~2 x that.  Forward y = x W^T + b and the
+# activation gradient dX = dY W go through it; the weight gradient dW = dY^T x (both operands activations, contraction over the
+# rows) stays with the library.  The weights are trainable: their images (W for the forward, W^T for dX, one launch each) are
+# rebuilt when the weight's version counter moves, i.e. once per optimizer step, and shared by the step's forwards.
+F16_LINEAR = __import__("os").environ.get("HOPMI_F16_LINEAR", "1") != "0"
+# From M N K = 5e9 on (tools/bench_linear.py, against the TUNED library kernels: GRU input projections 120 -> 80 us + 9 us of row
+# scales, align layer 96 -> 60, beat MLP 214 -> 134; below, the row-scales pass and the weight images eat the gain)
+F16_LINEAR_MIN_MNK = 5.0e9
+_F16_IMG = {}                       # (ids of the owner parameters, N, K, transpose) -> (weak references, versions, image, made under capture)
+
+
+def f16_weight_image(w, transpose=False, owners=None):
+    """The hopmi_gemm_f16x2 image of the row-major (N, K) weight `w` (transpose: of w^T, for dX = dY w).  `owners`: the
+    nn.Parameter objects `w` is (a view or packed alias of): the image is cached under their identities and version counters (a
+    hit must also come from the same side of a recording as the lookup, as in `_cast_param`); without owners nothing is cached
+    (addresses and version counters of temporaries repeat)."""
+    N, K = w.shape
+    L = _lib.lib()
+
+    def build():
+        wd = _dev_f32(w.detach().t().contiguous() if transpose else w.detach(), "weight")
+        n, k = wd.shape
+        img = torch.empty(L.hopmi_gemm_f16x2_image_bytes(n, k), dtype=torch.uint8, device=w.device)
+        _lib.check(L.hopmi_gemm_f16x2_prepare(wd.data_ptr(), n, k, img.data_ptr(), _stream()), "hopmi_gemm_f16x2_prepare")
+        return img
+
+    if not owners:
+        return build()
+    cap = torch.cuda.is_current_stream_capturing()
+    key = tuple(id(o) for o in owners) + (N, K, bool(transpose))
+    vers = tuple(o._version for o in owners)
+    hit = _F16_IMG.get(key)
+    if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == vers and hit[3] == cap:
+        return hit[2]
+    img = build()
+    if len(_F16_IMG) > 256:
+        _F16_IMG.clear()
+    _F16_IMG[key] = (tuple(weakref.ref(o) for o in owners), vers, img, cap)
+    return img
+
+
+def f16_linear_ok(x, w, b, owners=None) -> bool:
+    """Does `linear` send this product to hopmi_gemm_f16x2?  A weight with known owner parameters (its images are cached per optimizer
+    step), fp32 operands on the device, no autocast, K % 4 == 0, and enough work for the form to beat the tuned library GEMM."""
+    return bool(F16_LINEAR and owners and GEMM_PARTS == F16_PARTS and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
+                and w.dim() == 2 and (b is None or b.dtype == torch.float32) and not torch.is_autocast_enabled("cuda")
+                and w.shape[1] % 4 == 0 and w.shape[0] >= 128 and w.is_contiguous() and w.data_ptr() % 16 == 0
+                and float(x.numel()) * w.shape[0] >= F16_LINEAR_MIN_MNK)
+
+
+class _F16LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, owners):
+        N, K = w.shape
+        x2 = _dev_f32(x.detach(), "x").reshape(-1, K)
+        y = _split_gemm(x2, f16_weight_image(w, owners=owners), None if b is None else _dev_f32(b.detach(), "bias"), N, K, F16_PARTS,
+                        a_part=_take_rs(x, x2.shape[0]))
+        ctx.save_for_backward(x2, w)
+        ctx.x_shape, ctx.has_b, ctx.owners = x.shape, b is not None, owners
+        return torch.ops.aten._unsafe_view(y, list(x.shape[:-1]) + [N])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        N, K = w.shape
+        dy2 = _dev_f32(dy, "dy").reshape(-1, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if N % 4 == 0 and K >= 128:                  # (dX contracts over N: the kernel's K % 4 == 0 rule applies to it here)
+                dx = _split_gemm(dy2, f16_weight_image(w, transpose=True, owners=ctx.owners), None, K, N, F16_PARTS,
+                                 a_part=_take_rs(dy, dy2.shape[0]))
+            else:
+                dx = dy2 @ w
+            dx = dx.view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = dy2.t() @ x2
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, owners=None):
+    """F.linear(x, w, b).  `owners` = the nn.Parameter objects behind `w` (the weight itself for an nn.Linear; both directions'
+    parameters for a packed GRU weight): with them, in fp32 mode and with enough work, the product runs on hopmi_gemm_f16x2
+    (`_F16LinearFn`, fp32-equivalent); otherwise the library, with a bias that needs a gradient through _LinearFn (column-sum
+    kernel)."""
+    if f16_linear_ok(x, w, b, owners):
+        owners = tuple(owners)
+        if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad))):
+            N, K = w.shape
+            x2 = _dev_f32(x.detach(), "x").reshape(-1, K)
+            y = _split_gemm(x2, f16_weight_image(w, owners=owners), None if b is None else _dev_f32(b.detach(), "bias"), N, K, F16_PARTS,
+                            a_part=_take_rs(x, x2.shape[0]))
+            return y.view(*x.shape[:-1], N)
+        return _F16LinearFn.apply(x, w, b, owners)
     if b is None or not (torch.is_grad_enabled() and b.requires_grad):
         return torch.nn.functional.linear(x, w, b)
     return _LinearFn.apply(x, w, b)
@@ -783,7 +881,7 @@ class Linear(torch.nn.Linear):
     """torch.nn.Linear (same parameters, same state_dict keys) whose forward is `linear` above."""
 
     def forward(self, x):
-        return linear(x, self.weight, self.bias)
+        return linear(x, self.weight, self.bias, owners=(self.weight,))
 
 
 class _BiasGeluBf16Fn(torch.autograd.Function):
@@ -1544,7 +1642,8 @@ def gru_bidirectional(x: torch.Tensor, gru: torch.nn.GRU, dropout_p: float = 0.0
     for layer in range(gru.num_layers):
         al = lambda n: _PackedAlias.apply(bufs[layer][n], getattr(gru, f"{n}_l{layer}"), getattr(gru, f"{n}_l{layer}_reverse"))
         w_ih, b_ih = al("weight_ih"), al("bias_ih")
-        gi = linear(inp, w_ih.flatten(0, 1), b_ih.flatten()).view(inp.shape[0], inp.shape[1], 2, 3 * H)
+        gi = linear(inp, w_ih.flatten(0, 1), b_ih.flatten(), owners=(getattr(gru, f"weight_ih_l{layer}"), getattr(gru, f"weight_ih_l{layer}_reverse"))
+                    ).view(inp.shape[0], inp.shape[1], 2, 3 * H)
         inp = gru_layer(gi, al("weight_hh"), al("bias_hh"))
         if dropout_p > 0 and training and layer < gru.num_layers - 1:
             inp = torch.nn.functional.dropout(inp, dropout_p, True)

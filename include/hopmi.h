@@ -420,11 +420,18 @@ int hopmi_gemm_split_ep(const float* A, const void* Bimage, const float* bias, f
 
 /* The fp16 hi/lo form of the same product (round 4): every operand carried as TWO scaled fp16 numbers, THREE MFMA terms
  * (hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_f16), fp32-equivalent like the six-term bf16 form at half the matrix work
- * (csrc/gemm.hip).  hopmi_gemm_split_prepare / _image_bytes take parts = 16 for the weight image of this form (hi and lo images of
- * W 2^s + a trailer holding s: one power-of-two scale per weight tensor).  The activations carry one power-of-two scale PER ROW:
- * a_scales [2][M] = {s_row, 1 / s_row}, written by hopmi_row_scales(A, M, K, a_scales) -- or by whichever kernel produced A.
- * epilogue / C2 / aux as hopmi_gemm_split_ep.  Replaces the same reference arithmetic: the HF BERT linears behind
- * model/HOP.py:204 (built at run_ted.py:177-195). */
+ * (csrc/gemm.hip).  Any M, N and any K % 4 == 0: the weight image is padded to whole tiles.
+ *   hopmi_gemm_f16x2_prepare(W [N][K], N, K, image): the image of W, the Bt operand of y = x W^T (for dX = dY W the caller
+ *     prepares the image of the row-major W^T, [K][N]).  One launch; one power-of-two scale per image row.  Frozen weights: once;
+ *     trainable weights: once per optimizer step (hopmi/ops.py caches by owner parameter + version counter).
+ *     hopmi_gemm_split_prepare / _image_bytes with parts = 16 are the same calls.
+ *   a_scales [2][M] = {s_row, 1 / s_row}: the activations' power-of-two scale PER ROW, written by hopmi_row_scales(A, M, K, a_scales)
+ *     -- or by whichever kernel produced A (hopmi_bias_dropout_residual_layernorm_*_rs).
+ *   epilogue / C2 / aux as hopmi_gemm_split_ep.
+ * Replaces: the HF BERT linears behind model/HOP.py:204 (built at run_ted.py:177-195) and the generator's own nn.Linear / GRU input
+ * projections (HOP.py:118,130-134,166-167,259-265: align_layer, beat, gru weight_ih, the reprogramming projections). */
+size_t hopmi_gemm_f16x2_image_bytes(int N, int K);
+int hopmi_gemm_f16x2_prepare(const float* W, int N, int K, void* image, void* stream);
 int hopmi_row_scales(const float* A, int M, int K, float* scales, void* stream);
 int hopmi_gemm_f16x2(const float* A, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
                      const float* aux, int M, int N, int K, int epilogue, void* stream);

@@ -1651,6 +1651,45 @@ def test_row_scales_from_the_layernorm_kernels_equal_a_pass_of_their_own(monkeyp
     assert ops._take_rs(h1, M) is None
 
 
+@pytest.mark.parametrize("M,N,K", [(4352, 2100, 700), (4352, 2100, 992), (2048, 1700, 3400), (1100, 170, 1700), (4352, 768, 1536),
+                                   (1500, 1024, 768), (1030, 130, 68)])
+def test_f16_linear_trainable_weights_vs_float64(M, N, K, monkeypatch):
+    """ops.linear on the fp16 hi/lo GEMM form for TRAINABLE weights at the generator's own shapes (GRU input projections
+    2100 x 700 / 992, beat MLP, align layer, reprogramming projections; ragged N and K: the image is padded): forward, dX (through
+    the W^T image made from the same row-major W), dW and db (library / column-sum kernel) against float64, each within 3 x the
+    library fp32 path's own error; and the images follow the weight: after an in-place update of W the next call sees the new
+    values (version counter)."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5 * torch.logspace(-2, 2, N).unsqueeze(1)).to(dev).requires_grad_()   # rows of very different scale
+    b = torch.randn(N, generator=g).to(dev).requires_grad_()
+    gy = torch.randn(M, N, generator=g).to(dev)
+    monkeypatch.setattr(ops, "F16_LINEAR_MIN_MNK", 0.0)
+    assert ops.f16_linear_ok(x, w, b, owners=(w,)) and not ops.f16_linear_ok(x, w, b)
+    y = ops.linear(x, w, b, owners=(w,))
+    y.backward(gy)
+    x64, w64, b64 = (t.detach().double().requires_grad_() for t in (x, w, b))
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    y64.backward(gy.double())
+    xl, wl, bl = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    yl = torch.nn.functional.linear(xl, wl, bl)
+    yl.backward(gy)
+    for name, got, lib, want in (("y", y, yl, y64), ("dx", x.grad, xl.grad, x64.grad), ("dw", w.grad, wl.grad, w64.grad), ("db", b.grad, bl.grad, b64.grad)):
+        e, el = rel_err(got.double(), want), rel_err(lib.double(), want)
+        assert e <= 3 * el + 1e-7, (name, e, el)
+    with torch.no_grad():
+        w.mul_(-0.5)
+        y2 = ops.linear(x.detach(), w, b, owners=(w,))
+        assert rel_err(y2.double(), torch.nn.functional.linear(x64.detach(), -0.5 * w64.detach(), b64.detach())) <= 4e-6
+    # another weight of the same shape at the same address (what the allocator does with temporaries) is another owner: no stale image
+    w2 = torch.empty_like(w)
+    w2.copy_(torch.randn(N, K, generator=g))
+    y3 = ops.linear(x.detach(), w2, None, owners=(w2,))
+    assert rel_err(y3.double(), x64.detach() @ w2.double().t()) <= 4e-6
+
+
 def test_gemm_f16x2_special_values():
     """The fp16 form's scaling on degenerate operands: an all-zero activation matrix gives exactly the bias; one huge element
     (1e30) beside ordinary ones neither overflows nor disturbs the other rows (the scales are per row), and its own row is good to
