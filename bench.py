@@ -305,10 +305,16 @@ def main():
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "median_ms_per_step": median_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 storage, accumulation and elementwise arithmetic; the contractions inside the hand-written kernels run on the bf16 "
-                      "matrix cores as split-bf16 products with f32 accumulation: THREE terms (~2^-16 per product) in the WaveNet "
-                      "(wn_stack / wn_layer fwd + bwd), reprogramming-attention and GRU-recurrence kernels, SIX terms (f32-equivalent) "
-                      "in the frozen BERT's linears; library GEMMs f32" if args.dtype == "fp32" else
+            "dtype": ("f32 storage, accumulation and elementwise arithmetic; the contractions inside the hand-written kernels run on the "
+                      "16-bit matrix cores with f32 accumulation: THREE split-bf16 terms (~2^-16 per product) in the WaveNet "
+                      "(wn_stack / wn_layer fwd + bwd), reprogramming-attention and GRU-recurrence kernels; "
+                      + {"f16x2": "three terms of power-of-two-scaled fp16 hi/lo parts (22 significand bits per operand: f32-equivalent) in the "
+                                  "frozen BERT's linears and in the large trainable linears (GRU input projections, align layer, beat MLP: "
+                                  "forward and activation gradient)",
+                         "split3": "SIX split-bf16 terms (f32-equivalent) in the frozen BERT's linears",
+                         "split2": "THREE split-bf16 terms in the frozen BERT's linears",
+                         "library": "the frozen BERT's linears on the library's f32 GEMM"}[args.bert_gemm]
+                      + "; the remaining library GEMMs f32" if args.dtype == "fp32" else
                       "bf16 library GEMMs (autocast), bf16 activations between them (dtype argument of the BERT / GRU / attention HIP "
                       "kernels) + bf16 gradient exchange; inside the HIP kernels f32 accumulation and elementwise arithmetic with "
                       "split-bf16 MFMA products (3 terms, ~2^-16 per product); f32 WaveNet stack, master weights and optimizer"),

@@ -55,6 +55,8 @@ def mapping_grad_rows(dS, E, r0, r1, out_w, out_b, bf16=False):
     g = dS[r0:r1]
     if bf16:
         out_w[r0:r1].copy_(g.to(torch.bfloat16) @ E.to(torch.bfloat16).t())
+    elif _ops.f16_mm_nt_ok(g, E, (E,)):
+        _ops.f16_mm_nt(g.contiguous(), E, (E,), out=out_w[r0:r1])       # (E frozen: its image is made once, in an eager call)
     else:
         torch.mm(g, E.t(), out=out_w[r0:r1])
     torch.sum(g, dim=1, out=out_b[r0:r1])

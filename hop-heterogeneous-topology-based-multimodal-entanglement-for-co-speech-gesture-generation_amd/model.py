@@ -82,12 +82,19 @@ class _SplitKAffine(torch.autograd.Function):
         S = torch.bmm(W.view(W.shape[0], ks, kc).transpose(0, 1), E.view(ks, kc, E.shape[1])).sum(0)
         S += b.unsqueeze(1)
         ctx.save_for_backward(W, E)
+        ctx.E_obj = E                       # (the object itself: the cached fp16-form image of the frozen E is keyed on it)
         return S
 
     @staticmethod
     def backward(ctx, dS):
         W, E = ctx.saved_tensors
-        dW = dS @ E.t() if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[0]:
+            # dS (1500 x 768) E^T: E itself (30522 x 768, frozen) is the row-major Bt operand of the fp16 hi/lo GEMM form
+            if not ctx.needs_input_grad[1] and ops.f16_mm_nt_ok(dS, ctx.E_obj, (ctx.E_obj,)):
+                dW = ops.f16_mm_nt(dS.contiguous(), ctx.E_obj, (ctx.E_obj,))
+            else:
+                dW = dS @ E.t()
         dE = W.t() @ dS if ctx.needs_input_grad[1] else None
         db = dS.sum(1) if ctx.needs_input_grad[2] else None
         return dW, dE, db, None

@@ -380,9 +380,11 @@ def _take_rs(t, M):
 RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"     # row scales from the producing kernels (0: always a pass of their own)
 
 
-def _split_gemm(a2d, img, bias, N, K, parts, a_part=None):
+def _split_gemm(a2d, img, bias, N, K, parts, a_part=None, out=None):
     if parts == F16_PARTS:
-        return _split_gemm_ep(a2d, img, bias, N, K, parts, 0, a_part=a_part)[0]
+        return _split_gemm_ep(a2d, img, bias, N, K, parts, 0, a_part=a_part, out=out)[0]
+    if out is not None:
+        raise _lib.HopmiError("hopmi _split_gemm: `out` is for the fp16 form")
     M = a2d.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
     L = _lib.lib()
@@ -436,11 +438,14 @@ def split_linear(x, img_w, img_wt, bias, N, K, parts):
     return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
 
 
-def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None):
+def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None):
     """hopmi_gemm_split_ep / hopmi_gemm_f16x2: epilogue 0 -> a2d W^T + bias; 1 -> (gelu(h), h if keep else None) with
     h = a2d W^T + bias; 2 -> (a2d W^T) * gelu'(aux).  `a_part`: the fp16 form's per-row scales of a2d (row_scales) when the caller has them."""
     M = a2d.shape[0]
-    out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a2d.device:
+        raise _lib.HopmiError(f"hopmi _split_gemm: `out` must be a contiguous float32 ({M}, {N}) tensor on {a2d.device}")
     h = torch.empty_like(out) if (epilogue == 1 and keep) else None
     L = _lib.lib()
     if parts == F16_PARTS:
@@ -786,6 +791,7 @@ F16_LINEAR = __import__("os").environ.get("HOPMI_F16_LINEAR", "1") != "0"
 # scales, align layer 96 -> 60, beat MLP 214 -> 134; below, the row-scales pass and the weight images eat the gain)
 F16_LINEAR_MIN_MNK = 5.0e9
 _F16_IMG = {}                       # (ids of the owner parameters, N, K, transpose) -> (weak references, versions, image, made under capture)
+_F16_IMG_FROZEN = {}                # the same for owners that take no gradient (never reset by a recording)
 
 
 def f16_weight_image(w, transpose=False, owners=None):
@@ -805,16 +811,21 @@ def f16_weight_image(w, transpose=False, owners=None):
 
     if not owners:
         return build()
-    cap = torch.cuda.is_current_stream_capturing()
     key = tuple(id(o) for o in owners) + (N, K, bool(transpose))
-    vers = tuple(o._version for o in owners)
-    hit = _F16_IMG.get(key)
+    vers = tuple(o._version for o in owners) + (w.data_ptr(),)
+    # FROZEN owners (no gradient): the image is static -- one table that no recording resets (a recording may hold the address of an
+    # image made by an eager call: the table keeps it alive until the weight itself changes, and GraphedTrainStep drops its
+    # recordings when a frozen parameter's version moves)
+    frozen = not any(o.requires_grad for o in owners)
+    table = _F16_IMG_FROZEN if frozen else _F16_IMG
+    cap = False if frozen else torch.cuda.is_current_stream_capturing()
+    hit = table.get(key)
     if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == vers and hit[3] == cap:
         return hit[2]
     img = build()
-    if len(_F16_IMG) > 256:
-        _F16_IMG.clear()
-    _F16_IMG[key] = (tuple(weakref.ref(o) for o in owners), vers, img, cap)
+    if not frozen and len(table) > 256:
+        table.clear()
+    table[key] = (tuple(weakref.ref(o) for o in owners), vers, img, cap)
     return img
 
 
@@ -825,6 +836,23 @@ def f16_linear_ok(x, w, b, owners=None) -> bool:
                 and w.dim() == 2 and (b is None or b.dtype == torch.float32) and not torch.is_autocast_enabled("cuda")
                 and w.shape[1] % 4 == 0 and w.shape[0] >= 128 and w.is_contiguous() and w.data_ptr() % 16 == 0
                 and float(x.numel()) * w.shape[0] >= F16_LINEAR_MIN_MNK)
+
+
+def f16_mm_nt_ok(a2d, w, owners) -> bool:
+    return bool(F16_LINEAR and owners and GEMM_PARTS == F16_PARTS and a2d.is_cuda and a2d.dtype == torch.float32 and w.dtype == torch.float32
+                and a2d.dim() == 2 and w.dim() == 2 and not torch.is_autocast_enabled("cuda") and w.shape[1] % 4 == 0 and w.is_contiguous()
+                and w.data_ptr() % 16 == 0 and a2d.shape[0] >= F16_LINEAR_MIN_ROWS and float(a2d.numel()) * w.shape[0] >= F16_LINEAR_MIN_MNK)
+
+
+def f16_mm_nt(a2d, w, owners, out=None):
+    """a2d (M, K) @ w (N, K)^T on hopmi_gemm_f16x2 (no autograd), the image of `w` cached under `owners` -- e.g. the mapping
+    layer's weight gradient dW = dS E^T against the FROZEN word embeddings E (30522 x 768: E itself is the row-major Bt operand)."""
+    N, K = w.shape
+    a2d = _dev_f32(a2d.detach(), "a")
+    return _split_gemm(a2d, f16_weight_image(w, owners=tuple(owners)), None, N, K, F16_PARTS, a_part=_take_rs(a2d, a2d.shape[0]), out=out)
+
+
+F16_LINEAR_MIN_ROWS = 1024          # below: the 128-row tiles leave the chip empty
 
 
 class _F16LinearFn(torch.autograd.Function):
