@@ -183,15 +183,8 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   const int ntiles = tiles_m * tiles_n;
   const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
   const int per = ntiles >> 3, rem = ntiles & 7;
-  const int mine = per + (xcd < rem ? 1 : 0);
-  if (idx >= mine) return;
-  // experiment (HOPMI_GEMM_PAIR, bits 8.. of `ep`): the two-per-CU form -- workgroups idx and idx + P of an XCD's run are assumed to
-  // share a CU (P = CUs per XCD): give them ADJACENT tiles (same A panel), so that their A loads coincide in the CU's vector cache
-  const int pairP = ep >> 8;
-  ep &= 0xff;
-  int off = idx;
-  if (pairP > 0 && idx < 2 * pairP && 2 * pairP <= mine) off = 2 * (idx % pairP) + idx / pairP;
-  const int tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + off;
+  const int tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+  if (idx >= per + (xcd < rem ? 1 : 0)) return;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * GN;
   // fp16 form: N and K are the LOGICAL extents; the weight image is padded to Np x Kp (zeros) and carries Np inverse row scales
@@ -359,9 +352,8 @@ static void launch_gemm_variant(const float* A, const void* Bimg, const float* b
   }
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;                // every XCD gets the same number of slots; surplus ones return at once
-  const int pairP = DB ? 0 : env_int("HOPMI_GEMM_PAIR", 0);
   hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM, F16, RAGGED>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
-                     K, tiles_m, tiles_n, ep | (pairP << 8), C2, aux, a_rows);
+                     K, tiles_m, tiles_n, ep, C2, aux, a_rows);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
