@@ -48,6 +48,9 @@ def parse():
                     help="the frozen BERT's linears: the library's fp32 GEMM; hopmi_gemm_f16x2 (two scaled fp16 parts per operand, "
                          "three MFMA terms: fp32-equivalent, default); hopmi_gemm_split with 3 bf16 parts per operand (six MFMA terms: "
                          "fp32-equivalent) or 2 parts (three terms: 2^-16-class products)")
+    ap.add_argument("--strict-fp32", action="store_true",
+                    help="A/B: the three-term kernel families (WaveNet forward, reprogramming attention, GRU recurrences) on their "
+                         "fp32-exact forms (hopmi.strict_fp32): what the default owes to the 2^-16 products, as an upper bound")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the shipped table")
     ap.add_argument("--tuned-table", default=None, help="another TunableOp table than the shipped one (A/B runs)")
     ap.add_argument("--flat-exchange", action="store_true",
@@ -204,6 +207,7 @@ def main():
     V = 9 if args.dataset == "TED" else 42
     B = args.batch
     hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
+    hopmi.strict_fp32(bool(args.strict_fp32))
     hopmi.gemm_parts({"library": 0, "f16x2": 16, "split3": 3, "split2": 2}[args.bert_gemm])      # (fp32 mode only: bf16 mode autocasts)
     tuned = (not args.no_tuned_gemms) and hopmi.use_tuned_gemms(args.tuned_table)      # (the table holds fp32 and bf16 shapes)
     torch.manual_seed(0)                                       # identical replicas
@@ -305,9 +309,13 @@ def main():
             "value": world * B * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "median_ms_per_step": median_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 storage, accumulation and elementwise arithmetic; the contractions inside the hand-written kernels run on the "
-                      "16-bit matrix cores with f32 accumulation: THREE split-bf16 terms (~2^-16 per product) in the WaveNet "
-                      "(wn_stack / wn_layer fwd + bwd), reprogramming-attention and GRU-recurrence kernels; "
+            "dtype": (("f32 storage, accumulation and elementwise arithmetic; STRICT fp32 (hopmi.strict_fp32): the WaveNet block composed from "
+                       "the exact-f32 graph-conv kernel + library f32 GEMMs, the GRU recurrences as per-step exact-f32 kernels, the "
+                       "reprogramming attention as f32 tensor operations; " if args.strict_fp32 else
+                       "f32 storage, accumulation and elementwise arithmetic; the contractions inside the hand-written kernels run on the "
+                       "16-bit matrix cores with f32 accumulation: THREE split-bf16 terms (~2^-16 per product) in the WaveNet forward "
+                       "(wn_stack / wn_layer), reprogramming-attention and GRU-recurrence kernels (WaveNet backward and BERT "
+                       "self-attention: exact-f32 MFMA); ")
                       + {"f16x2": "three terms of power-of-two-scaled fp16 hi/lo parts (22 significand bits per operand: f32-equivalent) in the "
                                   "frozen BERT's linears and in the large trainable linears (GRU input projections, align layer, beat MLP: "
                                   "forward and activation gradient)",

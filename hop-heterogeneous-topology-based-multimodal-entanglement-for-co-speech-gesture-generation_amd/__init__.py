@@ -19,4 +19,4 @@ from .infer import generate_long                      # noqa: F401
 from .graph import GraphedTrainStep                   # noqa: F401
 from .feeder import HostFeeder, log_melspec           # noqa: F401
 from .tuning import use_tuned_gemms                   # noqa: F401
-from .ops import gemm_parts                           # noqa: F401
+from .ops import gemm_parts, strict_fp32              # noqa: F401

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libhopmi.so")
+_LIB_PATH = os.environ.get("HOPMI_LIB") or os.path.join(_HERE, "libhopmi.so")      # (HOPMI_LIB: a probe build of the same ABI)
 _lib = None
 
 _F = ctypes.POINTER(ctypes.c_float)

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   float4 a_st[AF4];
   u32x4 b_st[NP];
   auto issue = [&](int k0) {
+#ifdef HOPMI_GEMM_EXP_NOLOAD
+    if (k0 > 0) return;                              // (timing experiment: results wrong)
+#endif
 #pragma unroll
     for (int i = 0; i < AF4; ++i) {
       // (fp16 form: K may end inside the last k-step -- the image's pad columns are zero, the activations' must not be read)

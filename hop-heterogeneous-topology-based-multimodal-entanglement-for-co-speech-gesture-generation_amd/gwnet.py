@@ -268,6 +268,8 @@ class gwnet(nn.Module):
                 bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
                 bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
                 bn.num_batches_tracked += 1
+                # (the row replay_bn_update() re-applies when a later forward of the step reuses this one: mean | rstd | unbiased variance)
+                self._bn_keep.items.append(torch.cat([mean, torch.rsqrt(var + bn.eps), var * (n / max(n - 1, 1))]).float())
         else:
             mean, var = bn.running_mean, bn.running_var
         scale = bn.weight * torch.rsqrt(var + bn.eps)
@@ -349,10 +351,10 @@ class gwnet(nn.Module):
             A1, A2 = self.adjacency()
             prep = ops.gcn_prepare(A1, A2)      # on-chip images of the mix matrices, shared by all layers
             wimg = self._weight_images() if self.dropout == 0 else None
-            tails = self._skip_tails_fused(x, prep, wimg) if (not torch.is_grad_enabled() and self.dropout == 0) else None
+            tails = self._skip_tails_fused(x, prep, wimg) if (not torch.is_grad_enabled() and self.dropout == 0 and not ops.STRICT_FP32) else None
         if tails is not None:
             return self._tail(tails)
-        if self.training and self.dropout == 0 and ops.wn_fused_training_supported(x.shape[2]):
+        if self.training and self.dropout == 0 and ops.wn_fused_training_supported(x.shape[2]) and not ops.STRICT_FP32:
             # differentiable fused stack: one forward and one backward kernel per WaveNet layer
             params = []
             for i in range(len(DILATIONS)):
@@ -365,8 +367,10 @@ class gwnet(nn.Module):
             tails = _WaveNetStackFn.apply(x, A1, A2, prep, wimg, list(self.bn), keep, *params)
             self._count_batches()
             return self._tail(tails)
-        # eval-mode BatchNorm with autograd (fine-tuning with frozen statistics): composed from the gcn kernel
-        # and library GEMMs
+        # eval-mode BatchNorm with autograd (fine-tuning with frozen statistics), graphs beyond the fused kernels' size, and
+        # ops.strict_fp32: composed from the gcn kernel (exact-fp32 MFMA) and library GEMMs
+        if self.training:
+            self._bn_keep = _Keep()
         T_out = x.shape[1] - sum(DILATIONS)
         tails = []
         last = len(DILATIONS) - 1

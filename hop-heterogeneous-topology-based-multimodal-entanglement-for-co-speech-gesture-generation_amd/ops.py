@@ -312,6 +312,31 @@ def cut_point(t):
 
 # ------------------------------------------------------- frozen-weight linears on split-bf16 MFMA (hopmi_gemm_split)
 CAST_CACHE_ENABLED = __import__("os").environ.get("HOPMI_CAST_CACHE", "1") != "0"
+# ---- strict fp32 (A/B switch) ---------------------------------------------------------------------------------------------
+# The default path takes the contractions INSIDE three kernel families as three-term split-bf16 products (~2^-16 per product):
+# the fused WaveNet forward kernels (wn_stack / wn_layer), the reprogramming attention and the persistent GRU recurrences.
+# Everything else is exact fp32 or fp32-equivalent (WaveNet backward and BERT self-attention on the exact-fp32 MFMA, the fp16
+# hi/lo GEMM form, library GEMMs).  `strict_fp32(True)` (or HOPMI_STRICT_FP32=1) routes those three families to their
+# fp32-exact forms that the repository already carries: the WaveNet block as the composition of the graph-conv kernel
+# (exact-fp32 MFMA) with library fp32 GEMMs and torch's BatchNorm (gwnet.forward_cl's composed branch), the GRU recurrences as
+# per-time-step launches of the exact-fp32 kernel, the reprogramming attention as fp32 tensor operations (scores materialised).
+# It exists to say what the default owes to the 2^-16 products (bench.py --strict-fp32) -- an upper bound, since
+# the exact forms are also less fused.
+STRICT_FP32 = False
+
+
+def strict_fp32(on=None):
+    """Switch the three-term kernel families to their fp32-exact forms (see above).  Returns the previous setting."""
+    global STRICT_FP32
+    prev = STRICT_FP32
+    if on is not None:
+        STRICT_FP32 = bool(on)
+        import os
+        os.environ["HOPMI_GRU_SMALL"] = "0" if STRICT_FP32 else "1"       # (the small-hidden-size GRU kernels are three-term too)
+        _lib.lib().hopmi_reload_env()
+    return prev
+
+
 F16_PARTS = 16      # the `parts` code of the fp16 hi/lo form (two scaled fp16 parts per operand, three MFMA terms, fp32-equivalent)
 # 16: fp16 hi/lo, three terms (fp32-equivalent, default since round 4);  3: six-term bf16 split (fp32-equivalent);
 # 2: three-term bf16 split (2^-16 class);  0: library fp32 GEMM (hipBLASLt)
@@ -1231,6 +1256,12 @@ def hop_losses(out, target, out_rand=None, z_context=None, z_rand=None, mu=None,
 
 
 def reprog_attention(q, k, v, scale, p_drop=0.0, seed=0):
+    if STRICT_FP32 and q.dtype == torch.float32:
+        # HOP.py:289-299 as fp32 tensor operations (scores materialised; torch's dropout stream, not the kernel's hash)
+        p = torch.softmax(scale * torch.einsum("blhe,she->bhls", q, k.float()), dim=-1)
+        if p_drop > 0.0:
+            p = torch.nn.functional.dropout(p, p_drop, True)
+        return torch.einsum("bhls,she->blhe", p, v.float())
     return _ReprogAttnFn.apply(q, k, v, scale, p_drop, seed)
 
 
@@ -1490,7 +1521,7 @@ class no_persistent_gru:
 
 def gru_persistent_allowed() -> bool:
     import os
-    return (_PERSISTENT_HOLD == 0 and os.environ.get("HOPMI_GRU_PERSISTENT", "1") != "0"
+    return (_PERSISTENT_HOLD == 0 and not STRICT_FP32 and os.environ.get("HOPMI_GRU_PERSISTENT", "1") != "0"
             and os.environ.get("HOPMI_REHEARSE_ONE_GPU") != "1")
 
 
