@@ -99,6 +99,23 @@ def all_reduce_mean_finish(flat, pending):
         flat.div_(div)
 
 
+def inplace_group_ok(group=None) -> bool:
+    """Can a LIST of tensors be all-reduced in place under one RCCL group call (ncclGroupStart / End: one launch, no flat copy)?"""
+    import os
+    return (os.environ.get("HOPMI_EXCHANGE_INPLACE", "1") != "0" and hasattr(dist, "_coalescing_manager")
+            and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl")
+
+
+def all_reduce_mean_group(tensors, group=None, async_op=False):
+    """All-reduce (mean) every tensor of the list IN PLACE under one RCCL group call -- what the flat form does with two copies of
+    all the gradients around one all-reduce (pack / unpack: 2 x 80 MB read + written per step at fp32).  Returns the manager
+    (`async_op`: `.wait()` it: the current stream then waits for the collective)."""
+    with dist._coalescing_manager(group=group, async_ops=async_op) as cm:
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+    return cm
+
+
 def _params_behind(tensors):
     """ids of the leaf tensors (parameters) that the autograd graphs of `tensors` reach."""
     seen, out = set(), set()
@@ -188,7 +205,7 @@ class _Capture:
 
 class GraphedTrainStep:
     def __init__(self, args, model, discriminator, model_optim, dis_optimizer, accelerator=None, group=None,
-                 eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False, debug=False, overlap=True):
+                 eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False, debug=False, overlap=True, inplace=False):
         """`accelerator`: what the eager calls hand to train_llm (a GradSync when more than one rank trains; default a
         plain backward).  `grad_dtype=torch.bfloat16` halves the bytes of the flat gradient exchanges (the sums still
         land in fp32 gradients).  `enabled=False` makes every call the eager step (for A/B runs).  `force_exchange` runs
@@ -209,6 +226,13 @@ class GraphedTrainStep:
         self.eager_left = {}                        # phase (gan flag) -> eager calls still to make before recording it
         self.grad_dtype = grad_dtype
         self.overlap = bool(overlap)
+        # `inplace=True` (fp32 exchange over RCCL only): the gradient tensors are all-reduced IN PLACE under one RCCL group call instead
+        # of pack -> one all-reduce -> unpack (2 x 80 MB of copies).  Measured on the 1-rank rehearsal (round 4, one box,
+        # gpurun_out/rs4_*.log): NOT faster -- 16.19 vs 16.11 ms (TED), 22.60 vs 22.41 (GAN), 13.19 vs 13.11 (V = 42) against 15.71 /
+        # 21.93 / 12.70 without any exchange: a group call over ~150 tensors costs more than the two flat copies it saves, and what
+        # the exchange adds to the step is mostly its cuts and launches, not the copies.  Kept as an option for a measurement on
+        # real links; the flat form stays the default.
+        self.inplace = bool(inplace)
         self.enabled = enabled
         self.debug = debug
         self.records = {}
@@ -302,9 +326,15 @@ class GraphedTrainStep:
         if not early:
             return
         grads = [p.grad for p in early]
+        pending, grp = {}, self.group
+        if self._inplace():
+            # in place under one RCCL group call: the gradient tensors themselves are what the collective reads and writes
+            cap.keep.append(grads)
+            cap.cut(lambda: pending.__setitem__("w", all_reduce_mean_group(grads, grp, async_op=True)))
+            cap.early = dict(ids={id(p) for p in early}, grads=grads, views=None, flat=None, pending=pending)
+            return
         flat, views, _ = self._pack(grads)
         cap.keep.append(flat)
-        pending, grp = {}, self.group
         cap.cut(lambda: pending.__setitem__("w", all_reduce_mean_start(flat, grp)))
         cap.early = dict(ids={id(p) for p in early}, grads=grads, views=views, flat=flat, pending=pending)
 
@@ -318,6 +348,23 @@ class GraphedTrainStep:
                      and (early is None or id(p) not in early["ids"])]
             if not is_disc and self._has_proto and self._S.grad is not None:
                 grads.append(self._S.grad)
+            if self._inplace():
+                # this rank's persistent-kernel status words ride as one more (1-element) tensor of the group call
+                words = [w.float().reshape(()) for w in cap.status]
+                word = torch.zeros(1, dtype=torch.float32, device=grads[0].device)
+                if words:
+                    word.copy_(torch.stack(words).sum().reshape(1))
+                tensors = grads + [word]
+                cap.keep.append(tensors)
+                grp = self.group
+                if early is None:
+                    cap.cut(lambda: all_reduce_mean_group(tensors, grp))
+                else:
+                    e_pending = early["pending"]
+                    cap.cut(lambda: (e_pending.pop("w").wait(), all_reduce_mean_group(tensors, grp)))
+                self._peer_status.add_(word[0])
+                self._mapping_rows(is_disc)
+                return
             flat, views, n = self._pack(grads, extra=1)
             # one more element: this rank's persistent-GRU status words so far in the replay.  A hand-off time-out on one rank
             # then shows up in EVERY rank's next loss fetch, so all ranks raise at the same step instead of the healthy ones
@@ -334,6 +381,13 @@ class GraphedTrainStep:
                 torch._foreach_copy_(early["grads"], early["views"])
             torch._foreach_copy_(grads, views)
             self._peer_status.add_(flat[n].float())
+        self._mapping_rows(is_disc)
+
+    def _inplace(self):
+        return self.inplace and self.grad_dtype is None and inplace_group_ok(self.group)
+
+    def _mapping_rows(self, is_disc):
+        """Behind the generator's exchange: dS -> this rank's rows of the mapping layer's gradients."""
         if not is_disc and self._has_proto:
             m = self.model
             dS = self._S.grad

@@ -59,6 +59,43 @@ def main():
             diff = (a - b).abs()
             assert diff.max().item() <= 6.5e-3, (n, diff.max().item())
             assert _zero_grad_param(n) or diff.mean().item() <= 5e-5, (n, diff.mean().item())
+        # ---- the recorded step's exchange on the same 1-rank group (force_exchange): gradients all-reduced IN PLACE under one RCCL
+        # group call (`inplace=True`) and through the flat pack / all-reduce / unpack form (the default) must both reproduce the
+        # recording without any exchange (a mean over one rank is the identity): same losses at every step, same parameters after
+        steps._randn_like = lambda t: torch.full_like(t, 0.5)
+        steps._randperm = lambda n, device: torch.arange(n - 1, -1, -1, device=device)
+        from hopmi import graph as hgraph
+        assert hgraph.inplace_group_ok(None)
+        base_m, base_d = copy.deepcopy(m2), copy.deepcopy(d2)
+        batch = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"], inp["vid_indices"])
+
+        def recorded(**kw):
+            m, d = copy.deepcopy(base_m), copy.deepcopy(base_d)
+            m._randn_like = lambda t: torch.full_like(t, 0.25)
+            m.train(); d.train()
+            g_opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+            d_opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999))
+            step = hopmi.GraphedTrainStep(step_args(9), m, d, g_opt, d_opt, eager_calls=1, **kw)
+            rets = [step(11, *batch) for _ in range(4)]
+            assert step.n_replay == 3, step.n_replay
+            kinds = [k for rec in step.records.values() for k, _ in rec["cap"].plan]
+            return rets, m, d, kinds
+
+        r_plain, m_p, d_p, k_plain = recorded()
+        r_inpl, m_i, d_i, k_inpl = recorded(force_exchange=True, inplace=True)
+        r_flat, m_f, d_f, k_flat = recorded(force_exchange=True)
+        assert "eager" not in k_plain[:-1] or k_plain.count("eager") <= 1, k_plain      # (only the loss-fetch cut)
+        assert k_inpl.count("eager") >= 4 and k_flat.count("eager") == k_inpl.count("eager"), (k_inpl, k_flat)
+        for name, rr, mm, dd in (("in place", r_inpl, m_i, d_i), ("flat", r_flat, m_f, d_f)):
+            for it, (a, b) in enumerate(zip(r_plain, rr)):
+                assert sorted(a) == sorted(b), (name, it, a, b)
+                for k in a:
+                    assert abs(a[k] - b[k]) <= 2e-4 * max(abs(a[k]), 1e-6), (name, it, k, a[k], b[k])
+            for (n, a), (_, b) in zip(list(m_p.named_parameters()) + list(d_p.named_parameters()),
+                                      list(mm.named_parameters()) + list(dd.named_parameters())):
+                diff = (a - b).abs()
+                assert diff.max().item() <= 8.5e-3, (name, n, diff.max().item())
+                assert _zero_grad_param(n) or diff.mean().item() <= 1e-4, (name, n, diff.mean().item())
     finally:
         dist.destroy_process_group()
     print("RCCL_WORKER_OK", flush=True)
