@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3   # exact-f32 MFMA == vector peak
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def parse():

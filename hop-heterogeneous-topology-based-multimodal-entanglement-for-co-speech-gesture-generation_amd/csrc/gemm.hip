@@ -165,8 +165,12 @@ template <int NP, bool DB, int BM, bool F16 = false, bool RAGGED = false>
 __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bimg,
                                                          const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
                                                          int tiles_m, int tiles_n, int ep, float* __restrict__ C2,
-                                                         const float* __restrict__ aux, const float* __restrict__ a_rows) {
+                                                         const float* __restrict__ aux, const float* __restrict__ a_rows, int a_parts,
+                                                         float* __restrict__ c_rowmax) {
   static_assert(!F16 || NP == 2, "the fp16 form carries two parts");
+  // fp16 form: this tile's per-row activation scales (s, 1 / s) and, when asked for, the per-row maxima of what it writes
+  __shared__ float s_scale[F16 ? BM : 1], s_inv[F16 ? BM : 1];
+  __shared__ unsigned s_cmax[F16 ? BM : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // [buffer 2][A: part NP x BM rows | B: part NP x 128 rows][GLD]
   __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
@@ -200,7 +204,29 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   const int arow = (BM == 128) ? (tid >> 2) : (tid >> 3);
   const int acol = (BM == 128) ? 8 * (tid & 3) : 4 * (tid & 7);
   const float* a_src = A + (size_t)min(m0 + arow, M - 1) * K + acol;
-  const float sa = F16 ? a_rows[min(m0 + arow, M - 1)] : 1.f;
+  if (F16) {
+    // a_parts == 0: a_rows = [2][M] scale pairs (hopmi_row_scales / the LayerNorm kernels); a_parts = P > 0: a_rows = [P][M] partial
+    // row maxima of |A| as the kernel that produced A left them (one per workgroup that held a piece of the row): reduced here
+    if (tid < BM) {
+      const int row = min(m0 + tid, M - 1);
+      float sc, iv;
+      if (a_parts == 0) {
+        sc = a_rows[row];
+        iv = a_rows[M + row];
+      } else {
+        unsigned mx = 0;
+        for (int pp = 0; pp < a_parts; ++pp) mx = max(mx, __float_as_uint(a_rows[(size_t)pp * M + row]) & 0x7fffffffu);
+        const unsigned sb = scale_bits_for_max(mx);
+        sc = __uint_as_float(sb);
+        iv = inv_scale(sb);
+      }
+      s_scale[tid] = sc;
+      s_inv[tid] = iv;
+      s_cmax[tid] = 0u;
+    }
+    __syncthreads();
+  }
+  const float sa = F16 ? s_scale[arow] : 1.f;
   const __bf16* b_src = Bimg + (size_t)(n0 + brow) * Kp + 8 * bq;
   const size_t b_part = (size_t)Np * Kp;
   const int a_off = arow * GLD + acol, b_off = brow * GLD + 8 * bq;
@@ -317,6 +343,11 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
   }
 
   // epilogue: lane (q, n) holds rows 4q + r, column n of every 16 x 16 tile
+  unsigned rmx[F16 ? MI : 1][4];                     // (fp16 form, c_rowmax: max |value written| per row this lane touches)
+#pragma unroll
+  for (int mi = 0; mi < (F16 ? MI : 1); ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rmx[mi][r] = 0u;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + 32 * wc + 16 * ni + n;
@@ -327,23 +358,42 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (BM / 2) * wr + 16 * mi + 4 * q + r;
+        const int rl = (BM / 2) * wr + 16 * mi + 4 * q + r, row = m0 + rl;
         if (row < M) {
           const size_t at = (size_t)row * N + col;
-          const float h = F16 ? acc[mi][ni][r] * a_rows[M + row] * out_scale_b + bv : acc[mi][ni][r] + bv;
-          if (ep == EP_BIAS) C[at] = h;
+          const float h = F16 ? acc[mi][ni][r] * s_inv[rl] * out_scale_b + bv : acc[mi][ni][r] + bv;
+          float out;
+          if (ep == EP_BIAS) out = h;
           else if (ep == EP_GELU) {
             if (C2 != nullptr) C2[at] = h;
-            C[at] = gemm_gelu(h);
-          } else C[at] = h * gemm_gelu_grad(aux[at]);
+            out = gemm_gelu(h);
+          } else out = h * gemm_gelu_grad(aux[at]);
+          C[at] = out;
+          if (F16) rmx[mi][r] = max(rmx[mi][r], __float_as_uint(out) & 0x7fffffffu);
         }
       }
+  }
+  if (F16 && c_rowmax != nullptr) {
+    // the 16 lanes that share q hold 16 columns each of the same rows; then the four column waves through LDS; one row of
+    // c_rowmax [tiles_n][M] per column tile: the consuming GEMM reduces the tiles_n partial maxima in its prologue
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsigned v = rmx[mi][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+        if (n == 0) atomicMax(&s_cmax[(BM / 2) * wr + 16 * mi + 4 * q + r], v);
+      }
+    __syncthreads();
+    if (tid < BM && m0 + tid < M) c_rowmax[(size_t)tn * M + m0 + tid] = __uint_as_float(s_cmax[tid]);
   }
 }
 
 template <int NP, bool DB, int BM, bool F16 = false, bool RAGGED = false>
 static void launch_gemm_variant(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
-                                int ep, float* C2, const float* aux, const float* a_rows = nullptr) {
+                                int ep, float* C2, const float* aux, const float* a_rows = nullptr, int a_parts = 0,
+                                float* c_rowmax = nullptr) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + GN - 1) / GN;
   const size_t lds = (size_t)(DB ? 2 : 1) * NP * (BM + GN) * GLD * sizeof(__bf16);
   static bool attr_done = false;
@@ -356,7 +406,7 @@ static void launch_gemm_variant(const float* A, const void* Bimg, const float* b
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;                // every XCD gets the same number of slots; surplus ones return at once
   hipLaunchKernelGGL((gemm_split_kernel<NP, DB, BM, F16, RAGGED>), dim3(grid), dim3(GT), lds, st, A, static_cast<const __bf16*>(Bimg), bias, C, M, N,
-                     K, tiles_m, tiles_n, ep, C2, aux, a_rows);
+                     K, tiles_m, tiles_n, ep, C2, aux, a_rows, a_parts, c_rowmax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -491,19 +541,20 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
 // one step ahead (-12...-30 %).
 template <int NP, bool F16 = false>
 static int launch_gemm_split(const float* A, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
-                             int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr, const float* a_rows = nullptr) {
+                             int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr, const float* a_rows = nullptr,
+                             int a_parts = 0, float* c_rowmax = nullptr) {
   const int t128 = ((M + 127) / 128) * ((N + GN - 1) / GN);
   const int forced = env_int("HOPMI_GEMM_TILE", 0);       // diagnostics: 1 = 128/DB, 2 = 128/!DB, 3 = 64/!DB
   const int mode = (forced >= 1 && forced <= 3) ? forced : (t128 < 160 ? 3 : (t128 <= 256 ? 1 : 2));
   if (F16 && (K % GK) != 0) {                             // K ends inside the last k-step: the guarded A loads
-    if (mode == 1) launch_gemm_variant<NP, true, 128, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
-    else if (mode == 2) launch_gemm_variant<NP, false, 128, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
-    else launch_gemm_variant<NP, false, 64, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
+    if (mode == 1) launch_gemm_variant<NP, true, 128, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows, a_parts, c_rowmax);
+    else if (mode == 2) launch_gemm_variant<NP, false, 128, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows, a_parts, c_rowmax);
+    else launch_gemm_variant<NP, false, 64, F16, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows, a_parts, c_rowmax);
     return check_launch("hopmi_gemm_split");
   }
-  if (mode == 1) launch_gemm_variant<NP, true, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
-  else if (mode == 2) launch_gemm_variant<NP, false, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
-  else launch_gemm_variant<NP, false, 64, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows);
+  if (mode == 1) launch_gemm_variant<NP, true, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows, a_parts, c_rowmax);
+  else if (mode == 2) launch_gemm_variant<NP, false, 128, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows, a_parts, c_rowmax);
+  else launch_gemm_variant<NP, false, 64, F16>(A, Bimg, bias, C, M, N, K, st, ep, C2, aux, a_rows, a_parts, c_rowmax);
   return check_launch("hopmi_gemm_split");
 }
 
@@ -548,9 +599,14 @@ extern "C" int hopmi_row_scales(const float* A, int M, int K, float* scales, voi
   return check_launch("hopmi_row_scales");
 }
 
-extern "C" int hopmi_gemm_f16x2(const float* A, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
-                                const float* aux, int M, int N, int K, int epilogue, void* stream) {
-  if (!A || !a_scales || !Bimage || !C) { set_error("hopmi_gemm_f16x2: null pointer argument"); return HOPMI_EINVAL; }
+extern "C" int hopmi_gemm_f16x2_tiles_n(int N) { return N > 0 ? (N + GN - 1) / GN : 0; }
+
+extern "C" int hopmi_gemm_f16x2(const float* A, const float* a_scales, int a_parts, const void* Bimage, const float* bias, float* C,
+                                float* C2, const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream) {
+  if (!A || !a_scales || !Bimage || !C || a_parts < 0 || a_parts > 1024) {
+    set_error("hopmi_gemm_f16x2: null pointer argument / a_parts=%d", a_parts);
+    return HOPMI_EINVAL;
+  }
   if (M <= 0 || N <= 0 || K <= 0 || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) {
     set_error("hopmi_gemm_f16x2: need K %% 4 == 0 and a 16-byte aligned A (M=%d N=%d K=%d)", M, N, K);
     return HOPMI_EINVAL;
@@ -559,7 +615,8 @@ extern "C" int hopmi_gemm_f16x2(const float* A, const float* a_scales, const voi
     set_error("hopmi_gemm_f16x2: epilogue %d (0 bias, 1 gelu, 2 gelu gradient: needs aux)", epilogue);
     return HOPMI_EINVAL;
   }
-  return launch_gemm_split<2, true>(A, Bimage, bias, C, M, N, K, static_cast<hipStream_t>(stream), epilogue, C2, aux, a_scales);
+  return launch_gemm_split<2, true>(A, Bimage, bias, C, M, N, K, static_cast<hipStream_t>(stream), epilogue, C2, aux, a_scales, a_parts,
+                                    c_rowmax);
 }
 
 extern "C" int hopmi_gemm_split_prepare(const float* W, int N, int K, int parts, void* image, void* stream) {

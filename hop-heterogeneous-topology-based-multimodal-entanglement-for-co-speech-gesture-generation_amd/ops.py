@@ -406,6 +406,8 @@ RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"     # row 
 
 
 def _split_gemm(a2d, img, bias, N, K, parts, a_part=None, out=None):
+    """`a_part` (fp16 form): the A operand's [2][M] row-scale pairs, or a ([P][M] partial row maxima, P) pair as a producing GEMM's
+    `rowmax` left them; None: a hopmi_row_scales pass."""
     if parts == F16_PARTS:
         return _split_gemm_ep(a2d, img, bias, N, K, parts, 0, a_part=a_part, out=out)[0]
     if out is not None:
@@ -463,7 +465,7 @@ def split_linear(x, img_w, img_wt, bias, N, K, parts):
     return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
 
 
-def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None):
+def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None, rowmax=None):
     """hopmi_gemm_split_ep / hopmi_gemm_f16x2: epilogue 0 -> a2d W^T + bias; 1 -> (gelu(h), h if keep else None) with
     h = a2d W^T + bias; 2 -> (a2d W^T) * gelu'(aux).  `a_part`: the fp16 form's per-row scales of a2d (row_scales) when the caller has them."""
     M = a2d.shape[0]
@@ -476,10 +478,17 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
     if parts == F16_PARTS:
         if a_part is None:
             a_part = row_scales(a2d)
+        a_t, a_p = a_part if isinstance(a_part, tuple) else (a_part, 0)
+        if tuple(a_t.shape) != ((a_p, M) if a_p else (2, M)) or a_t.dtype != torch.float32 or not a_t.is_contiguous():
+            raise _lib.HopmiError(f"hopmi _split_gemm: bad operand-scale tensor {tuple(a_t.shape)} for M = {M}, parts = {a_p}")
+        # `rowmax` (a list): receives ([tiles_n][M] partial row maxima of the output, tiles_n) -- the `a_part` of the GEMM that consumes it
+        cm = torch.empty(L.hopmi_gemm_f16x2_tiles_n(N), M, dtype=torch.float32, device=a2d.device) if rowmax is not None else None
         _lib.check(_timed("gemm_split", 4 * (M * K + (3 if (h is not None or aux is not None) else 2) * M * N) + 4 * N * K, 2 * M * N * K,
-                          lambda: L.hopmi_gemm_f16x2(a2d.data_ptr(), a_part.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h),
-                                                     _ptr(aux), M, N, K, epilogue, _stream())),
+                          lambda: L.hopmi_gemm_f16x2(a2d.data_ptr(), a_t.data_ptr(), a_p, img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h),
+                                                     _ptr(aux), _ptr(cm), M, N, K, epilogue, _stream())),
                    "hopmi_gemm_f16x2")
+        if rowmax is not None:
+            rowmax.append((cm, cm.shape[0]))
         return out, h
     _lib.check(_timed("gemm_split", 4 * (M * K + (3 if (h is not None or aux is not None) else 2) * M * N) + 2 * parts * N * K, 2 * M * N * K,
                       lambda: L.hopmi_gemm_split_ep(a2d.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h), _ptr(aux), M, N, K,
@@ -499,8 +508,10 @@ class _SplitFfnFn(torch.autograd.Function):
     def forward(ctx, x, img1, img1t, b1, img2, img2t, N1, K, parts):
         x = _dev_f32(x, "x")
         rs = _take_rs(x, x.numel() // K) if parts == F16_PARTS else None
-        f, h = _split_gemm_ep(x.reshape(-1, K), img1, _dev_f32(b1.detach(), "bias"), N1, K, parts, 1, keep=ctx.needs_input_grad[0], a_part=rs)
-        o = _split_gemm(f, img2, None, K, N1, parts)
+        fmax = [] if (parts == F16_PARTS and RS_FUSED) else None           # the GELU epilogue leaves its output's row maxima
+        f, h = _split_gemm_ep(x.reshape(-1, K), img1, _dev_f32(b1.detach(), "bias"), N1, K, parts, 1, keep=ctx.needs_input_grad[0], a_part=rs,
+                              rowmax=fmax)
+        o = _split_gemm(f, img2, None, K, N1, parts, a_part=fmax[0] if fmax else None)
         ctx.save_for_backward(h)
         ctx.imgs, ctx.dims = (img1t, img2t), (N1, K, parts)
         return o.view(*x.shape[:-1], K)
@@ -513,8 +524,9 @@ class _SplitFfnFn(torch.autograd.Function):
         N1, K, parts = ctx.dims
         do = _dev_f32(do, "do")
         rs = _take_rs(do, do.numel() // K) if parts == F16_PARTS else None
-        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h, a_part=rs)           # (dO W2) * gelu'(h)
-        dx = _split_gemm(dh, img1t, None, K, N1, parts)                                           # dH W1
+        dmax = [] if (parts == F16_PARTS and RS_FUSED) else None
+        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h, a_part=rs, rowmax=dmax)   # (dO W2) * gelu'(h)
+        dx = _split_gemm(dh, img1t, None, K, N1, parts, a_part=dmax[0] if dmax else None)                         # dH W1
         return dx.view(*do.shape), None, None, None, None, None, None, None, None
 
 

@@ -425,16 +425,21 @@ int hopmi_gemm_split_ep(const float* A, const void* Bimage, const float* bias, f
  *     prepares the image of the row-major W^T, [K][N]).  One launch; one power-of-two scale per image row.  Frozen weights: once;
  *     trainable weights: once per optimizer step (hopmi/ops.py caches by owner parameter + version counter).
  *     hopmi_gemm_split_prepare / _image_bytes with parts = 16 are the same calls.
- *   a_scales [2][M] = {s_row, 1 / s_row}: the activations' power-of-two scale PER ROW, written by hopmi_row_scales(A, M, K, a_scales)
- *     -- or by whichever kernel produced A (hopmi_bias_dropout_residual_layernorm_*_rs).
+ *   a_parts = 0: a_scales [2][M] = {s_row, 1 / s_row}, the activations' power-of-two scale PER ROW, written by
+ *     hopmi_row_scales(A, M, K, a_scales) -- or by whichever kernel produced A (hopmi_bias_dropout_residual_layernorm_*_rs).
+ *   a_parts = P > 0: a_scales [P][M] = partial row maxima of |A| (one per workgroup of the producer that held a piece of the row),
+ *     reduced and turned into scales in this kernel's prologue -- what c_rowmax of another hopmi_gemm_f16x2 call is.
+ *   c_rowmax (nullable): [hopmi_gemm_f16x2_tiles_n(N)][M] receives, per column tile, the row maxima of |C| as written (after the
+ *     epilogue): the a_scales / a_parts = tiles_n of the GEMM that consumes C (BertIntermediate -> BertOutput.dense and its backward).
  *   epilogue / C2 / aux as hopmi_gemm_split_ep.
  * Replaces: the HF BERT linears behind model/HOP.py:204 (built at run_ted.py:177-195) and the generator's own nn.Linear / GRU input
  * projections (HOP.py:118,130-134,166-167,259-265: align_layer, beat, gru weight_ih, the reprogramming projections). */
 size_t hopmi_gemm_f16x2_image_bytes(int N, int K);
 int hopmi_gemm_f16x2_prepare(const float* W, int N, int K, void* image, void* stream);
 int hopmi_row_scales(const float* A, int M, int K, float* scales, void* stream);
-int hopmi_gemm_f16x2(const float* A, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
-                     const float* aux, int M, int N, int K, int epilogue, void* stream);
+int hopmi_gemm_f16x2_tiles_n(int N);
+int hopmi_gemm_f16x2(const float* A, const float* a_scales, int a_parts, const void* Bimage, const float* bias, float* C, float* C2,
+                     const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream);
 
 /* The same product with BOTH operands as part images (Aimage = hopmi_gemm_split_prepare(A, M, K, parts, ...), i.e.
  * [parts][M][K] bf16; a producer may also write that layout itself): nothing is split inside the kernel, every tile is staged
