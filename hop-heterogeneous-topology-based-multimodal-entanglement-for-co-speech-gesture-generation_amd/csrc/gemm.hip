@@ -99,6 +99,31 @@ __global__ __launch_bounds__(256) void row_scales_kernel(const float* __restrict
   if (lane == 0) store_row_scale(out, M, row, m);
 }
 
+// A [M][K] (K % 4 == 0) -> the A operand of the LDS-DMA form: scaled fp16 hi / lo images [2][M][K] and the scale pairs [2][M]; one
+// wave per row (maximum, then split: the row is read twice, the second time from the caches)
+__global__ __launch_bounds__(256) void f16_rows_image_kernel(const float* __restrict__ A, int M, int K, unsigned* __restrict__ img,
+                                                             float* __restrict__ scales) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float4* src = reinterpret_cast<const float4*>(A + (size_t)row * K);
+  unsigned m = 0;
+  for (int i = lane; i < K / 4; i += 64) m = abs_bits_max4(m, src[i]);
+  m = wave_max_u32(m);
+  const unsigned sb = scale_bits_for_max(m);
+  const float sc = __uint_as_float(sb);
+  if (lane == 0) { scales[row] = sc; scales[M + row] = inv_scale(sb); }
+  u32x2* hi = reinterpret_cast<u32x2*>(img + (size_t)row * (K / 2));
+  u32x2* lo = reinterpret_cast<u32x2*>(img + (size_t)M * (K / 2) + (size_t)row * (K / 2));
+  for (int i = lane; i < K / 4; i += 64) {
+    const float4 v = src[i];
+    unsigned p0[2], p1[2];
+    split_pair_f16(v.x * sc, v.y * sc, p0);
+    split_pair_f16(v.z * sc, v.w * sc, p1);
+    hi[i] = u32x2{p0[0], p1[0]};
+    lo[i] = u32x2{p0[1], p1[1]};
+  }
+}
+
 // W [N][K] (row-major, K % 2 == 0) -> its image: one wave per image row n < Np (two passes over the row: maximum, then split)
 __global__ __launch_bounds__(256) void f16_prepare_rows_kernel(const float* __restrict__ W, int N, int K, int Np, int Kp,
                                                                unsigned* __restrict__ img, float* __restrict__ inv_out) {
@@ -420,10 +445,13 @@ static void launch_gemm_variant(const float* A, const void* Bimg, const float* b
 // is issued while tile kt is multiplied; a counted s_waitcnt leaves the youngest tiles in flight across the raw barrier.
 __device__ __forceinline__ int gswz(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }
 
-template <int NP, int NBUF>
+// F16: the fp16 hi/lo form (NP = 2) -- A image [2][M][K] of scaled fp16 parts + a_rows [2][M] scale pairs as hopmi_rows_image_f16
+// writes them, B image padded to Np rows with its Np inverse row scales behind it (f16_np / hopmi_gemm_f16x2_prepare); N may be
+// ragged (store guard), K % 32 == 0.  The same three terms in the same order as gemm_split_kernel<2, ., ., true>: bit-identical.
+template <int NP, int NBUF, bool F16 = false>
 __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Bimg,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N,
-                                                             int K, int tiles_m, int tiles_n) {
+                                                             int K, int tiles_m, int tiles_n, const float* __restrict__ a_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int IMG = 128 * 64;                    // bytes of one part image of one operand tile
   constexpr int BUFB = 2 * NP * IMG;               // [A parts | B parts]
@@ -442,7 +470,9 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   const int srow = 16 * wv + (lane >> 2), sslot = (lane & 3) ^ gswz(lane >> 2);
   const __bf16* a_src = Aimg + (size_t)min(m0 + srow, M - 1) * K + 8 * sslot;
   const __bf16* b_src = Bimg + (size_t)(n0 + srow) * K + 8 * sslot;
-  const size_t a_part = (size_t)M * K, b_part = (size_t)N * K;
+  const int Np = F16 ? f16_np(N) : N;
+  const size_t a_part = (size_t)M * K, b_part = (size_t)Np * K;
+  const float* inv_b = reinterpret_cast<const float*>(Bimg + (size_t)NP * Np * K);
   auto stage = [&](int kt) {
     unsigned char* dst = smem_raw + (kt % NBUF) * BUFB + wv * 1024;
     const int k0 = kt * GK;
@@ -490,7 +520,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 #pragma unroll
         for (int s = NP - 1; s >= 0; --s)
 #pragma unroll
-          for (int i = 0; i <= s; ++i) c = mfma_bf16(af[mi][i], bf[s - i], c);
+          for (int i = 0; i <= s; ++i) c = F16 ? mfma_f16(af[mi][i], bf[s - i], c) : mfma_bf16(af[mi][i], bf[s - i], c);
         acc[mi][ni] = c;
       }
     }
@@ -504,32 +534,35 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + 32 * wc + 16 * ni + n;
+    if (F16 && col >= N) continue;                   // (pad columns of the last column tile)
     const float bv = bias != nullptr ? bias[col] : 0.f;
+    const float sb = F16 ? inv_b[col] : 1.f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 64 * wr + 16 * mi + 4 * q + r;
-        if (row < M) C[(size_t)row * N + col] = acc[mi][ni][r] + bv;
+        if (row < M) C[(size_t)row * N + col] = F16 ? acc[mi][ni][r] * a_rows[M + row] * sb + bv : acc[mi][ni][r] + bv;
       }
   }
 }
 
-template <int NP, int NBUF>
-static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st) {
-  const int tiles_m = (M + 127) / 128, tiles_n = N / GN;
+template <int NP, int NBUF, bool F16 = false>
+static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
+                           const float* a_rows = nullptr) {
+  const int tiles_m = (M + 127) / 128, tiles_n = (N + GN - 1) / GN;
   const size_t lds = (size_t)NBUF * 2 * NP * 128 * 64;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<NP, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<NP, NBUF, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
-                     static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF, F16>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
+                     static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n, a_rows);
 }
 
 // Tile choice by the number of 128 x 128 tiles, measured at the frozen BERT's shapes for M = 4352 (TED, batch 128) and M = 2176
@@ -597,6 +630,29 @@ extern "C" int hopmi_row_scales(const float* A, int M, int K, float* scales, voi
   }
   hipLaunchKernelGGL(row_scales_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), A, M, K, scales);
   return check_launch("hopmi_row_scales");
+}
+
+extern "C" int hopmi_rows_image_f16(const float* A, int M, int K, void* image, float* scales, void* stream) {
+  if (!A || !image || !scales || M <= 0 || K <= 0 || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) {
+    set_error("hopmi_rows_image_f16: need A (16-byte aligned), image [2][M][K] fp16, scales [2 M], K %% 4 == 0 (M=%d K=%d)", M, K);
+    return HOPMI_EINVAL;
+  }
+  hipLaunchKernelGGL(f16_rows_image_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), A, M, K,
+                     static_cast<unsigned*>(image), scales);
+  return check_launch("hopmi_rows_image_f16");
+}
+
+extern "C" int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M,
+                                   int N, int K, void* stream) {
+  if (!Aimage || !a_scales || !Bimage || !C) { set_error("hopmi_gemm_f16x2_ab: null pointer argument"); return HOPMI_EINVAL; }
+  if (M <= 0 || N <= 0 || K <= 0 || K % GK) {
+    set_error("hopmi_gemm_f16x2_ab: need K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+    return HOPMI_EINVAL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (env_int("HOPMI_GEMM_NBUF", 3) == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales);
+  else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales);
+  return check_launch("hopmi_gemm_f16x2_ab");
 }
 
 extern "C" int hopmi_gemm_f16x2_tiles_n(int N) { return N > 0 ? (N + GN - 1) / GN : 0; }

@@ -403,6 +403,10 @@ def _take_rs(t, M):
 
 
 RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"     # row scales from the producing kernels (0: always a pass of their own)
+# the LDS-DMA form of the fp16 GEMM (_split_gemm_ep): faster back to back (24 vs 30 us, 71 vs 92), bit-identical -- and no gain in
+# the step (15.96 vs 15.96 ms, A/B twice on one box: the image pass it needs costs what the k-loop split it saves did), so off
+GEMM_AB = __import__("os").environ.get("HOPMI_GEMM_AB", "0") == "1"
+GEMM_AB_MAX_N = 1024
 
 
 def _split_gemm(a2d, img, bias, N, K, parts, a_part=None, out=None):
@@ -476,6 +480,18 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
     h = torch.empty_like(out) if (epilogue == 1 and keep) else None
     L = _lib.lib()
     if parts == F16_PARTS:
+        if (a_part is None and GEMM_AB and epilogue == 0 and rowmax is None and N <= GEMM_AB_MAX_N and K % 32 == 0
+                and M >= F16_LINEAR_MIN_ROWS):
+            # no scales at hand and a problem that one 128 x 128 tile per CU covers: the pass that would take the row scales writes the
+            # operand's fp16 images as well, and the LDS-DMA form multiplies (bit-identical; tools/bench_gemm.py: 24 vs 30 us at
+            # N = K = 768, 71 vs 92 at K = 3072, M = 4352)
+            img_a = torch.empty(4 * M * K, dtype=torch.uint8, device=a2d.device)
+            sc = torch.empty(2, M, dtype=torch.float32, device=a2d.device)
+            _lib.check(L.hopmi_rows_image_f16(a2d.data_ptr(), M, K, img_a.data_ptr(), sc.data_ptr(), _stream()), "hopmi_rows_image_f16")
+            _lib.check(_timed("gemm_split", 4 * (M * K + M * N) + 4 * N * K, 2 * M * N * K,
+                              lambda: L.hopmi_gemm_f16x2_ab(img_a.data_ptr(), sc.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K,
+                                                            _stream())), "hopmi_gemm_f16x2_ab")
+            return out, None
         if a_part is None:
             a_part = row_scales(a2d)
         a_t, a_p = a_part if isinstance(a_part, tuple) else (a_part, 0)

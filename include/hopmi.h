@@ -441,6 +441,15 @@ int hopmi_gemm_f16x2_tiles_n(int N);
 int hopmi_gemm_f16x2(const float* A, const float* a_scales, int a_parts, const void* Bimage, const float* bias, float* C, float* C2,
                      const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream);
 
+/* The fp16 form with BOTH operands as images, every tile staged by LDS-DMA (no staging registers, no split in the k-loop; csrc/gemm.hip:
+ * gemm_split_ab_kernel<2, ., true>): hopmi_rows_image_f16 writes the activations' scaled fp16 hi / lo images [2][M][K] and their
+ * [2][M] row-scale pairs in one pass (what hopmi_row_scales + the in-kernel split do together), hopmi_gemm_f16x2_ab multiplies
+ * (K % 32 == 0, any N; bias epilogue only).  Bit-identical to hopmi_gemm_f16x2; faster where one 128 x 128 tile per CU covers the
+ * problem (N = 768 at M = 4352: 24 vs 30 us, K = 3072: 71 vs 92). */
+int hopmi_rows_image_f16(const float* A, int M, int K, void* image, float* scales, void* stream);
+int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M, int N,
+                        int K, void* stream);
+
 /* The same product with BOTH operands as part images (Aimage = hopmi_gemm_split_prepare(A, M, K, parts, ...), i.e.
  * [parts][M][K] bf16; a producer may also write that layout itself): nothing is split inside the kernel, every tile is staged
  * by LDS-DMA.  Same arithmetic (the same MFMA terms in the same order) as hopmi_gemm_split: results are bit-identical. */

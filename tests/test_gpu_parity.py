@@ -1714,6 +1714,27 @@ def test_gemm_f16x2_epilogue_row_maxima(M, N, K, ep):
         assert torch.equal(ops._split_gemm(c, img2, None, 256, N, 16, a_part=(cm, P)), ops._split_gemm(c, img2, None, 256, N, 16))
 
 
+@pytest.mark.parametrize("M,N,K", [(4352, 768, 768), (4352, 768, 3072), (1100, 700, 2304), (1030, 130, 64)])
+def test_gemm_f16x2_lds_dma_form_equals_the_split_form(M, N, K, monkeypatch):
+    """hopmi_rows_image_f16 + hopmi_gemm_f16x2_ab (both operands as fp16 hi / lo images, tiles staged by LDS-DMA) against
+    hopmi_row_scales + hopmi_gemm_f16x2 (activations split in the k-loop): the same scales, the same three terms in the same order
+    -- BIT-identical results, ragged M and N included; and through ops._split_gemm the form is chosen where it wins."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-3, 3, M).unsqueeze(1)).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    img = ops.split_weight_image(w, 16)
+    monkeypatch.setattr(ops, "GEMM_AB", True)
+    y_ab = ops._split_gemm(x, img, b, N, K, 16)
+    monkeypatch.setattr(ops, "GEMM_AB", False)
+    y_split = ops._split_gemm(x, img, b, N, K, 16)
+    assert torch.equal(y_ab, y_split)
+    want = x.double() @ w.double().t() + b.double()
+    assert rel_err((y_ab / x.abs().amax(1, keepdim=True)).double(), want / x.abs().amax(1, keepdim=True).double()) <= 4e-6
+
+
 def test_gemm_f16x2_special_values():
     """The fp16 form's scaling on degenerate operands: an all-zero activation matrix gives exactly the bias; one huge element
     (1e30) beside ordinary ones neither overflows nor disturbs the other rows (the scales are per row), and its own row is good to
