@@ -265,7 +265,7 @@ def main():
 
     # ---- 1. kernel region: instrumented eager steps (these also bring up handles / workspaces / autograd threads) ----
     ks = None
-    if args.kernel_steps > 0:
+    if args.kernel_steps > 0 and not args.strict_fp32:         # (--strict-fp32 does not run the graded kernel: no roofline object)
         eager_step()                                           # first call: lazy initialisation, GradSync's plan
         ops.TIMER = ops.KernelTimer()
         for _ in range(args.kernel_steps):
