@@ -228,7 +228,7 @@ class GraphedTrainStep:
         self.overlap = bool(overlap)
         # `inplace=True` (fp32 exchange over RCCL only): the gradient tensors are all-reduced IN PLACE under one RCCL group call instead
         # of pack -> one all-reduce -> unpack (2 x 80 MB of copies).  Measured on the 1-rank rehearsal (round 4, one box,
-        # gpurun_out/rs4_*.log): NOT faster -- 16.19 vs 16.11 ms (TED), 22.60 vs 22.41 (GAN), 13.19 vs 13.11 (V = 42) against 15.71 /
+        # profiles/r04_rehearse_sync.txt): NOT faster -- 16.19 vs 16.11 ms (TED), 22.60 vs 22.41 (GAN), 13.19 vs 13.11 (V = 42) against 15.71 /
         # 21.93 / 12.70 without any exchange: a group call over ~150 tensors costs more than the two flat copies it saves, and what
         # the exchange adds to the step is mostly its cuts and launches, not the copies.  Kept as an option for a measurement on
         # real links; the flat form stays the default.
@@ -477,7 +477,7 @@ class GraphedTrainStep:
 
     def _recording_failed(self, cap, exc):
         """An exception interrupted a recording: `self._stream` is still inside a stream capture.  Measured on this runtime
-        (tools/probes/capture_failure_probe.py, gpurun_out/capture_probe.log): a capture LEFT OPEN aborts the process at
+        (tools/probes/capture_failure_probe.py, profiles/r04_capture_probe.txt): a capture LEFT OPEN aborts the process at
         interpreter exit (SIGABRT out of the graph object's destructor); a healthy capture (a Python-level error, and most illegal
         calls, which this runtime refuses without invalidating the capture) ends the ordinary way; an INVALIDATED one (e.g. a
         device-wide synchronize under capture) makes hipStreamEndCapture answer with the invalidation error and the stream keeps
