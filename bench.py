@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the HOP generator training step on MI355X (contract: see the task statement).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE in the environment: this process starts the N
+                                                          ranks itself as children under torch.distributed.run; with WORLD_SIZE set
+                                                          -- the driver's own torch.distributed.run line -- it is one of the ranks)
 
 A "step" is one `train_llm` call (train_eval/train_llm.py:9-98 semantics, epoch <= 10: two generator forwards, one
 backward, Adam on 65.7 M parameters, plus the RCCL gradient exchange when N > 1) on one batch of synthetic 34-frame
@@ -60,6 +62,10 @@ def parse():
     ap.add_argument("--feed-host", action="store_true",
                     help="every step takes a fresh batch from HOST memory through hopmi.HostFeeder (pinned double-buffered staging, "
                          "log-mel computed on the GPU) instead of the batch resident in HBM")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="no GPU work: every rank joins a gloo group, the ranks run the timing reduction (barrier, MAX over ranks) and rank 0 "
+                         "prints a stub line with n_gpus and the group size -- what tests/test_parallel_gloo.py uses to run the launch "
+                         "path of `python bench.py --gpus N` on a box without GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -170,8 +176,29 @@ def roofline(ks, V, B, n_kernel_steps, dtype="fp32"):
     return r
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` typed as such (no WORLD_SIZE in the environment): start the N ranks as FRESH child processes
+    under torch.distributed.run (one process per GPU, run_ted.py:110-112 / accelerate in the reference), pass rank 0's JSON line
+    and the launcher's exit code through.  This process never touches the GPU (no torch import before this point), and nothing is
+    re-executed in place."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                                 # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0)) // args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must precede the first HIP call
     import torch
     import torch.distributed as dist
@@ -182,8 +209,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} in the environment"
+    if args.plumbing_check:
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"plumbing_check": True, "n_gpus": world, "ranks_in_group": dist.get_world_size() if world > 1 else 1,
+                              "max_over_ranks": t.item(), "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     # HOPMI_REHEARSE_ONE_GPU=1 (rehearsal on a single-GPU box only): every rank uses cuda:0 and the collectives go
     # through gloo, so the multi-process plumbing (rendezvous, exchange, timing reduction) can be exercised without a
     # second device (the persistent GRU kernels are withheld: two such launches cannot share one GPU)
@@ -356,12 +397,21 @@ def main():
                                 "a fresh batch from host memory every step (HostFeeder: pinned double-buffered staging, the 19 MB "
                                 "host -> device copy and the log-mel kernels enqueued in front of the step)",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "exchange": None if world == 1 and not args.rehearse_sync else
-                                   "prototype rows of the mapping layer sharded over ranks (all-gather S, all-reduce dS), " +
-                                   ("one flat all-reduce of the other gradients per module" if args.flat_exchange else
-                                    "the generator's backward cut at the decoder input: the all-reduce of the first half's gradients "
-                                    "(decoder GRU, head) runs under the second half, one flat all-reduce for the rest and one for the discriminator") +
-                                   ", eager RCCL calls between graph launches",
+                       "exchange": None if world == 1 and not args.rehearse_sync else {
+                           "form": ("eager GradSync: 64 MB buckets launched from post-accumulate-grad hooks in gradient-production order "
+                                    "(the persistent GRU / WaveNet-stack kernels are withheld while RCCL kernels may run beside the "
+                                    "backward: the eager N > 1 step is a slower program than the recorded one)" if args.eager else
+                                    "flat: one all-reduce behind the whole generator backward" if args.flat_exchange else
+                                    "overlapped: the generator's backward is cut at the decoder input, the all-reduce of the first half's "
+                                    "gradients (decoder GRU, head) runs under the second half, one flat all-reduce for the rest"),
+                           "backend": dist.get_backend() if dist.is_initialized() else None,
+                           "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,
+                           "gradient_dtype": args.dtype if grad_dtype is not None else "fp32",
+                           "prototype_rows": "mapping-layer rows sharded over ranks: all-gather of S (4.6 MB), all-reduce of dS instead of "
+                                             "the 183 MB weight gradient, Adam on own rows",
+                           "all_reduces": ({"eager_buckets": [[len(b.params), b.numel] for g in sync.groups for b in (g.buckets or ())]}
+                                           if args.eager else graphed.exchange_plan),
+                           "where": "eager RCCL calls between graph launches (nothing of RCCL is captured)"},
                        "llm": "BERT-base geometry, 6 layers, random init, frozen",
                        "arithmetic": "per-kernel error against float64 next to plain fp32 torch: tests/test_gpu_parity.py::test_*_vs_float64 "
                                      "(three-term split-bf16 kernels: within K x the fp32 reference's own error, K stated per test)",

@@ -20,6 +20,19 @@ __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_<0x140>(v));     // row_mirror
   return v;
 }
+// Maximum over the whole wave of a NON-NEGATIVE value, as a wave-uniform number: the 16-lane DPP rows first, then row_bcast15 /
+// row_bcast31 (gfx9 DPP: lane 15 of every row into the next row, lane 31 into the upper half) leave the total in lane 63, read back
+// with v_readlane -- 6 VALU operations + one readlane instead of six ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep_(float v) {      // lanes outside ROW_MASK keep v
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, dpp_keep_<0x142, 0xA>(v));      // row_bcast15 -> rows 1, 3
+  v = fmaxf(v, dpp_keep_<0x143, 0xC>(v));      // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_<0xB1>(v);
   v += dpp_<0x4E>(v);

@@ -22,6 +22,7 @@ namespace hopmi {
 
 __global__ __launch_bounds__(256) void gcn_prepare_kernel(const float* __restrict__ A1, const float* __restrict__ A2,
                                                           float* __restrict__ prep, GcnGeom g) {
+  __shared__ float colsum[256];
   const int V = g.V;
   float* AT = prep;
   float* AB = prep + g.KP * g.ldA;
@@ -36,6 +37,27 @@ __global__ __launch_bounds__(256) void gcn_prepare_kernel(const float* __restric
     float a = 0.f;
     if (v < V && k < 2 * V) a = (k < V) ? A1[v * V + k] : A2[v * V + (k - V)];
     AB[idx] = a;
+  }
+  // trailer (4 floats): the power-of-two operand scale s of the fused WaveNet kernels' contraction images [u | u A1 | u A2] and
+  // its inverse.  |u| <= 1 (tanh x sigmoid) and |(u A)[w]| <= max_w sum_v |A[v][w]|: the largest column sum of |A1|, |A2| (and 1)
+  // bounds every element of the images, s puts that bound in [2^14, 2^15) (f16_dev.h)
+  float cs = 0.f;
+  if (threadIdx.x < 2 * V) {
+    const float* A = threadIdx.x < V ? A1 : A2;
+    const int wcol = threadIdx.x < V ? threadIdx.x : threadIdx.x - V;
+    for (int v = 0; v < V; ++v) cs += fabsf(A[v * V + wcol]);
+  }
+  colsum[threadIdx.x] = cs;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = 1.f;
+    for (int i = 0; i < 2 * V; ++i) m = fmaxf(m, colsum[i]);
+    const unsigned sb = scale_bits_for_max(__float_as_uint(m));
+    float* tr = prep + g.KP * g.ldA + g.K2P * g.ldB;
+    tr[0] = __uint_as_float(sb);
+    tr[1] = inv_scale(sb);
+    tr[2] = m;
+    tr[3] = 0.f;
   }
 }
 
@@ -392,7 +414,7 @@ using namespace hopmi;
 extern "C" size_t hopmi_gcn_prep_floats(int V) {
   if (V < 1 || V > HOPMI_MAX_NODES) return 0;
   const GcnGeom g = make_geom(1, V, 1);
-  return (size_t)g.KP * g.ldA + (size_t)g.K2P * g.ldB;
+  return (size_t)g.KP * g.ldA + (size_t)g.K2P * g.ldB + 4;      // + the operand-scale trailer (gcn_prepare_kernel)
 }
 
 extern "C" int hopmi_gcn_prepare(const float* A1, const float* A2, float* prep, int V, void* stream) {

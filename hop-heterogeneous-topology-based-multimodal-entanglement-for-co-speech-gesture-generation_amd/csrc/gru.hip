@@ -8,8 +8,9 @@
 //   * the sequential part -- gh = h_{t-1} W_hh^T + b_hh, the gates, h_t -- runs here, both directions together,
 //     in one of two schedules behind the same entry point:
 //       - persistent (whenever every workgroup of the launch can be resident at once): ONE launch per layer; see the block
-//         comment in front of gru_fwd_persistent_kernel (recurrent weights as split-bf16 MFMA fragments in registers,
-//         16 x 32 tiles, h_t handed over through y itself: fill pattern + re-load, no counters);
+//         comment in front of gru_fwd_persistent_kernel (recurrent weights as scaled fp16 hi/lo MFMA fragments in registers --
+//         three-term products, fp32-equivalent, f16_dev.h --, 16 x 32 tiles, h_t handed over through y itself: fill pattern +
+//         re-load, no counters);
 //       - per-step: one launch per time step (a dependent launch boundary costs ~1.5 us on MI355X), the T launches
 //         enqueued from C in one ABI call, exact-fp32 MFMA.
 // Decomposition of a per-step launch: workgroup (jb, bb, dir) owns hidden units [16 jb, 16 jb + 16) of batch rows
@@ -23,7 +24,8 @@
 #include <utility>
 #include <vector>
 
-#include "bf16_dev.h"
+#include "attn_dev.h"
+#include "f16_dev.h"
 
 namespace hopmi {
 
@@ -323,9 +325,13 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
 // through the layer's own output arrays.
 //   * The recurrent weights never touch LDS: every wave keeps the MFMA B-operand fragments of its (unit half, K quarter)
 //     in registers for the whole launch, split into two bf16 parts once at kernel start (72 VGPRs at H = 350).
-//   * The product runs on v_mfma_f32_16x16x32_bf16 with both operands carried as hi + lo bf16 pairs (three terms,
-//     bf16_dev.h; ~2^-16 relative per product, fp32 accumulation): 27 MFMAs of 16 cycles per wave and step instead of the
-//     72 exact-fp32 MFMAs of 32 cycles that were 32 % of a step (tools/probes/gru_stamps.py).
+//   * The product runs on v_mfma_f32_16x16x32_f16 with both operands carried as scaled fp16 hi + lo pairs (three terms,
+//     f16_dev.h: 22 significand bits per operand, fp32 accumulation -- fp32-equivalent; rounds 2-4: bf16 pairs, 2^-16): 27 MFMAs
+//     of 16 cycles per wave and step instead of the 72 exact-fp32 MFMAs of 32 cycles that were 32 % of a step
+//     (tools/probes/gru_stamps.py).  Scales (powers of two): the recurrent weights one per (gate, unit) row, found once at kernel
+//     start (lane maximum -> the row's 4 lanes -> the 4 K-quarter waves through LDS); the state h, bounded by 1: 2^14; in the
+//     backward the handed-off dgh rows one per (gate block, batch row) segment from the maximum of the segment as its staging wave
+//     loaded it, with one accumulator per gate block so that segments of different scale never meet before the epilogue.
 //   * Hand-off without counters: the hand-off array is filled with a NaN bit pattern no computation produces before the
 //     kernel starts; a producer simply stores its values (sc1: write-through), a consumer loads the rows it needs with sc1
 //     loads (never served from a stale cache) and re-loads whatever still reads as the pattern.  One memory round trip
@@ -430,26 +436,75 @@ __device__ __forceinline__ void poll_segments(float2 (&v)[NSEG][MAXK2], SrcOf sr
   }
 }
 
-// commit one loaded segment to LDS row `row` of a split panel (hi image, lo image; WS2 32-bit words per row)
+// commit one loaded segment, times the power of two `sc`, to LDS row `row` of a split panel (hi image, lo image; WS2 32-bit words per row)
 template <int MAXK2>
-__device__ __forceinline__ void commit_split_row(unsigned* hi, unsigned* lo, int ws2, int row, const float2 (&v)[MAXK2], int lane) {
+__device__ __forceinline__ void commit_split_row(unsigned* hi, unsigned* lo, int ws2, int row, const float2 (&v)[MAXK2], int lane, float sc) {
 #pragma unroll
   for (int c = 0; c < MAXK2; ++c) {
-    const u32x2 p = split2(v[c].x, v[c].y);
+    const u32x2 p = split2h(v[c].x * sc, v[c].y * sc);
     hi[row * ws2 + lane + 64 * c] = p[0];
     lo[row * ws2 + lane + 64 * c] = p[1];
   }
 }
 
-// the 8 values W[k0 .. k0 + 8) of a weight row (nullptr row or k >= K -> 0) as one split MFMA operand
-__device__ __forceinline__ Split8 load_w_frag(const float* row, int k0, int K) {
+// the 8 values W[k0 .. k0 + 8) of a weight row (nullptr row or k >= K -> 0)
+__device__ __forceinline__ void load_w8(const float* row, int k0, int K, float4& a, float4& b) {
   float2 f[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int k = k0 + 2 * e;
     f[e] = (row != nullptr && k < K) ? *reinterpret_cast<const float2*>(row + k) : make_float2(0.f, 0.f);
   }
-  return split8(make_float4(f[0].x, f[0].y, f[1].x, f[1].y), make_float4(f[2].x, f[2].y, f[3].x, f[3].y));
+  a = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
+  b = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
+}
+__device__ __forceinline__ float absmax_w8(float m, const float* row, int k0, int K) {
+  float4 a, b;
+  load_w8(row, k0, K, a, b);
+  return absmax4(absmax4(m, a), b);
+}
+// ... times the power of two `sc`, as one split MFMA operand
+__device__ __forceinline__ Split8 load_w_frag(const float* row, int k0, int K, float sc) {
+  float4 a, b;
+  load_w8(row, k0, K, a, b);
+  return split8h(a, b, sc);
+}
+
+// Resident recurrent-weight fragments of a persistent-kernel wave (unit 16 ch + i of unit block j0, K quarter kq, 3 gates), scaled by
+// one power of two per (gate, unit) ROW: the row's maximum is taken over this lane's elements, its 4 lanes (q) and the 4 K-quarter
+// waves of the unit half (through `xch`: [8 waves][3][16] floats of LDS, two barriers; every lane ends with its row's scale).
+// `wrow(g)`: the row of gate g.  Returns the inverse scales in inv[3].
+template <int MAXK2, typename RowOf>
+__device__ __forceinline__ void load_resident_w(u32x4 (&wh)[3][MAXK2], u32x4 (&wl)[3][MAXK2], float (&inv)[3], RowOf wrow, int H, int kq,
+                                                int ch, int q, int i, int w, float* xch) {
+  float m[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float* row = wrow(g);
+    float mm = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < MAXK2; ++kk) mm = absmax_w8(mm, row, (kq * MAXK2 + kk) * 32 + 8 * q, H);
+    mm = fmaxf(mm, __shfl_xor(mm, 16));
+    mm = fmaxf(mm, __shfl_xor(mm, 32));
+    m[g] = mm;
+    if (q == 0) xch[(w * 3 + g) * 16 + i] = mm;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    float mm = m[g];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) mm = fmaxf(mm, xch[((ch * 4 + k2) * 3 + g) * 16 + i]);
+    const float sc = scale_for_absmax(mm);
+    inv[g] = inv_pow2(sc);
+    const float* row = wrow(g);
+#pragma unroll
+    for (int kk = 0; kk < MAXK2; ++kk) {
+      const Split8 f = load_w_frag(row, (kq * MAXK2 + kk) * 32 + 8 * q, H, sc);
+      wh[g][kk] = f.hi; wl[g][kk] = f.lo;
+    }
+  }
+  __syncthreads();                                                     // (xch is the partial-tile region: free again)
 }
 
 // KP = 128 MAXK2 >= H: K padded so that each of the 4 K quarters is MAXK2 MFMA steps of 32.
@@ -475,17 +530,21 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __res
   const int row = tid >> 5, b = b0 + row, bc = min(b, B - 1);           // the thread's element in the gate epilogue
 
   u32x4 wh[3][MAXK2], wl[3][MAXK2];                                    // resident W_hh fragments of this wave
+  float e_inv[3];                                                      // accumulator -> gh of the EPILOGUE element's unit: (1 / s_W[g][unit]) 2^-14
   {
     const int ju = j0 + 16 * ch + i;
+    float inv[3];
+    load_resident_w<MAXK2>(wh, wl, inv, [&](int g) -> const float* { return ju < H ? whh + ((size_t)(d * 3 + g) * H + ju) * H : nullptr; },
+                           H, kq, ch, q, i, w, red);
+    // the epilogue walks (row, unit jj = tid & 31): hand the inverse scales from the fragment layout (unit 16 ch + i) over through LDS
+    if (kq == 0 && q == 0) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      const float* wrow = ju < H ? whh + ((size_t)(d * 3 + g) * H + ju) * H : nullptr;
-#pragma unroll
-      for (int kk = 0; kk < MAXK2; ++kk) {
-        const Split8 f = load_w_frag(wrow, (kq * MAXK2 + kk) * 32 + 8 * q, H);
-        wh[g][kk] = f.hi; wl[g][kk] = f.lo;
-      }
+      for (int g = 0; g < 3; ++g) red[g * GP_NU + 16 * ch + i] = inv[g] * H_UNIT_INV;
     }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) e_inv[g] = red[g * GP_NU + jj];
+    __syncthreads();
   }
   float e_bhh[3];
 #pragma unroll
@@ -510,7 +569,7 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __res
       }, H, lane, dead, status);
       GRU_STAMP(1);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane);
+      for (int m = 0; m < 2; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane, H_UNIT_SCALE);   // |h| <= 1
       __syncthreads();
       GRU_STAMP(2);
       f32x4 acc[3];
@@ -523,7 +582,7 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __res
         const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + 16 * kk);
         const u32x4 al = *reinterpret_cast<const u32x4*>(alp + 16 * kk);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = mfma_split3(ah, al, wh[g][kk], wl[g][kk], acc[g]);
+        for (int g = 0; g < 3; ++g) acc[g] = mfma_h3(ah, al, wh[g][kk], wl[g][kk], acc[g]);
       }
       GRU_STAMP(3);
 #pragma unroll
@@ -539,8 +598,10 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __res
       for (int g = 0; g < 3; ++g) {
         float a = e_bhh[g];
         if (s > 0) {
+          float p = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < 4; ++ww) a += red[(ww * GP_BM + row) * GP_RED_F + 32 * g + jj];
+          for (int ww = 0; ww < 4; ++ww) p += red[(ww * GP_BM + row) * GP_RED_F + 32 * g + jj];
+          a += p * e_inv[g];
         }
         gh[g] = a;
       }
@@ -581,12 +642,18 @@ __global__ __launch_bounds__(256) void gru_fwd_small_kernel(const TG* __restrict
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
   const int j = 16 * w + i;                                            // this lane's unit (C layout column)
   u32x4 wh[3][2], wl[3][2];
+  float e_inv[3];                                                      // accumulator -> gh: (1 / s_W[g][unit]) 2^-14
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
-    const float* wrow = whh + ((size_t)(d * 3 + g) * H + j) * H;
+    const float* wrow = whh + ((size_t)(d * 3 + g) * H + j) * H;       // the whole row sits in this unit's 4 lanes (q)
+    float m = absmax_w8(absmax_w8(0.f, wrow, 8 * q, H), wrow, 32 + 8 * q, H);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float sc = scale_for_absmax(m);
+    e_inv[g] = inv_pow2(sc) * H_UNIT_INV;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const Split8 f = load_w_frag(wrow, 32 * ks + 8 * q, H);
+      const Split8 f = load_w_frag(wrow, 32 * ks + 8 * q, H, sc);
       wh[g][ks] = f.hi; wl[g][ks] = f.lo;
     }
   }
@@ -619,16 +686,20 @@ __global__ __launch_bounds__(256) void gru_fwd_small_kernel(const TG* __restrict
         const int t = d ? T - 1 - s : s;
         f32x4 acc[3];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = {e_bhh[g], e_bhh[g], e_bhh[g], e_bhh[g]};
+        for (int g = 0; g < 3; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
           const float* hp = &hbuf[(s - 1) & 1][i][8 * q];
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const Split8 a = split8(*reinterpret_cast<const float4*>(hp + 32 * ks), *reinterpret_cast<const float4*>(hp + 32 * ks + 4));
+            const Split8 a = split8h(*reinterpret_cast<const float4*>(hp + 32 * ks), *reinterpret_cast<const float4*>(hp + 32 * ks + 4), H_UNIT_SCALE);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = mfma_split3(a.hi, a.lo, wh[g][ks], wl[g][ks], acc[g]);
+            for (int g = 0; g < 3; ++g) acc[g] = mfma_h3(a.hi, a.lo, wh[g][ks], wl[g][ks], acc[g]);
           }
         }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[g][r] = acc[g][r] * e_inv[g] + e_bhh[g];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float gr = sigmoidf_(gbuf[u][r][0] + acc[0][r]);
@@ -662,6 +733,7 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
   unsigned* Ahi = reinterpret_cast<unsigned*>(smem);                   // [3 gate blocks][16][WS2]  dgh rows, hi parts
   unsigned* Alo = Ahi + 3 * GP_BM * WS2;
   float* red = reinterpret_cast<float*>(Alo + 3 * GP_BM * WS2);        // [4 K quarters][16][GP_RED_B]
+  float* SCA = red + 4 * GP_BM * GP_RED_B;                             // [3 gate blocks][16] inverse scale of the staged dgh segment
   const GpWork wk = gp_decode(nJ, nbb);
   if (!wk.valid) return;
   const int d = wk.d, bb = wk.bb, jb = wk.jb;
@@ -673,17 +745,11 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
   const int row = tid >> 5, b = b0 + row, bc = min(b, B - 1);
 
   u32x4 wh[3][MAXK2], wl[3][MAXK2];
+  float iw[3];                                                         // 1 / s of W_hh^T[unit 16 ch + i][gate block g]: this lane's accumulator column
   {
     const int ju = j0 + 16 * ch + i;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      const float* wrow = ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr;
-#pragma unroll
-      for (int kk = 0; kk < MAXK2; ++kk) {
-        const Split8 f = load_w_frag(wrow, (kq * MAXK2 + kk) * 32 + 8 * q, H);
-        wh[g][kk] = f.hi; wl[g][kk] = f.lo;
-      }
-    }
+    load_resident_w<MAXK2>(wh, wl, iw, [&](int g) -> const float* { return ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr; },
+                           H, kq, ch, q, i, w, red);
   }
   float dhz_own = 0.f;                                                 // D_{p+1} z_{p+1} of this thread's element
   bool dead = false;
@@ -709,7 +775,15 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
       }, H, lane, dead, status);
       GRU_STAMP(1);
 #pragma unroll
-      for (int m = 0; m < 6; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane);
+      for (int m = 0; m < 6; ++m) {
+        // one power-of-two scale per staged segment (gate block, batch row): the maximum of what this wave just loaded
+        float mm = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXK2; ++c) mm = fmaxf(mm, fmaxf(fabsf(v[m][c].x), fabsf(v[m][c].y)));
+        const float sc = scale_for_absmax(wave_max_nonneg(mm));
+        commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane, sc);
+        if (lane == 0) SCA[w + 8 * m] = inv_pow2(sc);                  // (segment index = gate block x 16 + row)
+      }
       __syncthreads();
       GRU_STAMP(2);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -717,12 +791,15 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
       for (int g = 0; g < 3; ++g) {
         const unsigned* ahp = Ahi + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
         const unsigned* alp = Alo + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
+        f32x4 ag = {0.f, 0.f, 0.f, 0.f};                               // (per gate block: its segments carry their own scales)
 #pragma unroll
         for (int kk = 0; kk < MAXK2; ++kk) {
           const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + 16 * kk);
           const u32x4 al = *reinterpret_cast<const u32x4*>(alp + 16 * kk);
-          acc = mfma_split3(ah, al, wh[g][kk], wl[g][kk], acc);
+          ag = mfma_h3(ah, al, wh[g][kk], wl[g][kk], ag);
         }
+        const float4 ia = *reinterpret_cast<const float4*>(SCA + g * GP_BM + 4 * q);     // rows 4 q + r of the accumulator
+        acc[0] += ag[0] * (ia.x * iw[g]); acc[1] += ag[1] * (ia.y * iw[g]); acc[2] += ag[2] * (ia.z * iw[g]); acc[3] += ag[3] * (ia.w * iw[g]);
       }
       GRU_STAMP(3);
 #pragma unroll
@@ -768,14 +845,23 @@ __global__ __launch_bounds__(256) void gru_bwd_small_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
   const int j = 16 * w + i;                                            // this lane's unit (C layout column)
   u32x4 wh[3][2], wl[3][2];
+  float iw;                                                            // 1 / s of this unit's row of W_hh^T (all 3H columns: one accumulator)
+  {
+    const float* wrow0 = whhT + ((size_t)d * H + j) * K;               // W_hh^T: row = unit, columns = the 3H recurrent pre-activations
+    float m = 0.f;
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const float* wrow = whhT + ((size_t)d * H + j) * K + g * H;        // W_hh^T: row = unit, columns = the 3H recurrent pre-activations
+    for (int g = 0; g < 3; ++g) m = absmax_w8(absmax_w8(m, wrow0 + g * H, 8 * q, H), wrow0 + g * H, 32 + 8 * q, H);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float sc = scale_for_absmax(m);
+    iw = inv_pow2(sc);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const Split8 f = load_w_frag(wrow, 32 * ks + 8 * q, H);
-      wh[g][ks] = f.hi; wl[g][ks] = f.lo;
-    }
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const Split8 f = load_w_frag(wrow0 + g * H, 32 * ks + 8 * q, H, sc);
+        wh[g][ks] = f.hi; wl[g][ks] = f.lo;
+      }
   }
   int brow[4];
 #pragma unroll
@@ -807,13 +893,27 @@ __global__ __launch_bounds__(256) void gru_bwd_small_kernel(const float* __restr
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
           const float* pp = &pbuf[(s - 1) & 1][i][8 * q];
+          // the wave reads the whole 16 x 192 panel: ONE power-of-two scale from its maximum (every wave finds the same number)
+          float4 pa[3][2], pb[3][2];
+          float mm = 0.f;
 #pragma unroll
           for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-              const Split8 a = split8(*reinterpret_cast<const float4*>(pp + g * H + 32 * ks), *reinterpret_cast<const float4*>(pp + g * H + 32 * ks + 4));
-              acc = mfma_split3(a.hi, a.lo, wh[g][ks], wl[g][ks], acc);
+              pa[g][ks] = *reinterpret_cast<const float4*>(pp + g * H + 32 * ks);
+              pb[g][ks] = *reinterpret_cast<const float4*>(pp + g * H + 32 * ks + 4);
+              mm = absmax4(absmax4(mm, pa[g][ks]), pb[g][ks]);
             }
+          const float sc = scale_for_absmax(wave_max_nonneg(mm));
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const Split8 a = split8h(pa[g][ks], pb[g][ks], sc);
+              acc = mfma_h3(a.hi, a.lo, wh[g][ks], wl[g][ks], acc);
+            }
+          const float k = inv_pow2(sc) * iw;
+          acc[0] *= k; acc[1] *= k; acc[2] *= k; acc[3] *= k;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -975,7 +1075,7 @@ static int gru_persistent_capacity(int H) {
       return gru_resident_capacity(reinterpret_cast<const void*>(&gru_fwd_persistent_kernel<MK_, TG>),                        \
                                    (size_t)2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_F * sizeof(float));  \
     return gru_resident_capacity(reinterpret_cast<const void*>(&gru_bwd_persistent_kernel<MK_, TG>),                          \
-                                 (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_B * sizeof(float)); \
+                                 (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)(4 * GP_BM * GP_RED_B + 3 * GP_BM) * sizeof(float)); \
   }
   if (mk <= 1) HOPMI_GP_CAP(1)
   if (mk == 2) HOPMI_GP_CAP(2)
@@ -1069,7 +1169,7 @@ static void launch_gru_bwd_persistent(int grid, hipStream_t st, const float* dy,
                                       const float* whhT, TG* dgi, float* dgh, int* status, int B, int T, int H, int nJ,
                                       int nbb) {
   constexpr int WS2 = (128 * MAXK2 + 48) / 2;
-  const size_t lds = (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_B * sizeof(float);
+  const size_t lds = (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)(4 * GP_BM * GP_RED_B + 3 * GP_BM) * sizeof(float);
   hipLaunchKernelGGL((gru_bwd_persistent_kernel<MAXK2, TG>), dim3(grid), dim3(512), lds, st, dy, y, gates, whhT, dgi, dgh, status, B,
                      T, H, nJ, nbb);
 }

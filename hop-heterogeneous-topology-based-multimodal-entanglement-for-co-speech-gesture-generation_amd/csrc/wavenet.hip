@@ -12,17 +12,21 @@
 // Work decomposition: the output rows (clip b, frame t', node v) are flat, row = slab*V + v with
 // slab = b*T_out + t'; a workgroup of 8 waves takes tiles of S consecutive output slabs (<= 80 rows): wave (w, h)
 // owns output channels 16 w + [0, 16) of the 16-row MFMA tiles of row half h.  The two channel contractions (gated TCN,
-// K = 2 taps x 64; graph conv, K = 192) run as three-term split-bf16 products on v_mfma_f32_16x16x32_bf16
-// (bf16_dev.h: fp32-class accuracy at 5.3x the fp32 matrix rate); their weight operands are split MFMA fragments
-// prepared once per forward pass for all layers (hopmi_wn_prepare_weights) and held in registers (112 VGPRs); the
-// activations are split once when the tile is committed to LDS.  The node mix (K = V) stays on the exact-fp32 MFMA.
+// K = 2 taps x 64; graph conv, K = 192) run as three-term products of scaled fp16 hi/lo operands on v_mfma_f32_16x16x32_f16
+// (f16_dev.h: 22 significand bits per operand -- fp32-equivalent -- at 5.3x the fp32 matrix rate; rounds 2-4 carried bf16 hi/lo
+// pairs, 2^-16 per product); their weight operands are split MFMA fragments with one power-of-two scale per output channel,
+// prepared once per forward pass for all layers (hopmi_wn_prepare_weights) and held in registers (112 VGPRs); the activations
+// are scaled (one power of two per tile row, found over both taps by the 16 lanes that hold the row; a fixed one for the gate
+// activations, which are bounded by 1, and their node mixes, bounded through the mix matrices' column sums) and split once when
+// the tile is committed to LDS.  The node mix (K = V) stays on the exact-fp32 MFMA.
 // Per tile: two tap panels HBM -> registers -> normalise -> split -> LDS; TCN; gate (hardware exp); skip tail;
 // node mix; contraction; epilogue adds bias + residual, stores y and accumulates the BatchNorm partial sums.  A tiny
 // second kernel turns the per-(workgroup, half) partials into mean / rstd / running stats / the next layer's
 // scale+shift in a fixed order (reproducible).  Nothing is saved for the backward: it recomputes the gates from xin.
 #include <hip/hip_ext.h>
 
-#include "bf16_dev.h"
+#include "attn_dev.h"
+#include "f16_dev.h"
 #include "io_dev.h"
 #include "wn_dev.h"
 
@@ -45,33 +49,51 @@ __device__ __forceinline__ float gate_(float a, float g) {
 constexpr int WN_MAX_LAYERS = 8;
 struct WeightPtrs { const float* wf[WN_MAX_LAYERS]; const float* wg[WN_MAX_LAYERS]; const float* wm[WN_MAX_LAYERS]; };
 
-// one thread = one (hi, lo) pair of 16-byte fragment units: 8 consecutive-k weights of one output channel
+// one thread = one (hi, lo) pair of 16-byte fragment units: 8 consecutive-k weights of one output channel, scaled by the power
+// of two that puts the largest magnitude of the channel's whole row (both taps of a TCN matrix: 128 weights; Wm: 192) in
+// [2^14, 2^15); the thread that holds a row's first unit also writes the row's inverse scale behind the fragments
 __global__ __launch_bounds__(256) void wn_prepare_weights_kernel(WeightPtrs P, u32x4* __restrict__ img) {
   constexpr int PAIRS = WIMG_UNITS / 2;                     // 3584 per layer
   const int layer = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= PAIRS) return;
   const int lane = t & 63, n = lane & 15, q = lane >> 4;
-  u32x4* out = img + (size_t)layer * WIMG_UNITS;
+  u32x4* out = img + (size_t)layer * WIMGH_UNITS;
+  float* inv_out = reinterpret_cast<float*>(out + WIMG_UNITS);
   float v[8];
-  int unit;
+  int unit, inv_at;
+  const float* rowp;
+  int row_n4;
+  bool first;
   if (t < WIMG_TCN_UNITS / 2) {
     const int ks = (t >> 6) & 3, gate = (t >> 8) & 1, w = t >> 9;
-    const float* src = (gate ? P.wg[layer] : P.wf[layer]) + ((size_t)(16 * w + n) * C + 32 * (ks & 1) + 8 * q) * 2 + (ks >> 1);
+    rowp = (gate ? P.wg[layer] : P.wf[layer]) + (size_t)(16 * w + n) * C * 2;      // Conv2d layout [out][in][1][tap]: 128 floats
+    row_n4 = 2 * C / 4;
+    const float* src = rowp + (32 * (ks & 1) + 8 * q) * 2 + (ks >> 1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = src[2 * e];          // Conv2d layout [out][in][1][tap]
+    for (int e = 0; e < 8; ++e) v[e] = src[2 * e];
     unit = (((w * 2 + gate) * 4 + ks) * 2) * 64 + lane;
+    inv_at = gate * C + 16 * w + n;
+    first = ks == 0 && q == 0;
   } else {
     const int u = t - WIMG_TCN_UNITS / 2;
     const int wks = u >> 6, ks = wks % 6, w = wks / 6;
-    const float* src = P.wm[layer] + (size_t)(16 * w + n) * K3 + 32 * ks + 8 * q;
+    rowp = P.wm[layer] + (size_t)(16 * w + n) * K3;
+    row_n4 = K3 / 4;
+    const float* src = rowp + 32 * ks + 8 * q;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = src[e];
     unit = WIMG_TCN_UNITS + ((w * 6 + ks) * 2) * 64 + lane;
+    inv_at = 2 * C + 16 * w + n;
+    first = ks == 0 && q == 0;
   }
-  const Split8 s = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+  float m = 0.f;
+  for (int i = 0; i < row_n4; ++i) m = absmax4(m, reinterpret_cast<const float4*>(rowp)[i]);
+  const float sc = scale_for_absmax(m);
+  const Split8 s = split8h(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sc);
   out[unit] = s.hi;
   out[unit + 64] = s.lo;
+  if (first) inv_out[inv_at] = inv_pow2(sc);
 }
 
 // per-thread description of the NIT rows this thread streams in a tile (the idx -> row map is the same
@@ -93,7 +115,7 @@ constexpr int wn_rows_nit(int mt) { return ((16 * mt + 4) * 16 + WN_THREADS - 1)
 // one node: one 8-byte store per part.  Stacked nodes m >= 2V of the padded N go to the dump row.
 template <int KS, int MTN, bool HOLD>
 __device__ __forceinline__ void node_mix2(const float* U, __bf16* Hh, __bf16* Hl, const float* AT, const GcnGeom& g, int nsl,
-                                          int dump_row, int w, int h, int q, int j) {
+                                          int dump_row, int w, int h, int q, int j, float sh) {
   // HOLD: the mix matrix fragments stay in registers for all slabs of the tile (small V: many slabs per tile);
   // !HOLD: they are read from LDS next to each MFMA (V = 42: one slab per tile, 66 registers would buy nothing)
   const int V = g.V;
@@ -134,7 +156,7 @@ __device__ __forceinline__ void node_mix2(const float* U, __bf16* Hh, __bf16* Hl
 #pragma unroll
       for (int sg = 0; sg < SGN; ++sg) {
         const int off = woff[mt] >= 0 ? (s + 2 * sg) * V * HS + woff[mt] : dump;
-        const Split4 sp = split4(acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3]);
+        const Split4 sp = split4h(acc[sg][0] * sh, acc[sg][1] * sh, acc[sg][2] * sh, acc[sg][3] * sh);
         *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
         *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
       }
@@ -150,7 +172,7 @@ __device__ __forceinline__ void node_mix2(const float* U, __bf16* Hh, __bf16* Hl
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = mfma16(xb[ks], HOLD ? am[mt][ks] : AT[(4 * ks + q) * g.ldA + 16 * mt + j], acc);
       const int off = woff[mt] >= 0 ? s * V * HS + woff[mt] : dump;
-      const Split4 sp = split4(acc[0], acc[1], acc[2], acc[3]);
+      const Split4 sp = split4h(acc[0] * sh, acc[1] * sh, acc[2] * sh, acc[3] * sh);
       *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
       *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
     }
@@ -159,7 +181,7 @@ __device__ __forceinline__ void node_mix2(const float* U, __bf16* Hh, __bf16* Hl
 
 // any V (runtime loops)
 __device__ __forceinline__ void node_mix2_generic(const float* U, __bf16* Hh, __bf16* Hl, const float* AT, const GcnGeom& g,
-                                                  int nsl, int w, int h, int q, int j) {
+                                                  int nsl, int w, int h, int q, int j, float sh) {
   const int V = g.V;
   const int ksteps = g.KP >> 2, mt_n = g.MP >> 4;
   for (int s = h; s < nsl; s += 2) {
@@ -172,7 +194,7 @@ __device__ __forceinline__ void node_mix2_generic(const float* U, __bf16* Hh, __
       if (m < 2 * V) {
         const int blk = (m >= V) ? 1 : 0;
         const int off = (s * V + m - blk * V) * HS + C * (1 + blk) + 16 * w + 4 * q;
-        const Split4 sp = split4(acc[0], acc[1], acc[2], acc[3]);
+        const Split4 sp = split4h(acc[0] * sh, acc[1] * sh, acc[2] * sh, acc[3] * sh);
         *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
         *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
       }
@@ -212,6 +234,7 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
   __bf16* Hh = reinterpret_cast<__bf16*>(U + rows_lds * LDD);     // [rows_lds][HS]
   __bf16* Hl = Hh + rows_lds * HS;
   float* AT = reinterpret_cast<float*>(Hl + rows_lds * HS);       // [KP][ldA]
+  float* RSI = AT + g.KP * g.ldA;                                 // [rows_lds] inverse of the tap panels' row scales
   // (the wave index is wave-uniform: as a scalar it keeps every per-wave base address out of the vector registers)
   int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), w = wv & 3, h = wv >> 2;
@@ -270,6 +293,20 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
   const float4 bg4 = *reinterpret_cast<const float4*>(bgp + 16 * w + 4 * q);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (do_gcn) bias4 = *reinterpret_cast<const float4*>(bm + 16 * w + 4 * q);
+  // inverse weight scales of this lane's 4 output channels (behind the fragments in the image); the operand scale of the
+  // contraction images u | uA1 | uA2 (behind the mix images in `prep`: hopmi_gcn_prepare bounds the mixes by the column sums)
+  const float* winv = reinterpret_cast<const float*>(wimg + WIMG_UNITS);
+  const float4 isf4 = *reinterpret_cast<const float4*>(winv + 16 * w + 4 * q);
+  const float4 isg4 = *reinterpret_cast<const float4*>(winv + C + 16 * w + 4 * q);
+  float4 ism4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sh = H_UNIT_SCALE;
+  if (do_gcn) {
+    const float* ptr = prep + g.KP * g.ldA + g.K2P * g.ldB;
+    sh = ptr[0];
+    const float ish = ptr[1];
+    const float4 t = *reinterpret_cast<const float4*>(winv + 2 * C + 16 * w + 4 * q);
+    ism4 = make_float4(t.x * ish, t.y * ish, t.z * ish, t.w * ish);
+  }
   const float4 sc4 = reinterpret_cast<const float4*>(scsh)[c4];
   const float4 sh4 = reinterpret_cast<const float4*>(scsh + C)[c4];
   f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};   // BatchNorm partial sums of channels 16w + 4q + r
@@ -321,12 +358,16 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
         a = make_float4(a.x * sc4.x + sh4.x, a.y * sc4.y + sh4.y, a.z * sc4.z + sh4.z, a.w * sc4.w + sh4.w);
         b2 = make_float4(b2.x * sc4.x + sh4.x, b2.y * sc4.y + sh4.y, b2.z * sc4.z + sh4.z, b2.w * sc4.w + sh4.w);
         if (!rm.ok[it]) { a = make_float4(0.f, 0.f, 0.f, 0.f); b2 = a; }
-        const Split4 sa = split4(a.x, a.y, a.z, a.w), sb = split4(b2.x, b2.y, b2.z, b2.w);
+        // one power-of-two scale per output row over BOTH taps (they meet in one accumulator): the row's 128 values sit in
+        // the 16 lanes of a DPP row
+        const float rs = scale_for_absmax(row16_max(absmax4(absmax4(0.f, a), b2)));
+        const Split4 sa = split4h(a.x * rs, a.y * rs, a.z * rs, a.w * rs), sb = split4h(b2.x * rs, b2.y * rs, b2.z * rs, b2.w * rs);
         const int off = row * RS + 4 * c4;
         *reinterpret_cast<u32x2*>(R0h + off) = sa.hi;
         *reinterpret_cast<u32x2*>(R0l + off) = sa.lo;
         *reinterpret_cast<u32x2*>(R1h + off) = sb.hi;
         *reinterpret_cast<u32x2*>(R1l + off) = sb.lo;
+        if (c4 == 0) RSI[row] = inv_pow2(rs);
       }
     }
     __syncthreads();
@@ -350,8 +391,8 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
         }
 #pragma unroll
         for (int i = 0; i < MTH; ++i) {
-          af[i] = mfma_split3(wt[0][ks][0], wt[0][ks][1], bh[i], bl[i], af[i]);
-          ag[i] = mfma_split3(wt[1][ks][0], wt[1][ks][1], bh[i], bl[i], ag[i]);
+          af[i] = mfma_h3(wt[0][ks][0], wt[0][ks][1], bh[i], bl[i], af[i]);
+          ag[i] = mfma_h3(wt[1][ks][0], wt[1][ks][1], bh[i], bl[i], ag[i]);
         }
       }
       HOPMI_STAMP(3);
@@ -365,16 +406,20 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
         const int mt = h * MTH + i;
         if (mt < MT) {
           const int row = 16 * mt + j;
-          const float4 u = make_float4(gate_(af[i][0] + bf4.x, ag[i][0] + bg4.x), gate_(af[i][1] + bf4.y, ag[i][1] + bg4.y),
-                                       gate_(af[i][2] + bf4.z, ag[i][2] + bg4.z), gate_(af[i][3] + bf4.w, ag[i][3] + bg4.w));
+          const float ir = RSI[row];
+          // pre-activations in real units: accumulator x (1 / row scale) x (1 / output channel's weight scale) + bias
+          const float4 pf = make_float4(af[i][0] * (isf4.x * ir) + bf4.x, af[i][1] * (isf4.y * ir) + bf4.y, af[i][2] * (isf4.z * ir) + bf4.z,
+                                        af[i][3] * (isf4.w * ir) + bf4.w);
+          const float4 pg = make_float4(ag[i][0] * (isg4.x * ir) + bg4.x, ag[i][1] * (isg4.y * ir) + bg4.y, ag[i][2] * (isg4.z * ir) + bg4.z,
+                                        ag[i][3] * (isg4.w * ir) + bg4.w);
+          const float4 u = make_float4(gate_(pf.x, pg.x), gate_(pf.y, pg.y), gate_(pf.z, pg.z), gate_(pf.w, pg.w));
           *reinterpret_cast<float4*>(U + row * LDD + 16 * w + 4 * q) = u;
-          const Split4 su = split4(u.x, u.y, u.z, u.w);
+          const Split4 su = split4h(u.x * sh, u.y * sh, u.z * sh, u.w * sh);
           *reinterpret_cast<u32x2*>(Hh + row * HS + 16 * w + 4 * q) = su.hi;
           *reinterpret_cast<u32x2*>(Hl + row * HS + 16 * w + 4 * q) = su.lo;
           if (fs != nullptr && row < R) {                        // diagnostic output only
-            const float4 f = make_float4(tanh_(af[i][0] + bf4.x), tanh_(af[i][1] + bf4.y), tanh_(af[i][2] + bf4.z), tanh_(af[i][3] + bf4.w));
-            const float4 sg = make_float4(sigmoid_(ag[i][0] + bg4.x), sigmoid_(ag[i][1] + bg4.y), sigmoid_(ag[i][2] + bg4.z),
-                                          sigmoid_(ag[i][3] + bg4.w));
+            const float4 f = make_float4(tanh_(pf.x), tanh_(pf.y), tanh_(pf.z), tanh_(pf.w));
+            const float4 sg = make_float4(sigmoid_(pg.x), sigmoid_(pg.y), sigmoid_(pg.z), sigmoid_(pg.w));
             float* fp = fs + (orow0 + row) * (2 * C) + 16 * w + 4 * q;
             *reinterpret_cast<float4*>(fp) = f;
             *reinterpret_cast<float4*>(fp + C) = sg;
@@ -395,9 +440,9 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
     if (do_gcn) {
       // ---- phase 2: node mix (exact fp32 MFMA, K = V) -> split images -------------------------------------------------
       const int dump_row = rows_lds - 1;
-      if (V == 9) node_mix2<3, 2, true>(U, Hh, Hl, AT, g, nsl, dump_row, w, h, q, j);              // TED
-      else if (V == 42) node_mix2<11, 6, false>(U, Hh, Hl, AT, g, nsl, dump_row, w, h, q, j);       // TED-Expressive
-      else node_mix2_generic(U, Hh, Hl, AT, g, nsl, w, h, q, j);
+      if (V == 9) node_mix2<3, 2, true>(U, Hh, Hl, AT, g, nsl, dump_row, w, h, q, j, sh);              // TED
+      else if (V == 42) node_mix2<11, 6, false>(U, Hh, Hl, AT, g, nsl, dump_row, w, h, q, j, sh);       // TED-Expressive
+      else node_mix2_generic(U, Hh, Hl, AT, g, nsl, w, h, q, j, sh);
       __syncthreads();
       HOPMI_STAMP(5);
       // ---- phase 3: channel contraction (K = 192, split products) + bias + residual, y store, BatchNorm sums ------
@@ -414,7 +459,7 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
           bl[i] = *reinterpret_cast<const u32x4*>(Hl + (16 * mt + j) * HS + 32 * ks + 8 * q);
         }
 #pragma unroll
-        for (int i = 0; i < MTH; ++i) acc[i] = mfma_split3(wm[ks][0], wm[ks][1], bh[i], bl[i], acc[i]);
+        for (int i = 0; i < MTH; ++i) acc[i] = mfma_h3(wm[ks][0], wm[ks][1], bh[i], bl[i], acc[i]);
       }
       HOPMI_STAMP(6);
 #pragma unroll
@@ -422,10 +467,10 @@ __global__ __launch_bounds__(WN_THREADS) void wn_layer_fwd_kernel(const TS* __re
         const int mt = h * MTH + i;
         const int row = 16 * mt + j;
         if (mt < MT && row < R) {
-          const float4 res = join4(*reinterpret_cast<const u32x2*>(R1h + row * RS + 16 * w + 4 * q),
-                                   *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q));        // gwnet.py:233
-          const f32x4 yv = {acc[i][0] + bias4.x + res.x, acc[i][1] + bias4.y + res.y, acc[i][2] + bias4.z + res.z,
-                            acc[i][3] + bias4.w + res.w};
+          const float4 res = join4h(*reinterpret_cast<const u32x2*>(R1h + row * RS + 16 * w + 4 * q),
+                                    *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q), RSI[row]);   // gwnet.py:233
+          const f32x4 yv = {acc[i][0] * ism4.x + bias4.x + res.x, acc[i][1] * ism4.y + bias4.y + res.y, acc[i][2] * ism4.z + bias4.z + res.z,
+                            acc[i][3] * ism4.w + bias4.w + res.w};
           if (y != nullptr) st4(y + (orow0 + row) * C + 16 * w + 4 * q, make_float4(yv[0], yv[1], yv[2], yv[3]));
           st1 += yv;
           st2 += yv * yv;
@@ -549,7 +594,7 @@ static int wn_grid(const LayerGeom& L) {
 }
 
 static size_t wn_fwd_lds_bytes(const GcnGeom& g) {
-  return (size_t)g.rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + ((size_t)g.rows_lds * LDD + (size_t)g.KP * g.ldA) * sizeof(float);
+  return (size_t)g.rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + ((size_t)g.rows_lds * (LDD + 1) + (size_t)g.KP * g.ldA) * sizeof(float);
 }
 
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;    // hopmi_time_next_launch
@@ -619,7 +664,7 @@ extern "C" int hopmi_noop_launch(void* stream) {
 }
 
 extern "C" size_t hopmi_wn_weight_image_bytes(int n_layers) {
-  return (n_layers > 0 && n_layers <= WN_MAX_LAYERS) ? (size_t)n_layers * WIMG_UNITS * sizeof(u32x4) : 0;
+  return (n_layers > 0 && n_layers <= WN_MAX_LAYERS) ? (size_t)n_layers * WIMGH_UNITS * sizeof(u32x4) : 0;
 }
 
 extern "C" int hopmi_wn_prepare_weights(const float* const* wf, const float* const* wg, const float* const* Wm, int n_layers,

@@ -7,8 +7,8 @@
 // Training-mode BatchNorm makes every layer a chip-wide dependency: layer i + 1 of ANY clip needs the statistics of layer i over
 // ALL clips.  As eight launches that seam was a kernel boundary plus a finalisation launch per layer (8 x (10.9 + 9.8) us at
 // TED / B = 128); here it is an in-launch exchange whose critical path is THREE memory hops.  Per layer every workgroup
-//   1. runs its tile(s) of the layer exactly as wn_layer_fwd_kernel does (same phases, same arithmetic), writing y_i with sc1
-//      (write-through) stores;
+//   1. runs its tile(s) of the layer exactly as wn_layer_fwd_kernel does (same phases, same arithmetic: three-term products of
+//      scaled fp16 hi/lo operands, f16_dev.h -- fp32-equivalent), writing y_i with sc1 (write-through) stores;
 //   2. publishes its 128 partial sums at once as data-tagged granules (8 bytes = {tag, fp32 bits}, ONE aligned store each:
 //      the data is the flag, nothing to drain first);
 //   3. the first workgroup of each group (group = workgroup index mod 8: one XCD under round-robin placement -- for speed
@@ -34,7 +34,7 @@
 #include <vector>
 
 #include "attn_dev.h"
-#include "bf16_dev.h"
+#include "f16_dev.h"
 #include "io_dev.h"
 #include "wn_dev.h"
 
@@ -72,6 +72,7 @@ struct StackArgs {
   int max_tiles;
   int n_layers, B, V, utail_ld4, n_comb;
   int KP, ldA, MP;       // mix-matrix image geometry (GcnGeom)
+  int prep_tr;           // float offset of prep's operand-scale trailer {s, 1 / s} (hopmi_gcn_prepare)
   float invV, momentum, eps;
 };
 
@@ -152,7 +153,7 @@ __device__ __forceinline__ bool stk_sweep(const u64* const (&p)[N], unsigned tag
 // Node mix of the slabs s = h, h + 2, ... of a tile (as wavenet.hip: node_mix2; see there).
 template <int KS, int MTN, bool HOLD>
 __device__ __forceinline__ void stk_node_mix(const float* U, __bf16* Hh, __bf16* Hl, const float* AT, int V, int ldA, int nsl,
-                                             int dump_row, int w, int h, int q, int j) {
+                                             int dump_row, int w, int h, int q, int j, float sh) {
   float am[HOLD ? MTN : 1][HOLD ? KS : 1];
   int woff[MTN];
 #pragma unroll
@@ -188,7 +189,7 @@ __device__ __forceinline__ void stk_node_mix(const float* U, __bf16* Hh, __bf16*
 #pragma unroll
       for (int sg = 0; sg < SGN; ++sg) {
         const int off = woff[mt] >= 0 ? (s + 2 * sg) * V * HS + woff[mt] : dump;
-        const Split4 sp = split4(acc[sg][0], acc[sg][1], acc[sg][2], acc[sg][3]);
+        const Split4 sp = split4h(acc[sg][0] * sh, acc[sg][1] * sh, acc[sg][2] * sh, acc[sg][3] * sh);
         *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
         *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
       }
@@ -204,7 +205,7 @@ __device__ __forceinline__ void stk_node_mix(const float* U, __bf16* Hh, __bf16*
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = mfma16(xb[ks], HOLD ? am[mt][ks] : AT[(4 * ks + q) * ldA + 16 * mt + j], acc);
       const int off = woff[mt] >= 0 ? s * V * HS + woff[mt] : dump;
-      const Split4 sp = split4(acc[0], acc[1], acc[2], acc[3]);
+      const Split4 sp = split4h(acc[0] * sh, acc[1] * sh, acc[2] * sh, acc[3] * sh);
       *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
       *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
     }
@@ -212,7 +213,7 @@ __device__ __forceinline__ void stk_node_mix(const float* U, __bf16* Hh, __bf16*
 }
 
 __device__ __forceinline__ void stk_node_mix_generic(const float* U, __bf16* Hh, __bf16* Hl, const float* AT, int V, int ldA, int KP,
-                                                     int MP, int nsl, int w, int h, int q, int j) {
+                                                     int MP, int nsl, int w, int h, int q, int j, float sh) {
   const int ksteps = KP >> 2, mt_n = MP >> 4;
   for (int s = h; s < nsl; s += 2) {
     const float* us = U + (s * V + q) * LDD + 16 * w + j;
@@ -224,7 +225,7 @@ __device__ __forceinline__ void stk_node_mix_generic(const float* U, __bf16* Hh,
       if (m < 2 * V) {
         const int blk = (m >= V) ? 1 : 0;
         const int off = (s * V + m - blk * V) * HS + C * (1 + blk) + 16 * w + 4 * q;
-        const Split4 sp = split4(acc[0], acc[1], acc[2], acc[3]);
+        const Split4 sp = split4h(acc[0] * sh, acc[1] * sh, acc[2] * sh, acc[3] * sh);
         *reinterpret_cast<u32x2*>(Hh + off) = sp.hi;
         *reinterpret_cast<u32x2*>(Hl + off) = sp.lo;
       }
@@ -255,6 +256,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
   int* FLAG = reinterpret_cast<int*>(SCSH + 2 * C);                // [4]
   float* GB = reinterpret_cast<float*>(FLAG + 4);                  // [n_layers][128] gamma | beta of every layer (read once: the
                                                                    // finalisation sits on the critical path of every exchange)
+  float* WINV = GB + STK_MAX_LAYERS * 2 * C;                       // [n_layers][192] inverse weight scales: filter | gate | Wm (x 1 / s_h)
+  float* RSI = WINV + STK_MAX_LAYERS * 3 * C;                      // [rows_lds] inverse of the tap panels' row scales
   // exchange scratch, aliased onto the (dead between layers) operand images Hh | Hl: 2 x rows_lds x 416 B >= 16.6 KB at MT = 1
   float* RED = reinterpret_cast<float*>(Hh);                       // [2][128] floats
   double* COMB = reinterpret_cast<double*>(RED + 4 * C);           // [4][128] doubles
@@ -279,6 +282,13 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
     const int l = idx / (2 * C), c = idx % (2 * C);
     GB[idx] = c < C ? A.L[l].gamma[c] : A.L[l].beta[c - C];
   }
+  // operand scale of the contraction images u | uA1 | uA2 (uniform; hopmi_gcn_prepare) and the layers' inverse weight scales
+  const float sh = A.prep[A.prep_tr], ish = A.prep[A.prep_tr + 1];
+  for (int idx = tid; idx < A.n_layers * 3 * C; idx += STK_THREADS) {
+    const int l = idx / (3 * C), c = idx % (3 * C);
+    const float v = reinterpret_cast<const float*>(A.wimg + (size_t)l * WIMGH_UNITS + WIMG_UNITS)[c];
+    WINV[idx] = c < 2 * C ? v : v * ish;
+  }
   if (tid == 0) { FLAG[0] = FLAG[1] = FLAG[2] = 0; FLAG[3] = *reinterpret_cast<volatile int*>(A.sync); }   // [3]: launch sequence number
   // u rows this workgroup never writes (tiles smaller than MT, the 4 padding rows) are read by the node mix's K padding times
   // zero: they must be finite
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
   u32x4 wt[2][4][2];
   u32x4 wm[6][2];
   auto load_wt = [&](int layer) {
-    const u32x4* tp = A.wimg + (size_t)layer * WIMG_UNITS + (size_t)(w * 2) * 4 * 2 * 64 + lane;
+    const u32x4* tp = A.wimg + (size_t)layer * WIMGH_UNITS + (size_t)(w * 2) * 4 * 2 * 64 + lane;
 #pragma unroll
     for (int gate = 0; gate < 2; ++gate)
 #pragma unroll
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         for (int part = 0; part < 2; ++part) wt[gate][ks][part] = tp[((gate * 4 + ks) * 2 + part) * 64];
   };
   auto load_wm = [&](int layer) {
-    const u32x4* mp = A.wimg + (size_t)layer * WIMG_UNITS + WIMG_TCN_UNITS + (size_t)(w * 6) * 2 * 64 + lane;
+    const u32x4* mp = A.wimg + (size_t)layer * WIMGH_UNITS + WIMG_TCN_UNITS + (size_t)(w * 6) * 2 * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
@@ -397,12 +407,15 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           a = make_float4(a.x * sc4.x + sh4.x, a.y * sc4.y + sh4.y, a.z * sc4.z + sh4.z, a.w * sc4.w + sh4.w);
           b2 = make_float4(b2.x * sc4.x + sh4.x, b2.y * sc4.y + sh4.y, b2.z * sc4.z + sh4.z, b2.w * sc4.w + sh4.w);
           if (!ok[it]) { a = make_float4(0.f, 0.f, 0.f, 0.f); b2 = a; }
-          const Split4 sa = split4(a.x, a.y, a.z, a.w), sb = split4(b2.x, b2.y, b2.z, b2.w);
+          // one power-of-two scale per output row over BOTH taps (the row's 128 values sit in the 16 lanes of a DPP row)
+          const float rs = scale_for_absmax(row16_max(absmax4(absmax4(0.f, a), b2)));
+          const Split4 sa = split4h(a.x * rs, a.y * rs, a.z * rs, a.w * rs), sb = split4h(b2.x * rs, b2.y * rs, b2.z * rs, b2.w * rs);
           const int off = row * RS + 4 * c4;
           *reinterpret_cast<u32x2*>(R0h + off) = sa.hi;
           *reinterpret_cast<u32x2*>(R0l + off) = sa.lo;
           *reinterpret_cast<u32x2*>(R1h + off) = sb.hi;
           *reinterpret_cast<u32x2*>(R1l + off) = sb.lo;
+          if (c4 == 0) RSI[row] = inv_pow2(rs);
         }
       }
       // the TCN weight fragments (L2-resident image, 128 KiB per workgroup through the CU's 64 B/clk vector-memory path: ~2 000
@@ -437,8 +450,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 #pragma unroll
           for (int i = 0; i < MTH; ++i) {
             if (2 * i + h < nt) {
-              af[i] = mfma_split3(wt[0][ks][0], wt[0][ks][1], bh[i], bl[i], af[i]);
-              ag[i] = mfma_split3(wt[1][ks][0], wt[1][ks][1], bh[i], bl[i], ag[i]);
+              af[i] = mfma_h3(wt[0][ks][0], wt[0][ks][1], bh[i], bl[i], af[i]);
+              ag[i] = mfma_h3(wt[1][ks][0], wt[1][ks][1], bh[i], bl[i], ag[i]);
             }
           }
         }
@@ -448,10 +461,16 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           const int mt = 2 * i + h;
           if (mt < MT && mt < nt) {
             const int row = 16 * mt + j;
-            const float4 u = make_float4(stk_gate(af[i][0] + bf4.x, ag[i][0] + bg4.x), stk_gate(af[i][1] + bf4.y, ag[i][1] + bg4.y),
-                                         stk_gate(af[i][2] + bf4.z, ag[i][2] + bg4.z), stk_gate(af[i][3] + bf4.w, ag[i][3] + bg4.w));
+            const float ir = RSI[row];
+            const float4 isf4 = *reinterpret_cast<const float4*>(WINV + layer * 3 * C + 16 * w + 4 * q);
+            const float4 isg4 = *reinterpret_cast<const float4*>(WINV + layer * 3 * C + C + 16 * w + 4 * q);
+            // pre-activations in real units: accumulator x (1 / row scale) x (1 / output channel's weight scale) + bias
+            const float4 u = make_float4(stk_gate(af[i][0] * (isf4.x * ir) + bf4.x, ag[i][0] * (isg4.x * ir) + bg4.x),
+                                         stk_gate(af[i][1] * (isf4.y * ir) + bf4.y, ag[i][1] * (isg4.y * ir) + bg4.y),
+                                         stk_gate(af[i][2] * (isf4.z * ir) + bf4.z, ag[i][2] * (isg4.z * ir) + bg4.z),
+                                         stk_gate(af[i][3] * (isf4.w * ir) + bf4.w, ag[i][3] * (isg4.w * ir) + bg4.w));
             *reinterpret_cast<float4*>(U + row * LDD + 16 * w + 4 * q) = u;
-            const Split4 su = split4(u.x, u.y, u.z, u.w);
+            const Split4 su = split4h(u.x * sh, u.y * sh, u.z * sh, u.w * sh);
             *reinterpret_cast<u32x2*>(Hh + row * HS + 16 * w + 4 * q) = su.hi;
             *reinterpret_cast<u32x2*>(Hl + row * HS + 16 * w + 4 * q) = su.lo;
           }
@@ -474,9 +493,9 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       }
 
       // ---- phase 2: node mix (exact fp32 MFMA, K = V) -> split images ------------------------------------------------
-      if (V == 9) stk_node_mix<3, 2, true>(U, Hh, Hl, AT, V, A.ldA, nsl, rows_lds - 1, w, h, q, j);
-      else if (V == 42) stk_node_mix<11, 6, false>(U, Hh, Hl, AT, V, A.ldA, nsl, rows_lds - 1, w, h, q, j);
-      else stk_node_mix_generic(U, Hh, Hl, AT, V, A.ldA, A.KP, A.MP, nsl, w, h, q, j);
+      if (V == 9) stk_node_mix<3, 2, true>(U, Hh, Hl, AT, V, A.ldA, nsl, rows_lds - 1, w, h, q, j, sh);
+      else if (V == 42) stk_node_mix<11, 6, false>(U, Hh, Hl, AT, V, A.ldA, nsl, rows_lds - 1, w, h, q, j, sh);
+      else stk_node_mix_generic(U, Hh, Hl, AT, V, A.ldA, A.KP, A.MP, nsl, w, h, q, j, sh);
       __syncthreads();
       STK_STAMP(layer, 4);
 
@@ -495,7 +514,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         }
 #pragma unroll
         for (int i = 0; i < MTH; ++i)
-          if (2 * i + h < nt) acc[i] = mfma_split3(wm[ks][0], wm[ks][1], bh[i], bl[i], acc[i]);
+          if (2 * i + h < nt) acc[i] = mfma_h3(wm[ks][0], wm[ks][1], bh[i], bl[i], acc[i]);
       }
       STK_STAMP(layer, 5);
 #pragma unroll
@@ -503,10 +522,11 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         const int mt = 2 * i + h;
         const int row = 16 * mt + j;
         if (mt < MT && row < R) {
-          const float4 res = join4(*reinterpret_cast<const u32x2*>(R1h + row * RS + 16 * w + 4 * q),
-                                   *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q));
-          const f32x4 yv = {acc[i][0] + bias4.x + res.x, acc[i][1] + bias4.y + res.y, acc[i][2] + bias4.z + res.z,
-                            acc[i][3] + bias4.w + res.w};
+          const float4 res = join4h(*reinterpret_cast<const u32x2*>(R1h + row * RS + 16 * w + 4 * q),
+                                    *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q), RSI[row]);
+          const float4 ism4 = *reinterpret_cast<const float4*>(WINV + layer * 3 * C + 2 * C + 16 * w + 4 * q);   // (1 / s_o)(1 / s_h)
+          const f32x4 yv = {acc[i][0] * ism4.x + bias4.x + res.x, acc[i][1] * ism4.y + bias4.y + res.y, acc[i][2] * ism4.z + bias4.z + res.z,
+                            acc[i][3] * ism4.w + bias4.w + res.w};
           IO::store(make_float4(yv[0], yv[1], yv[2], yv[3]), yr, ((orow0 + row) * C + 16 * w + 4 * q) * ES);
           st1 += yv;
           st2 += yv * yv;
@@ -699,8 +719,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 
 static size_t stk_lds_bytes(int mt, int KP, int ldA) {
   const size_t rows_lds = 16 * mt + 4;
-  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * LDD + (size_t)KP * ldA + 2 * C) * sizeof(float) + 16 +
-         (size_t)STK_MAX_LAYERS * 2 * C * sizeof(float);
+  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * (LDD + 1) + (size_t)KP * ldA + 2 * C) * sizeof(float) + 16 +
+         (size_t)STK_MAX_LAYERS * (2 + 3) * C * sizeof(float);
 }
 
 struct StackPlan {
@@ -864,6 +884,7 @@ extern "C" int hopmi_wn_stack_fwd_dt(const void* x0, const void* wimg, const flo
   A.max_tiles = P.tiles_max;
   A.n_layers = n_layers; A.B = B; A.V = V; A.utail_ld4 = utail_ld / 4; A.n_comb = P.n_comb;
   A.KP = g.KP; A.ldA = g.ldA; A.MP = g.MP;
+  A.prep_tr = g.KP * g.ldA + g.K2P * g.ldB;
   A.invV = 1.0f / V; A.momentum = momentum; A.eps = eps;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipEvent_t e1 = nullptr;

@@ -233,6 +233,7 @@ class GraphedTrainStep:
         # the exchange adds to the step is mostly its cuts and launches, not the copies.  Kept as an option for a measurement on
         # real links; the flat form stays the default.
         self.inplace = bool(inplace)
+        self.exchange_plan = {}                      # what each recorded all-reduce carries (filled while recording; bench.py reports it)
         self.enabled = enabled
         self.debug = debug
         self.records = {}
@@ -334,6 +335,7 @@ class GraphedTrainStep:
             cap.early = dict(ids={id(p) for p in early}, grads=grads, views=None, flat=None, pending=pending)
             return
         flat, views, _ = self._pack(grads)
+        self.exchange_plan["generator_first_half"] = dict(tensors=len(grads), elements=flat.numel(), dtype=str(flat.dtype).replace("torch.", ""))
         cap.keep.append(flat)
         cap.cut(lambda: pending.__setitem__("w", all_reduce_mean_start(flat, grp)))
         cap.early = dict(ids={id(p) for p in early}, grads=grads, views=views, flat=flat, pending=pending)
@@ -366,6 +368,8 @@ class GraphedTrainStep:
                 self._mapping_rows(is_disc)
                 return
             flat, views, n = self._pack(grads, extra=1)
+            self.exchange_plan["discriminator" if is_disc else ("generator_second_half" if early is not None else "generator")] = dict(
+                tensors=len(grads), elements=flat.numel(), dtype=str(flat.dtype).replace("torch.", ""))
             # one more element: this rank's persistent-GRU status words so far in the replay.  A hand-off time-out on one rank
             # then shows up in EVERY rank's next loss fetch, so all ranks raise at the same step instead of the healthy ones
             # waiting in the next collective for a rank that has stopped.

@@ -265,7 +265,20 @@ def batch_norm_cl(x, bn, training):
     if not (bn.affine and bn.track_running_stats and bn.momentum is not None and bn.running_mean is not None and C <= 64 and x.is_cuda):
         # what the kernels do not cover (no affine parameters, no running statistics, cumulative-average momentum, > 64 channels):
         # the module itself on the (B, C, T) view
-        return bn(x.transpose(1, 2)).transpose(1, 2)
+        if bool(training) == bool(bn.training):
+            return bn(x.transpose(1, 2)).transpose(1, 2)
+        # the caller's mode, not the module's own flag: the functional form with the module's buffers (batch statistics also when the
+        # module tracks none; the cumulative average when momentum is None)
+        use_batch = bool(training) or bn.running_mean is None
+        mom = bn.momentum
+        if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            if mom is None:
+                mom = 1.0 / float(bn.num_batches_tracked)
+        return torch.nn.functional.batch_norm(x.transpose(1, 2), bn.running_mean if (not training or bn.track_running_stats) else None,
+                                              bn.running_var if (not training or bn.track_running_stats) else None, bn.weight, bn.bias,
+                                              use_batch, 0.0 if mom is None else float(mom), float(bn.eps)).transpose(1, 2)
     if training:
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -340,7 +353,14 @@ def strict_fp32(on=None):
 F16_PARTS = 16      # the `parts` code of the fp16 hi/lo form (two scaled fp16 parts per operand, three MFMA terms, fp32-equivalent)
 # 16: fp16 hi/lo, three terms (fp32-equivalent, default since round 4);  3: six-term bf16 split (fp32-equivalent);
 # 2: three-term bf16 split (2^-16 class);  0: library fp32 GEMM (hipBLASLt)
-GEMM_PARTS = int(__import__("os").environ.get("HOPMI_GEMM_PARTS", "16"))
+def _env_gemm_parts():
+    raw = __import__("os").environ.get("HOPMI_GEMM_PARTS", "16")
+    if raw not in ("0", "2", "3", "16"):
+        raise ValueError(f"HOPMI_GEMM_PARTS={raw!r}: 0 (library fp32), 2, 3 (bf16 parts) or 16 (fp16 hi/lo)")
+    return int(raw)
+
+
+GEMM_PARTS = _env_gemm_parts()
 
 
 def gemm_parts(parts=None):
@@ -762,6 +782,21 @@ def cast_cache_reset():
     without recording the cast (stale or freed memory on every replay); a copy made while recording lives in the graph's pool."""
     _CAST_CACHE.clear()
     _F16_IMG.clear()
+    # frozen-owner images survive a recording (it may hold their address) -- except one that was first BUILT under capture: its
+    # prepare launch was only recorded and its memory belongs to the graph's pool, so an eager step must not be served it
+    for key in [k for k, v in _F16_IMG_FROZEN.items() if v[3]]:
+        del _F16_IMG_FROZEN[key]
+
+
+def invalidate_weight_images():
+    """Forget every cached operand derived from a weight (bf16 casts, fp16 hi/lo images of trainable AND frozen owners).  The caches
+    are keyed on the owner parameters' identity + version counter, so an update that bypasses the counter (`p.data.copy_`,
+    `p.data.mul_`, an EMA written through `.data`) leaves a stale image behind that every later forward / dX product would use
+    until the next optimizer step: call this after any such write.  (`load_state_dict`, optimizer steps and in-place ops on the
+    parameter itself move the counter and need nothing.)"""
+    _CAST_CACHE.clear()
+    _F16_IMG.clear()
+    _F16_IMG_FROZEN.clear()
 
 
 def _cast_param(w, dt):
@@ -871,9 +906,10 @@ def f16_weight_image(w, transpose=False, owners=None):
     # recordings when a frozen parameter's version moves)
     frozen = not any(o.requires_grad for o in owners)
     table = _F16_IMG_FROZEN if frozen else _F16_IMG
-    cap = False if frozen else torch.cuda.is_current_stream_capturing()
+    cap = w.is_cuda and torch.cuda.is_current_stream_capturing()
     hit = table.get(key)
-    if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == vers and hit[3] == cap:
+    # (a frozen image made by an EAGER call serves both sides of a recording; one made under capture only the recording)
+    if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == vers and (hit[3] == cap or (frozen and not hit[3])):
         return hit[2]
     img = build()
     if not frozen and len(table) > 256:
@@ -1401,10 +1437,19 @@ def stack_ws_prepare(from_stream: int, to_stream: int):
             _STACK_WS[new] = torch.zeros_like(_STACK_WS[key])
 
 
-def stack_ws_forget():
-    """Drop every stack workspace (after a launch raised its status word: the word is sticky and the launch sequence number was
-    not advanced, so the old workspaces must not serve another launch)."""
-    _STACK_WS.clear()
+def stack_ws_reset():
+    """After a launch raised its status word (sticky; the launch sequence number was not advanced): zero every stack workspace IN
+    PLACE, each on the stream it belongs to.  The memory is never released -- a recorded step holds the workspace of its stream by
+    ADDRESS (GraphedTrainStep keeps its recordings when the caller catches the time-out error and goes on stepping), so dropping
+    the tensors would let the allocator hand the same bytes to somebody else under the next replay's hand-off counters.  All-zero
+    tags match no launch (tag = sequence number x 16 + layer + 1 >= 1)."""
+    for key, ws in _STACK_WS.items():
+        if key[1]:
+            with torch.cuda.stream(torch.cuda.ExternalStream(key[1], device=ws.device)):
+                ws.zero_()
+        else:
+            with torch.cuda.stream(torch.cuda.default_stream(ws.device)):
+                ws.zero_()
 
 
 def wn_stack_supported(B: int, T_in: int, V: int, dilations) -> int:

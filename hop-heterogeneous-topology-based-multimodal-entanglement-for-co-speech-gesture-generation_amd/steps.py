@@ -144,8 +144,8 @@ class _LossFetch:
         vals = list(vals)
         if has_status and vals.pop() != 0.0:
             # (the stack kernel's status word is sticky and its launch sequence number was not advanced by the launch that timed
-            # out: its workspaces are dead -- the next launch gets fresh, zeroed ones)
-            _ops.stack_ws_forget()
+            # out: its workspaces are zeroed IN PLACE -- a recorded step holds them by address, they are never released)
+            _ops.stack_ws_reset()
             raise RuntimeError("hopmi: a persistent kernel (GRU recurrence / WaveNet stack) timed out waiting for a hand-off; "
                                "set HOPMI_GRU_PERSISTENT=0 to use per-step / per-layer launches")
         ret = {}

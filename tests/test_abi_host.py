@@ -38,7 +38,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert b"null pointer" in L.hopmi_last_error()
     assert L.hopmi_gcn_bwd_ws_floats(4, 9) == 64 * 192 + 64 + 2 * 81        # one workgroup tile
     assert L.hopmi_gcn_bwd_ws_floats(4, 49) == 0
-    assert L.hopmi_gcn_prep_floats(9) == 12 * 48 + 20 * 16 and L.hopmi_gcn_prep_floats(49) == 0
+    assert L.hopmi_gcn_prep_floats(9) == 12 * 48 + 20 * 16 + 4 and L.hopmi_gcn_prep_floats(49) == 0
 
 
 @pytest.mark.parametrize("V", [9, 42])

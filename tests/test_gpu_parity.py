@@ -1855,27 +1855,28 @@ def test_split_ffn_equals_unfused_composition(M, parts):
     assert rel_err(xa.grad.double(), xd.grad) <= tol
 
 
-# ---- the three-term split-bf16 kernels against float64, next to plain fp32 torch ---------------------------------------------
-# hopmi_gemm_split carries operands as three bf16 numbers (six MFMA terms) and is fp32-EQUIVALENT (test above).  The WaveNet,
-# reprogramming-attention and GRU-recurrence kernels carry them as TWO (hi + lo, 16 significand bits) and sum three MFMA terms
-# with fp32 accumulation: a product is good to ~2^-16 instead of fp32's 2^-24, so against float64 these kernels sit 2^8 = 256 x
-# above an fp32 evaluation of the same contraction in the worst case (random-sign terms: both errors grow with sqrt(K), the ratio
-# stays) -- and two orders of magnitude inside the north_star's 1e-3.  The tests pin exactly that: error vs float64 <= K_SPLIT3 x
-# the error of the plain-PyTorch fp32 evaluation (+ one fp32 rounding of the result), and <= CAP_SPLIT3 outright.
-K_SPLIT3 = 256.0
-CAP_SPLIT3 = 6e-5
+# ---- the three-term fp16 hi/lo kernels against float64, next to plain fp32 torch ----------------------------------------------
+# Since round 5 every hand-written contraction of the hot path carries its operands as two power-of-two-scaled fp16 numbers (hi + lo,
+# 22 significand bits; csrc/f16_dev.h) and sums three MFMA terms with fp32 accumulation: a product is good to a few 2^-23, i.e. at
+# or below what the fp32 accumulation of the dot product itself leaves.  (Rounds 2-4 carried bf16 hi/lo pairs in the WaveNet,
+# reprogramming-attention and GRU-recurrence kernels: 2^-16 per product, held to 256 x plain fp32's error and 6e-5 here.)  The tests
+# pin the fp32-equivalent class: error vs float64 <= K_FP32_CLASS x the error of the plain-PyTorch fp32 evaluation of the same
+# arithmetic (+ one fp32 rounding of the result), and <= CAP_FP32_CLASS outright.
+K_FP32_CLASS = 4.0
+CAP_FP32_CLASS = 2e-6
 
 
-def _assert_split3_class(dev_out, f32_out, f64_out, what):
+def _assert_fp32_class(dev_out, f32_out, f64_out, what, k=K_FP32_CLASS, cap=CAP_FP32_CLASS):
     e_dev, e_32 = rel_err(dev_out, f64_out), rel_err(f32_out, f64_out)
-    assert e_dev <= CAP_SPLIT3, f"{what}: error vs float64 {e_dev:.3e} > {CAP_SPLIT3} (plain fp32: {e_32:.3e})"
-    assert e_dev <= K_SPLIT3 * e_32 + 1.2e-7, f"{what}: error vs float64 {e_dev:.3e} > {K_SPLIT3} x plain fp32's {e_32:.3e}"
+    print(f"[fp32 class] {what}: device {e_dev:.3e}  plain fp32 {e_32:.3e}  ratio {e_dev / max(e_32, 1e-30):.2f}")
+    assert e_dev <= cap, f"{what}: error vs float64 {e_dev:.3e} > {cap} (plain fp32: {e_32:.3e})"
+    assert e_dev <= k * e_32 + 1.2e-7, f"{what}: error vs float64 {e_dev:.3e} > {k} x plain fp32's {e_32:.3e}"
     return e_dev, e_32
 
 
 @pytest.mark.parametrize("V,B", [(9, 128), (42, 64)])
 def test_wn_layer_vs_float64(V, B):
-    """One fused WaveNet layer (hopmi_wn_layer_fwd: gated TCN K = 128, graph conv K = 192 as three-term split-bf16 products, node
+    """One fused WaveNet layer (hopmi_wn_layer_fwd: gated TCN K = 128, graph conv K = 192 as three-term fp16 hi/lo products, node
     mix on the exact-fp32 MFMA) at the BASELINE.json shapes: pre-BatchNorm output y and the gated activations' skip tail against
     the float64 evaluation of gwnet.py:186-233, next to the same layer evaluated with plain fp32 torch ops."""
     from hopmi import ops
@@ -1905,12 +1906,12 @@ def test_wn_layer_vs_float64(V, B):
     scsh = torch.cat([torch.ones(64), torch.zeros(64)]).to(dev)
     y, _, _, _ = ops.wn_layer_fwd(xd, scsh, wimg, bf.to(dev), bg.to(dev), prep, bm.to(dev), tails, d, want_y=True, do_gcn=True)
     torch.cuda.synchronize()
-    _assert_split3_class(y.permute(0, 3, 2, 1), y32, y64, "y")
-    _assert_split3_class(tails.permute(0, 3, 2, 1), t32, t64, "skip tail")
+    _assert_fp32_class(y.permute(0, 3, 2, 1), y32, y64, "y")
+    _assert_fp32_class(tails.permute(0, 3, 2, 1), t32, t64, "skip tail")
 
 
 def test_reprog_attention_vs_float64():
-    """hopmi_reprog_attn_fwd / _bwd (scores, P V and the three backward contractions as three-term split-bf16 products, softmax in
+    """hopmi_reprog_attn_fwd / _bwd (scores, P V and the three backward contractions as three-term fp16 hi/lo products, softmax in
     fp32) at the real dimensions (34 x 8 heads x 128 against 1500 prototypes; B = 16 keeps the float64 score tensor small):
     output and dq, dk, dv against float64, next to plain fp32 torch."""
     from hopmi import ops
@@ -1934,11 +1935,11 @@ def test_reprog_attention_vs_float64():
     (o * go.to(dev)).sum().backward()
     torch.cuda.synchronize()
     for name, got, r32, r64 in zip(("o", "dq", "dk", "dv"), (o, qd.grad, kd.grad, vd.grad), ref32, ref64):
-        _assert_split3_class(got, r32, r64, name)
+        _assert_fp32_class(got, r32, r64, name)
 
 
 def test_gru_recurrence_vs_float64(monkeypatch):
-    """hopmi_gru_fwd / hopmi_gru_bwd (the recurrent product h W_hh^T as three-term split-bf16 MFMA products with the fragments in
+    """hopmi_gru_fwd / hopmi_gru_bwd (the recurrent product h W_hh^T as three-term fp16 hi/lo MFMA products with the fragments in
     registers; input projections and weight gradients are library fp32 GEMMs) at the decoder's shape (B = 128, T = 34, 992 -> 350,
     two of its four bidirectional layers): output, input gradient and the recurrent weights' gradients against a float64
     nn.GRU, next to the fp32 nn.GRU on the host.  34 dependent steps carry a step's error forward, for both evaluations."""
@@ -1967,7 +1968,14 @@ def test_gru_recurrence_vs_float64(monkeypatch):
     torch.cuda.synchronize()
     got = [yd, xd.grad] + [gd.get_parameter(n).grad for n in ("weight_hh_l0", "weight_hh_l1_reverse", "weight_ih_l1")]
     for name, a, r32, r64 in zip(("y", "dx", "dW_hh l0", "dW_hh l1 reverse", "dW_ih l1"), got, ref32, ref64):
-        _assert_split3_class(a, r32, r64, name)
+        # y and dx are the recurrence kernels' own outputs (y: measured 1.1 x the host fp32 evaluation's error; dx: 3.2 x, through the
+        # input projection's dX GEMM).  The weight gradients are GEMMs over the B T = 4 352 rows behind the kernels: their error is the
+        # GEMM's summation order, 4.9-6.6 x the host's with the exact-fp32 per-step recurrence kernels as with these
+        # (tools/probes/attn_f64.py, round 5): 8 x / 4e-6 for those
+        if name.startswith("dW"):
+            _assert_fp32_class(a, r32, r64, name, k=8.0, cap=4e-6)
+        else:
+            _assert_fp32_class(a, r32, r64, name)
 
 
 def test_strict_fp32_switch_vs_float64():
@@ -1975,7 +1983,8 @@ def test_strict_fp32_switch_vs_float64():
     the exact-fp32 graph-conv kernel + library GEMMs + torch BatchNorm, the GRU recurrences as per-time-step launches of the
     exact-fp32 kernel, the reprogramming attention as fp32 tensor operations).  Each against float64 next to plain fp32 torch on the
     host: the strict forms must be fp32-CLASS (error <= 3 x the fp32 evaluation's + one rounding, the bound hopmi_gemm_split's
-    fp32-equivalent forms are held to), the default forms stay in the three-term class (K_SPLIT3)."""
+    fp32-equivalent forms are held to).  Since round 5 the DEFAULT forms (fp16 hi/lo products) are fp32-class too (K_FP32_CLASS);
+    the switch stays as a second, independently written evaluation of the same three operators."""
     import copy
     import hopmi
     from hopmi import ops
@@ -2006,7 +2015,7 @@ def test_strict_fp32_switch_vs_float64():
         with torch.no_grad():
             out_strict = m(x0.to(dev)).cpu()
         strict_class(out_strict, w32, w64, "gwnet out")
-        _assert_split3_class(out_default, w32, w64, "gwnet out (default)")
+        _assert_fp32_class(out_default, w32, w64, "gwnet out (default)")
 
         # ---- reprogramming attention
         g = torch.Generator().manual_seed(23)

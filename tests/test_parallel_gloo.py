@@ -207,3 +207,26 @@ def test_real_generator_skeleton_and_prototype_sharding_world2_gloo():
         assert r["S_ok"] and r["outside_zero"]
         assert r["dW_err"] <= 1e-6 and r["db_err"] <= 1e-6, r
     assert a["rows"] == (0, 6, 6) and b["rows"] == (6, 11, 6)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` typed as such (no WORLD_SIZE): the process starts two fresh ranks under torch.distributed.run,
+    they rendezvous on 127.0.0.1, run the timing reduction and rank 0's JSON line comes back through the parent with exit code 0
+    (`--plumbing-check`: no GPU work -- this box has none).  Without the check the ranks stop at the "needs MI355X GPUs"
+    assertion -- not at the WORLD_SIZE one that used to fire in the parent -- and the parent forwards a non-zero code."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--plumbing-check"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_in_group"] == 2 and out["max_over_ranks"] == 2.0 and out["steps"] == 3
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                           text=True, timeout=240)
+        assert r.returncode != 0
+        assert "needs MI355X GPUs" in r.stderr and "WORLD_SIZE=" not in r.stderr
