@@ -70,6 +70,10 @@ SIGNATURES = {
     "hopmi_bias_dropout_residual_layernorm_fwd_rs": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float,
                                                          ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
     "hopmi_bias_dropout_residual_layernorm_bwd_rs": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
+    "hopmi_bias_dropout_residual_layernorm_fwd_im": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float,
+                                                         ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
+    "hopmi_bias_dropout_residual_layernorm_bwd_im": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I,
+                                                         _VP]),
     "hopmi_bert_attn_fwd_dt": (_I, [_VP, _VP, _I, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
     "hopmi_bert_attn_bwd_dt": (_I, [_VP, _VP, _VP, _I, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
     "hopmi_bn_cl_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float, ctypes.c_float, _I, _VP]),
@@ -83,7 +87,11 @@ SIGNATURES = {
     "hopmi_gemm_f16x2_prepare": (_I, [_VP, _I, _I, _VP, _VP]),
     "hopmi_rows_image_f16": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "hopmi_gemm_f16x2_ab": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "hopmi_gemm_f16x2_ab_ep": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gemm_f16x2_tiles_n": (_I, [_I]),
+    "hopmi_gemm_f16x2_tn_ws_floats": (ctypes.c_size_t, [_I, _I, _I, _I]),
+    "hopmi_gemm_f16x2_tn": (_I, [_VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _I, _I, _I, _I, _I,
+                                _VP]),
     "hopmi_gemm_f16x2": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gemm_split_ep": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "hopmi_gru_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),

@@ -163,20 +163,22 @@ __device__ __forceinline__ void load_row_frags(const TIO* p, u32x4 (&fh)[4], u32
 }
 
 // Running scale of ONE row of a dS tile (accumulator layout: a lane holds two columns of the row, the row spans the 16 lanes of a
-// DPP row): mr = running maximum of |dS| over the row so far; the row's power-of-two scale is a function of it (not kept:
-// registers).  Returns the scale to split this tile's row with; when it differs from the previous one, the row of the
-// accumulator is taken along (x new / old: exact).
+// DPP row).  `sd` is the row's current power-of-two scale (start: 2^60, "as large as any value could use"); a tile whose largest
+// magnitude would not fit under it (>= 2^15 after scaling) replaces it by the scale of that magnitude, and the row of the
+// accumulator is taken along (x new / old: exact, and rare -- the running maximum has to double).  Returns the scale to split
+// this tile's row with.
+constexpr float DS_SCALE0 = 1152921504606846976.f;                  // 2^60
 template <int NACC>
-__device__ __forceinline__ float ds_row_scale(float d0, float d1, float& mr, f32x4 (&acc)[NACC], int r) {
-  const float so = scale_for_absmax(mr);
-  mr = fmaxf(mr, row16_max(fmaxf(fabsf(d0), fabsf(d1))));
-  const float sn = scale_for_absmax(mr);
-  if (__ballot(sn != so) != 0ull) {                                 // (rare: the running maximum crossed a power of two)
-    const float ratio = sn * inv_pow2(so);
+__device__ __forceinline__ float ds_row_scale(float d0, float d1, float& sd, f32x4 (&acc)[NACC], int r) {
+  const float rm = row16_max(fmaxf(fabsf(d0), fabsf(d1)));
+  if (__ballot(rm * sd >= 32768.f) != 0ull) {
+    const float sn = rm * sd >= 32768.f ? scale_for_absmax(rm) : sd;
+    const float ratio = sn * inv_pow2(sd);
 #pragma unroll
     for (int nt = 0; nt < NACC; ++nt) acc[nt][r] *= ratio;
+    sd = sn;
   }
-  return sn;
+  return sd;
 }
 
 // XOR swizzle of the 16-byte slots of 64-byte LDS rows ([rows][32 x bf16]) read as MFMA operands by ds_read_b128
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void reprog_attn_bwd_dkv_
       vh[ks] = g.hi; vl[ks] = g.lo;
     }
   }
-  float mr[4] = {0.f, 0.f, 0.f, 0.f};                                  // running maximum of |dS^T| per key row (its scale: ds_row_scales)
+  float sds[4] = {DS_SCALE0, DS_SCALE0, DS_SCALE0, DS_SCALE0};         // running power-of-two scale of dS^T per key row (ds_row_scale)
   f32x4 acc_dk[8], acc_dv[8];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) { acc_dk[nt] = {0.f, 0.f, 0.f, 0.f}; acc_dv[nt] = {0.f, 0.f, 0.f, 0.f}; }
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void reprog_attn_bwd_dkv_
         pm[nt] = pr * keepf;                                          // (P o M)^T
         ds[nt] = pr * (acc_dp[nt][r] * cd * keepf - drow[nt]);        // dS^T / scale (the scale joins in the epilogue)
       }
-      const float sd = ds_row_scale(ds[0], ds[1], mr[r], acc_dk, r);   // (key row r of the tile: running maximum over the query rows)
+      const float sd = ds_row_scale(ds[0], ds[1], sds[r], acc_dk, r);  // (key row r of the tile: running scale over the query rows)
       const u32x2 sp = split2h(pm[0] * H_UNIT_SCALE, pm[1] * H_UNIT_SCALE), ss = split2h(ds[0] * sd, ds[1] * sd);
       const int prow = 4 * q + r;
       const int off = prow * 64 + (((j >> 2) ^ swz64(prow)) << 4) + ((j & 3) << 2);
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void reprog_attn_bwd_dkv_
   for (int r = 0; r < 4; ++r) {
     const int key = key_c0 + r;
     if (key < S) {
-      const float kk = inv_pow2(scale_for_absmax(mr[r])) * inv_q * scale, kv = H_UNIT_INV * inv_d;   // accumulator units: s_dS[key] s_Q / scale and 2^14 s_dO
+      const float kk = inv_pow2(sds[r]) * inv_q * scale, kv = H_UNIT_INV * inv_d;   // accumulator units: s_dS[key] s_Q / scale and 2^14 s_dO
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
         dK[(size_t)key * rs + (size_t)h * AE + 16 * nt + j] = acc_dk[nt][r] * kk;

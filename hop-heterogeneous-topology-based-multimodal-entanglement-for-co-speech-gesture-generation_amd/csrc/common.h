@@ -30,11 +30,13 @@ int env_int(const char* name, int dflt);   // cached environment knob (api.hip)
 inline int ceil_to(int x, int m) { return (x + m - 1) / m * m; }
 
 // ---- operand scales of the fp16 hi/lo GEMM form (gemm.hip; also written by the kernels that produce its A operand)
-// power-of-two scale for a row / tensor whose largest magnitude has the bits `m` (sign cleared): max * s in [2^14, 2^15); 1 for an
-// all-zero / subnormal / non-finite one (a NaN or infinity then travels through the products as itself)
+// power-of-two scale for a row / tensor whose largest magnitude has the bits `m` (sign cleared): max * s in [2^14, 2^15); 1 for a
+// non-finite one (a NaN or infinity then travels through the products as itself); the LARGEST scale (2^123) for an all-zero /
+// subnormal one -- "no magnitude to protect": whoever takes the minimum over a set of rows' scales (gemm_tn.hip: the operand's one
+// scale when the rows are the contraction index) is then not held back by its empty rows
 __device__ __forceinline__ unsigned scale_bits_for_max(unsigned m) {
   const int e = (int)(m >> 23);
-  const int sb = (e == 0 || e == 255) ? 127 : min(268 - e, 250);
+  const int sb = e == 255 ? 127 : (e == 0 ? 250 : min(268 - e, 250));
   return (unsigned)sb << 23;
 }
 __device__ __forceinline__ float inv_scale(unsigned scale_bits) { return __uint_as_float((254u << 23) - scale_bits); }

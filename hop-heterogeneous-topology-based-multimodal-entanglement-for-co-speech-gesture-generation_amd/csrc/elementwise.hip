@@ -9,6 +9,7 @@
 // LayerNorm rows (D <= 1024, D % 4 == 0; 768 for BERT-base) are one wave each: the row lives in registers,
 // mean/variance by DPP + cross-row shuffles, so x is read once and out written once.  Dropout uses the same
 // stateless hash as the attention kernel (seed, row, column) so the backward regenerates the mask.
+#include "f16_dev.h"
 #include "io_dev.h"
 
 namespace hopmi {
@@ -57,6 +58,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int LN_MAX4 = 4;            // float4 per lane: D <= 64 * 4 * 4 = 1024
 
+// The row a wave holds in registers, times its power-of-two scale, as the fp16 hi / lo images [2][M][D] that hopmi_gemm_f16x2_ab
+// reads by LDS-DMA (hopmi_rows_image_f16's layout): the GEMM behind this operator then needs neither the split in its k-loop nor a
+// pass of its own over the activations (round 5).
+__device__ __forceinline__ void ln_store_image(unsigned* __restrict__ image, const float4 (&v)[LN_MAX4], int M, int D4, int row, int lane, float sc) {
+  u32x2* hi = reinterpret_cast<u32x2*>(image) + (size_t)row * D4;
+  u32x2* lo = reinterpret_cast<u32x2*>(image) + ((size_t)M + row) * D4;
+#pragma unroll
+  for (int k = 0; k < LN_MAX4; ++k) {
+    const int c4 = lane + 64 * k;
+    if (c4 < D4) {
+      const Split4 sp = split4h(v[k].x * sc, v[k].y * sc, v[k].z * sc, v[k].w * sc);
+      hi[c4] = sp.hi;
+      lo[c4] = sp.lo;
+    }
+  }
+}
+
 // one wave per row: z = dropout(x + bias) + res[row % res_rows] ; out = (z - mean) * rstd * gamma + beta
 // saves z's normalised form xhat and rstd for the backward.
 // `x` is typed (the GEMM output); `out` stays fp32 (it is the next block's residual) and `out_t` (nullable) receives the same
@@ -69,7 +87,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
                                                                    float* __restrict__ xhat, float* __restrict__ rstd_out, int M,
                                                                    int D, int res_rows, float eps, unsigned drop_thresh,
                                                                    float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev,
-                                                                   float* __restrict__ row_scales) {
+                                                                   float* __restrict__ row_scales, unsigned* __restrict__ image) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -118,12 +136,14 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
       if (out_t != nullptr) st4(out_t + ((size_t)row * D4 + c4) * 4, o);
       if (xhat != nullptr) reinterpret_cast<float4*>(xhat)[(size_t)row * D4 + c4] = h;
       amax = abs_bits_max4(amax, o);
+      z[k] = o;                                 // (kept for the image below)
     }
   }
   if (rstd_out != nullptr && lane == 0) rstd_out[row] = rstd;
   if (row_scales != nullptr) {
     amax = wave_max_u32(amax);
     if (lane == 0) store_row_scale(row_scales, M, row, amax);
+    if (image != nullptr) ln_store_image(image, z, M, D4, row, lane, __uint_as_float(scale_bits_for_max(amax)));
   }
 }
 
@@ -135,7 +155,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
                                                                    const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                                    T* __restrict__ dx, float* __restrict__ dres, int M, int D,
                                                                    unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev,
-                                                                   float* __restrict__ row_scales) {
+                                                                   float* __restrict__ row_scales, unsigned* __restrict__ image) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -178,11 +198,13 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
       }
       st4(dx + ((size_t)row * D4 + c4) * 4, dz);
       amax = abs_bits_max4(amax, dz);
+      dh[k] = dz;                               // (kept for the image below)
     }
   }
   if (row_scales != nullptr) {
     amax = wave_max_u32(amax);
     if (lane == 0) store_row_scale(row_scales, M, row, amax);
+    if (image != nullptr) ln_store_image(image, dh, M, D4, row, lane, __uint_as_float(scale_bits_for_max(amax)));
   }
 }
 
@@ -427,11 +449,12 @@ extern "C" int hopmi_bias_gelu_bwd(const float* x, const float* bias, const floa
   return hopmi_bias_gelu_bwd_dt(x, bias, dy, dx, M, N, HOPMI_F32, stream);
 }
 
-extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_rs(const void* x, const float* bias, const float* res, int res_rows,
+extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_im(const void* x, const float* bias, const float* res, int res_rows,
                                                             const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
-                                                            float* rstd, float* row_scales, int M, int D, float eps, float p_drop,
+                                                            float* rstd, float* row_scales, void* image, int M, int D, float eps, float p_drop,
                                                             unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_fwd")) return e;
+  if (image != nullptr && !row_scales) { set_error("hopmi_bias_dropout_residual_layernorm_fwd_im: the image needs row_scales"); return HOPMI_EINVAL; }
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_fwd_dt", dtype)) return e;
   if (!x || !bias || !res || !gamma || !beta || !out) { set_error("hopmi_bias_dropout_residual_layernorm_fwd: null pointer argument"); return HOPMI_EINVAL; }
   if (D > 256 * LN_MAX4 || res_rows <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
@@ -443,11 +466,21 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_rs(const void* x, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == HOPMI_BF16)
     hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const __bf16*>(x), bias, res,
-                       gamma, beta, out, static_cast<__bf16*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales);
+                       gamma, beta, out, static_cast<__bf16*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales,
+                       static_cast<unsigned*>(image));
   else
     hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const float*>(x), bias, res,
-                       gamma, beta, out, static_cast<float*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales);
+                       gamma, beta, out, static_cast<float*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales,
+                       static_cast<unsigned*>(image));
   return check_launch("hopmi_bias_dropout_residual_layernorm_fwd");
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_rs(const void* x, const float* bias, const float* res, int res_rows,
+                                                            const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
+                                                            float* rstd, float* row_scales, int M, int D, float eps, float p_drop,
+                                                            unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
+  return hopmi_bias_dropout_residual_layernorm_fwd_im(x, bias, res, res_rows, gamma, beta, out, out_t, xhat, rstd, row_scales, nullptr, M, D, eps,
+                                                      p_drop, seed, seed_dev, dtype, stream);
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const float* bias, const float* res, int res_rows,
@@ -458,10 +491,12 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const
                                                       seed, seed_dev, dtype, stream);
 }
 
-extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
-                                                            const float* gamma, void* dx, float* dres, float* row_scales, int M, int D,
-                                                            float p_drop, unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
+extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_im(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                            const float* gamma, void* dx, float* dres, float* row_scales, void* image, int M,
+                                                            int D, float p_drop, unsigned seed, const unsigned* seed_dev, int dtype,
+                                                            void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
+  if (image != nullptr && !row_scales) { set_error("hopmi_bias_dropout_residual_layernorm_bwd_im: the image needs row_scales"); return HOPMI_EINVAL; }
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_bwd_dt", dtype)) return e;
   if (!dout || !xhat || !rstd || !gamma || !dx || !dres) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: null pointer argument"); return HOPMI_EINVAL; }
   if (D > 256 * LN_MAX4 || !(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: D=%d p_drop=%f", D, p_drop); return HOPMI_EINVAL; }
@@ -470,11 +505,18 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == HOPMI_BF16)
     hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const __bf16*>(dout_t), xhat,
-                       rstd, gamma, static_cast<__bf16*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales);
+                       rstd, gamma, static_cast<__bf16*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales, static_cast<unsigned*>(image));
   else
     hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const float*>(dout_t), xhat,
-                       rstd, gamma, static_cast<float*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales);
+                       rstd, gamma, static_cast<float*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales, static_cast<unsigned*>(image));
   return check_launch("hopmi_bias_dropout_residual_layernorm_bwd");
+}
+
+extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                            const float* gamma, void* dx, float* dres, float* row_scales, int M, int D,
+                                                            float p_drop, unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
+  return hopmi_bias_dropout_residual_layernorm_bwd_im(dout, dout_t, xhat, rstd, gamma, dx, dres, row_scales, nullptr, M, D, p_drop, seed, seed_dev,
+                                                      dtype, stream);
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, const void* dout_t, const float* xhat, const float* rstd,

@@ -451,7 +451,10 @@ __device__ __forceinline__ int gswz(int row) { return (0x1230 >> (4 * ((row >> 2
 template <int NP, int NBUF, bool F16 = false>
 __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Bimg,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N,
-                                                             int K, int tiles_m, int tiles_n, const float* __restrict__ a_rows) {
+                                                             int K, int tiles_m, int tiles_n, const float* __restrict__ a_rows, int ep,
+                                                             float* __restrict__ C2, const float* __restrict__ aux,
+                                                             float* __restrict__ c_rowmax) {
+  __shared__ unsigned s_cmax[F16 ? 128 : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int IMG = 128 * 64;                    // bytes of one part image of one operand tile
   constexpr int BUFB = 2 * NP * IMG;               // [A parts | B parts]
@@ -531,6 +534,15 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
     __builtin_amdgcn_s_barrier();
   }
 
+  // epilogue (the split form's, gemm_split_kernel: bias / GELU (+ the pre-activation) / GELU gradient; the row maxima of what is
+  // written per column tile for the GEMM that consumes C)
+  if (F16 && c_rowmax != nullptr && tid < 128) s_cmax[tid] = 0u;
+  if (F16 && c_rowmax != nullptr) __syncthreads();
+  unsigned rmx[F16 ? 4 : 1][4];
+#pragma unroll
+  for (int mi = 0; mi < (F16 ? 4 : 1); ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rmx[mi][r] = 0u;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int col = n0 + 32 * wc + 16 * ni + n;
@@ -542,14 +554,39 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 64 * wr + 16 * mi + 4 * q + r;
-        if (row < M) C[(size_t)row * N + col] = F16 ? acc[mi][ni][r] * a_rows[M + row] * sb + bv : acc[mi][ni][r] + bv;
+        if (row < M) {
+          const size_t at = (size_t)row * N + col;
+          const float h = F16 ? acc[mi][ni][r] * a_rows[M + row] * sb + bv : acc[mi][ni][r] + bv;
+          float out;
+          if (!F16 || ep == EP_BIAS) out = h;
+          else if (ep == EP_GELU) {
+            if (C2 != nullptr) C2[at] = h;
+            out = gemm_gelu(h);
+          } else out = h * gemm_gelu_grad(aux[at]);
+          C[at] = out;
+          if (F16) rmx[mi][r] = max(rmx[mi][r], __float_as_uint(out) & 0x7fffffffu);
+        }
       }
+  }
+  if (F16 && c_rowmax != nullptr) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsigned v = rmx[mi][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+        if (n == 0) atomicMax(&s_cmax[64 * wr + 16 * mi + 4 * q + r], v);
+      }
+    __syncthreads();
+    if (tid < 128 && m0 + tid < M) c_rowmax[(size_t)tn * M + m0 + tid] = __uint_as_float(s_cmax[tid]);
   }
 }
 
 template <int NP, int NBUF, bool F16 = false>
 static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
-                           const float* a_rows = nullptr) {
+                           const float* a_rows = nullptr, int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr,
+                           float* c_rowmax = nullptr) {
   const int tiles_m = (M + 127) / 128, tiles_n = (N + GN - 1) / GN;
   const size_t lds = (size_t)NBUF * 2 * NP * 128 * 64;
   static bool attr_done = false;
@@ -562,7 +599,7 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF, F16>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
-                     static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n, a_rows);
+                     static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n, a_rows, ep, C2, aux, c_rowmax);
 }
 
 // Tile choice by the number of 128 x 128 tiles, measured at the frozen BERT's shapes for M = 4352 (TED, batch 128) and M = 2176
@@ -642,17 +679,31 @@ extern "C" int hopmi_rows_image_f16(const float* A, int M, int K, void* image, f
   return check_launch("hopmi_rows_image_f16");
 }
 
-extern "C" int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M,
-                                   int N, int K, void* stream) {
+extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
+                                      const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream) {
   if (!Aimage || !a_scales || !Bimage || !C) { set_error("hopmi_gemm_f16x2_ab: null pointer argument"); return HOPMI_EINVAL; }
   if (M <= 0 || N <= 0 || K <= 0 || K % GK) {
     set_error("hopmi_gemm_f16x2_ab: need K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
     return HOPMI_EINVAL;
   }
+  if (epilogue < EP_BIAS || epilogue > EP_GELU_GRAD || (epilogue == EP_GELU_GRAD && !aux)) {
+    set_error("hopmi_gemm_f16x2_ab: epilogue %d (0 bias, 1 gelu, 2 gelu gradient: needs aux)", epilogue);
+    return HOPMI_EINVAL;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (env_int("HOPMI_GEMM_NBUF", 3) == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales);
-  else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales);
+  // tile buffers (tools/probes/bench_ab.py, M = 4352): two (64 KB: two workgroups per CU) where the output has many column tiles
+  // (N = 2304: 69 vs 75 us, N = 3072: 84 vs 100), three (one workgroup per CU) for long contractions over few tiles (N = 768: K = 768
+  // 26 vs 28, K = 2304 59 vs 65, K = 3072 77 vs 86)
+  const int forced = env_int("HOPMI_GEMM_NBUF", 0);
+  const int nbuf = (forced == 2 || forced == 3) ? forced : (N >= 2048 ? 2 : 3);
+  if (nbuf == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
+  else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   return check_launch("hopmi_gemm_f16x2_ab");
+}
+
+extern "C" int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M,
+                                   int N, int K, void* stream) {
+  return hopmi_gemm_f16x2_ab_ep(Aimage, a_scales, Bimage, bias, C, nullptr, nullptr, nullptr, M, N, K, EP_BIAS, stream);
 }
 
 extern "C" int hopmi_gemm_f16x2_tiles_n(int N) { return N > 0 ? (N + GN - 1) / GN : 0; }

@@ -477,13 +477,19 @@ __device__ __forceinline__ Split8 load_w_frag(const float* row, int k0, int K, f
 template <int MAXK2, typename RowOf>
 __device__ __forceinline__ void load_resident_w(u32x4 (&wh)[3][MAXK2], u32x4 (&wl)[3][MAXK2], float (&inv)[3], RowOf wrow, int H, int kq,
                                                 int ch, int q, int i, int w, float* xch) {
+  // ONE pass over the rows (a lane's loads are row-strided: 64 cache lines per wave instruction -- the second pass of the first
+  // version cost 15 us per launch): the raw values wait in registers (24 MAXK2 floats) for the row maxima
+  float4 ra[3][MAXK2], rb[3][MAXK2];
   float m[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     const float* row = wrow(g);
     float mm = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < MAXK2; ++kk) mm = absmax_w8(mm, row, (kq * MAXK2 + kk) * 32 + 8 * q, H);
+    for (int kk = 0; kk < MAXK2; ++kk) {
+      load_w8(row, (kq * MAXK2 + kk) * 32 + 8 * q, H, ra[g][kk], rb[g][kk]);
+      mm = absmax4(absmax4(mm, ra[g][kk]), rb[g][kk]);
+    }
     mm = fmaxf(mm, __shfl_xor(mm, 16));
     mm = fmaxf(mm, __shfl_xor(mm, 32));
     m[g] = mm;
@@ -497,10 +503,9 @@ __device__ __forceinline__ void load_resident_w(u32x4 (&wh)[3][MAXK2], u32x4 (&w
     for (int k2 = 0; k2 < 4; ++k2) mm = fmaxf(mm, xch[((ch * 4 + k2) * 3 + g) * 16 + i]);
     const float sc = scale_for_absmax(mm);
     inv[g] = inv_pow2(sc);
-    const float* row = wrow(g);
 #pragma unroll
     for (int kk = 0; kk < MAXK2; ++kk) {
-      const Split8 f = load_w_frag(row, (kq * MAXK2 + kk) * 32 + 8 * q, H, sc);
+      const Split8 f = split8h(ra[g][kk], rb[g][kk], sc);
       wh[g][kk] = f.hi; wl[g][kk] = f.lo;
     }
   }
@@ -786,20 +791,27 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
       }
       __syncthreads();
       GRU_STAMP(2);
+      // one accumulator per gate block (its segments carry their own scales), the three chains interleaved; combined afterwards
+      f32x4 ag[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) ag[g] = {0.f, 0.f, 0.f, 0.f};
+      const unsigned* ahp = Ahi + i * WS2 + 4 * q + kq * MAXK2 * 16;
+      const unsigned* alp = Alo + i * WS2 + 4 * q + kq * MAXK2 * 16;
+#pragma unroll
+      for (int kk = 0; kk < MAXK2; ++kk) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + g * GP_BM * WS2 + 16 * kk);
+          const u32x4 al = *reinterpret_cast<const u32x4*>(alp + g * GP_BM * WS2 + 16 * kk);
+          ag[g] = mfma_h3(ah, al, wh[g][kk], wl[g][kk], ag[g]);
+        }
+      }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        const unsigned* ahp = Ahi + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
-        const unsigned* alp = Alo + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
-        f32x4 ag = {0.f, 0.f, 0.f, 0.f};                               // (per gate block: its segments carry their own scales)
-#pragma unroll
-        for (int kk = 0; kk < MAXK2; ++kk) {
-          const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + 16 * kk);
-          const u32x4 al = *reinterpret_cast<const u32x4*>(alp + 16 * kk);
-          ag = mfma_h3(ah, al, wh[g][kk], wl[g][kk], ag);
-        }
         const float4 ia = *reinterpret_cast<const float4*>(SCA + g * GP_BM + 4 * q);     // rows 4 q + r of the accumulator
-        acc[0] += ag[0] * (ia.x * iw[g]); acc[1] += ag[1] * (ia.y * iw[g]); acc[2] += ag[2] * (ia.z * iw[g]); acc[3] += ag[3] * (ia.w * iw[g]);
+        acc[0] += ag[g][0] * (ia.x * iw[g]); acc[1] += ag[g][1] * (ia.y * iw[g]); acc[2] += ag[g][2] * (ia.z * iw[g]);
+        acc[3] += ag[g][3] * (ia.w * iw[g]);
       }
       GRU_STAMP(3);
 #pragma unroll

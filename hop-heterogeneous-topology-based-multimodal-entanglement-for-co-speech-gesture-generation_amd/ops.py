@@ -422,18 +422,39 @@ def _take_rs(t, M):
     return sc
 
 
-RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"     # row scales from the producing kernels (0: always a pass of their own)
+def _attach_img(t, img, sc):
+    """Remember the fp16 hi / lo operand image `img` ([2][M][K] halves as bytes) and its row scales `sc` of tensor `t` ON the tensor
+    object (as _attach_rs does for the scales alone): the LayerNorm kernels write it beside `t`, the GEMM that consumes `t` asks
+    `_take_img` and runs the LDS-DMA form (hopmi_gemm_f16x2_ab_ep)."""
+    t._hopmi_img = (img, sc, t.data_ptr(), t._version)
+    _attach_rs(t, sc)
+
+
+def _take_img(t, M, K):
+    hit = getattr(t, "_hopmi_img", None)
+    if hit is None or not IMG_FUSED:
+        return None
+    img, sc, ptr, ver = hit
+    if ptr != t.data_ptr() or ver != t._version or img.numel() != 4 * M * K or tuple(sc.shape) != (2, M) or img.device != t.device:
+        return None
+    return img, sc
+
+
+RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"
+# the LayerNorm operators also write the fp16 hi/lo image of what they hand to the next GEMM (A/B: HOPMI_IMG_FUSED=0)
+IMG_FUSED = __import__("os").environ.get("HOPMI_IMG_FUSED", "1") != "0"
+IMG_MIN_ROWS = 1024     # row scales from the producing kernels (0: always a pass of their own)
 # the LDS-DMA form of the fp16 GEMM (_split_gemm_ep): faster back to back (24 vs 30 us, 71 vs 92), bit-identical -- and no gain in
 # the step (15.96 vs 15.96 ms, A/B twice on one box: the image pass it needs costs what the k-loop split it saves did), so off
 GEMM_AB = __import__("os").environ.get("HOPMI_GEMM_AB", "0") == "1"
 GEMM_AB_MAX_N = 1024
 
 
-def _split_gemm(a2d, img, bias, N, K, parts, a_part=None, out=None):
+def _split_gemm(a2d, img, bias, N, K, parts, a_part=None, out=None, a_img=None):
     """`a_part` (fp16 form): the A operand's [2][M] row-scale pairs, or a ([P][M] partial row maxima, P) pair as a producing GEMM's
-    `rowmax` left them; None: a hopmi_row_scales pass."""
+    `rowmax` left them; None: a hopmi_row_scales pass.  `a_img`: (image, scales) of a2d as `_take_img` returns them."""
     if parts == F16_PARTS:
-        return _split_gemm_ep(a2d, img, bias, N, K, parts, 0, a_part=a_part, out=out)[0]
+        return _split_gemm_ep(a2d, img, bias, N, K, parts, 0, a_part=a_part, out=out, a_img=a_img)[0]
     if out is not None:
         raise _lib.HopmiError("hopmi _split_gemm: `out` is for the fp16 form")
     M = a2d.shape[0]
@@ -472,7 +493,8 @@ class _SplitLinearFn(torch.autograd.Function):
     def forward(ctx, x, img_w, img_wt, bias, N, K, parts):
         x = _dev_f32(x, "x")
         rs = _take_rs(x, x.numel() // K) if parts == F16_PARTS else None
-        y = _split_gemm(x.reshape(-1, K), img_w, None if bias is None else _dev_f32(bias.detach(), "bias"), N, K, parts, a_part=rs)
+        ai = _take_img(x, x.numel() // K, K) if parts == F16_PARTS else None
+        y = _split_gemm(x.reshape(-1, K), img_w, None if bias is None else _dev_f32(bias.detach(), "bias"), N, K, parts, a_part=rs, a_img=ai)
         ctx.img_wt, ctx.N, ctx.K, ctx.parts = img_wt, N, K, parts
         return y.view(*x.shape[:-1], N)
 
@@ -481,7 +503,8 @@ class _SplitLinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         dy = _dev_f32(dy, "dy")
         rs = _take_rs(dy, dy.numel() // ctx.N) if ctx.parts == F16_PARTS else None
-        dx = _split_gemm(dy.reshape(-1, ctx.N), ctx.img_wt, None, ctx.K, ctx.N, ctx.parts, a_part=rs)      # dX = dY . W = dY . (W^T)^T
+        ai = _take_img(dy, dy.numel() // ctx.N, ctx.N) if ctx.parts == F16_PARTS else None
+        dx = _split_gemm(dy.reshape(-1, ctx.N), ctx.img_wt, None, ctx.K, ctx.N, ctx.parts, a_part=rs, a_img=ai)      # dX = dY . W = dY . (W^T)^T
         return dx.view(*dy.shape[:-1], ctx.K), None, None, None, None, None, None
 
 
@@ -489,7 +512,7 @@ def split_linear(x, img_w, img_wt, bias, N, K, parts):
     return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
 
 
-def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None, rowmax=None):
+def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None, rowmax=None, a_img=None):
     """hopmi_gemm_split_ep / hopmi_gemm_f16x2: epilogue 0 -> a2d W^T + bias; 1 -> (gelu(h), h if keep else None) with
     h = a2d W^T + bias; 2 -> (a2d W^T) * gelu'(aux).  `a_part`: the fp16 form's per-row scales of a2d (row_scales) when the caller has them."""
     M = a2d.shape[0]
@@ -499,6 +522,17 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
         raise _lib.HopmiError(f"hopmi _split_gemm: `out` must be a contiguous float32 ({M}, {N}) tensor on {a2d.device}")
     h = torch.empty_like(out) if (epilogue == 1 and keep) else None
     L = _lib.lib()
+    if parts == F16_PARTS and a_img is not None and K % 32 == 0:
+        # the producer (a LayerNorm kernel) wrote the operand's image: both operands by LDS-DMA, nothing split in the k-loop
+        img_a, sc = a_img
+        cm = torch.empty(L.hopmi_gemm_f16x2_tiles_n(N), M, dtype=torch.float32, device=a2d.device) if rowmax is not None else None
+        _lib.check(_timed("gemm_split", 4 * (M * K + (3 if (h is not None or aux is not None) else 2) * M * N) + 4 * N * K, 2 * M * N * K,
+                          lambda: L.hopmi_gemm_f16x2_ab_ep(img_a.data_ptr(), sc.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h),
+                                                           _ptr(aux), _ptr(cm), M, N, K, epilogue, _stream())),
+                   "hopmi_gemm_f16x2_ab_ep")
+        if rowmax is not None:
+            rowmax.append((cm, cm.shape[0]))
+        return out, h
     if parts == F16_PARTS:
         if (a_part is None and GEMM_AB and epilogue == 0 and rowmax is None and N <= GEMM_AB_MAX_N and K % 32 == 0
                 and M >= F16_LINEAR_MIN_ROWS):
@@ -514,6 +548,7 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
             return out, None
         if a_part is None:
             a_part = row_scales(a2d)
+            _attach_rs(a2d, a_part)                    # (a later consumer of the same tensor object -- the weight-gradient GEMM -- takes them)
         a_t, a_p = a_part if isinstance(a_part, tuple) else (a_part, 0)
         if tuple(a_t.shape) != ((a_p, M) if a_p else (2, M)) or a_t.dtype != torch.float32 or not a_t.is_contiguous():
             raise _lib.HopmiError(f"hopmi _split_gemm: bad operand-scale tensor {tuple(a_t.shape)} for M = {M}, parts = {a_p}")
@@ -544,9 +579,10 @@ class _SplitFfnFn(torch.autograd.Function):
     def forward(ctx, x, img1, img1t, b1, img2, img2t, N1, K, parts):
         x = _dev_f32(x, "x")
         rs = _take_rs(x, x.numel() // K) if parts == F16_PARTS else None
+        ai = _take_img(x, x.numel() // K, K) if parts == F16_PARTS else None
         fmax = [] if (parts == F16_PARTS and RS_FUSED) else None           # the GELU epilogue leaves its output's row maxima
         f, h = _split_gemm_ep(x.reshape(-1, K), img1, _dev_f32(b1.detach(), "bias"), N1, K, parts, 1, keep=ctx.needs_input_grad[0], a_part=rs,
-                              rowmax=fmax)
+                              rowmax=fmax, a_img=ai)
         o = _split_gemm(f, img2, None, K, N1, parts, a_part=fmax[0] if fmax else None)
         ctx.save_for_backward(h)
         ctx.imgs, ctx.dims = (img1t, img2t), (N1, K, parts)
@@ -560,8 +596,9 @@ class _SplitFfnFn(torch.autograd.Function):
         N1, K, parts = ctx.dims
         do = _dev_f32(do, "do")
         rs = _take_rs(do, do.numel() // K) if parts == F16_PARTS else None
+        ai = _take_img(do, do.numel() // K, K) if parts == F16_PARTS else None
         dmax = [] if (parts == F16_PARTS and RS_FUSED) else None
-        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h, a_part=rs, rowmax=dmax)   # (dO W2) * gelu'(h)
+        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h, a_part=rs, rowmax=dmax, a_img=ai)   # (dO W2) * gelu'(h)
         dx = _split_gemm(dh, img1t, None, K, N1, parts, a_part=dmax[0] if dmax else None)                         # dH W1
         return dx.view(*do.shape), None, None, None, None, None, None, None, None
 
@@ -671,10 +708,14 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         # the fp16-form GEMMs behind this operator take their A operand's row scales from here (the rows are in registers)
         ctx.rs = RS_FUSED and GEMM_PARTS == F16_PARTS
         sc = torch.empty(2, M, dtype=torch.float32, device=x.device) if ctx.rs else None
+        # ... and, where the LDS-DMA form of that GEMM pays (enough rows, whole 32-wide k-steps), the operand's image itself
+        ctx.im = bool(ctx.rs and IMG_FUSED and D % 32 == 0 and M >= IMG_MIN_ROWS)
+        im = torch.empty(4 * M * D, dtype=torch.uint8, device=x.device) if ctx.im else None
         _lib.check(_timed("bias_drop_res_ln_fwd", 4 * x.numel() * (4 if need else 3), 0,
-                          lambda: L.hopmi_bias_dropout_residual_layernorm_fwd_rs(
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_fwd_im(
                               x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
-                              out.data_ptr(), None, _ptr(xhat), _ptr(rstd), _ptr(sc), M, D, float(eps), float(p_drop), int(seed) & _M32, sp, 0, st)),
+                              out.data_ptr(), None, _ptr(xhat), _ptr(rstd), _ptr(sc), _ptr(im), M, D, float(eps), float(p_drop),
+                              int(seed) & _M32, sp, 0, st)),
                    "hopmi_bias_dropout_residual_layernorm_fwd")
         if need:
             ctx.save_for_backward(xhat, rstd, gamma)
@@ -682,11 +723,13 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if sc is not None:
             ctx.mark_non_differentiable(sc)
-        return out, out.detach(), sc
+        if im is not None:
+            ctx.mark_non_differentiable(im)
+        return out, out.detach(), sc, im
 
     @staticmethod
     @_bwd32
-    def backward(ctx, dout, dout2, _dsc=None):
+    def backward(ctx, dout, dout2, _dsc=None, _dim=None):
         xhat, rstd, gamma = ctx.saved_tensors
         if dout is None:
             dout, dout2 = dout2, None
@@ -699,12 +742,15 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         dx, dres = torch.empty_like(xhat), torch.empty_like(xhat)
         L, st = _lib.lib(), _stream()
         sc = torch.empty(2, M, dtype=torch.float32, device=dx.device) if ctx.rs else None      # dx feeds the backward's next GEMM
+        im = torch.empty(4 * M * D, dtype=torch.uint8, device=dx.device) if ctx.im else None
         _lib.check(_timed("bias_drop_res_ln_bwd", (16 if d2 is None else 20) * xhat.numel(), 0,
-                          lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_rs(
+                          lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_im(
                               dout.data_ptr(), _ptr(d2), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                              dres.data_ptr(), _ptr(sc), M, D, ctx.p_drop, ctx.seed, ctx.sp, 0, st)),
+                              dres.data_ptr(), _ptr(sc), _ptr(im), M, D, ctx.p_drop, ctx.seed, ctx.sp, 0, st)),
                    "hopmi_bias_dropout_residual_layernorm_bwd_dt")
-        if sc is not None:
+        if im is not None:
+            _attach_img(dx, im, sc)
+        elif sc is not None:
             _attach_rs(dx, sc)
         if tuple(ctx.res_shape) != tuple(dres.shape):            # broadcast residual (e.g. position embeddings)
             dres = dres.view(-1, *ctx.res_shape).sum(0)
@@ -713,8 +759,10 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
 
 def bias_dropout_residual_layernorm2(x, bias, res, gamma, beta, eps, p_drop=0.0, seed=0):
     """(out, out again on the same storage): see _BiasDropResLn2Fn."""
-    out, out2, sc = _BiasDropResLn2Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
-    if sc is not None:
+    out, out2, sc, im = _BiasDropResLn2Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
+    if im is not None:
+        _attach_img(out, im, sc)
+    elif sc is not None:
         _attach_rs(out, sc)
     return out, out2
 
@@ -943,33 +991,96 @@ def f16_mm_nt(a2d, w, owners, out=None):
 
 F16_LINEAR_MIN_ROWS = 1024          # below: the 128-row tiles leave the chip empty
 
+# dW = dY^T X on hopmi_gemm_f16x2_tn (csrc/gemm_tn.hip) instead of the library's fp32 GEMM: from M N K = 2e9 on (below, the row-scale
+# passes and the slab sum eat the gain)
+F16_TN = __import__("os").environ.get("HOPMI_F16_TN", "1") != "0"
+F16_TN_MIN_MNK = 2.0e9
+_UNIT_RS = {}                       # (device, M) -> [2][M] row-scale pairs {2^14, 2^-14}: operands bounded by 1 (GRU states)
+
+
+def unit_row_scales(M, device):
+    """The row-scale pairs of an operand whose magnitudes are bounded by 1 (no pass over it): s = 2^14 for every row."""
+    key = (str(device), M)
+    t = _UNIT_RS.get(key)
+    if t is None or (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+        t = torch.empty(2, M, dtype=torch.float32, device=device)
+        t[0].fill_(16384.0)
+        t[1].fill_(1.0 / 16384.0)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _UNIT_RS[key] = t
+    return t
+
+
+def f16_mm_tn_ok(a, b) -> bool:
+    """Does the weight gradient a^T b (a: (.., M, N), b: (.., M, K), rows strided or not) go to hopmi_gemm_f16x2_tn?"""
+    return bool(F16_TN and GEMM_PARTS == F16_PARTS and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+                and not torch.is_autocast_enabled("cuda") and a.stride(-1) == 1 and b.stride(-1) == 1
+                and float(a.shape[-2]) * a.shape[-1] * b.shape[-1] * (a.shape[0] if a.dim() == 3 else 1) >= F16_TN_MIN_MNK)
+
+
+def f16_mm_tn(a, b, a_rs, b_rs, out=None, accumulate=False):
+    """a^T b on hopmi_gemm_f16x2_tn (no autograd): a (M, N) and b (M, K) fp32, unit stride along the last axis, any row stride; or
+    (batch, M, N) / (batch, M, K) with one batch stride each.  a_rs / b_rs: the operands' [2][M] row-scale pairs (row_scales,
+    _take_rs, unit_row_scales; shared by the batch members).  Returns (N, K) or (batch, N, K)."""
+    batched = a.dim() == 3
+    bt = a.shape[0] if batched else 1
+    M, N = a.shape[-2:]
+    K = b.shape[-1]
+    if b.shape[-2] != M or (batched and b.shape[0] != bt) or a.stride(-1) != 1 or b.stride(-1) != 1:
+        raise _lib.HopmiError(f"hopmi f16_mm_tn: bad operands {tuple(a.shape)} / {tuple(b.shape)}")
+    for t, nm in ((a_rs, "a_rs"), (b_rs, "b_rs")):
+        if tuple(t.shape) != (2, M) or t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.HopmiError(f"hopmi f16_mm_tn: {nm} must be a contiguous float32 (2, {M}) tensor")
+    if out is None:
+        out = torch.empty((bt, N, K) if batched else (N, K), dtype=torch.float32, device=a.device)
+        accumulate = False
+    elif out.dtype != torch.float32 or out.stride(-1) != 1 or tuple(out.shape) != ((bt, N, K) if batched else (N, K)):
+        raise _lib.HopmiError("hopmi f16_mm_tn: bad `out`")
+    L = _lib.lib()
+    nws = L.hopmi_gemm_f16x2_tn_ws_floats(M, N, K, bt)
+    ws = torch.empty(nws, dtype=torch.float32, device=a.device) if nws else None
+    _lib.check(_timed("gemm_tn", 4 * bt * (M * N + M * K + N * K), 2 * bt * M * N * K,
+                      lambda: L.hopmi_gemm_f16x2_tn(a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, a_rs.data_ptr(),
+                                                    b.data_ptr(), b.stride(-2), b.stride(0) if batched else 0, b_rs.data_ptr(),
+                                                    out.data_ptr(), out.stride(-2), out.stride(0) if batched else 0, _ptr(ws), M, N, K, bt,
+                                                    1 if accumulate else 0, _stream())),
+               "hopmi_gemm_f16x2_tn")
+    return out
+
+
 
 class _F16LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, owners):
         N, K = w.shape
         x2 = _dev_f32(x.detach(), "x").reshape(-1, K)
+        xs = _take_rs(x, x2.shape[0])
+        if xs is None:
+            xs = row_scales(x2)                        # (kept: the weight gradient takes its operand scale from them)
         y = _split_gemm(x2, f16_weight_image(w, owners=owners), None if b is None else _dev_f32(b.detach(), "bias"), N, K, F16_PARTS,
-                        a_part=_take_rs(x, x2.shape[0]))
-        ctx.save_for_backward(x2, w)
+                        a_part=xs)
+        ctx.save_for_backward(x2, w, xs)
         ctx.x_shape, ctx.has_b, ctx.owners = x.shape, b is not None, owners
         return torch.ops.aten._unsafe_view(y, list(x.shape[:-1]) + [N])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
+        x2, w, xs = ctx.saved_tensors
         N, K = w.shape
         dy2 = _dev_f32(dy, "dy").reshape(-1, N)
         dx = dw = db = None
+        tn = ctx.needs_input_grad[1] and f16_mm_tn_ok(dy2, x2)
+        ds = _take_rs(dy, dy2.shape[0])
+        if ds is None and (tn or (ctx.needs_input_grad[0] and N % 4 == 0 and K >= 128)) and N % 4 == 0:
+            ds = row_scales(dy2)                       # one pass serves both gradient products
         if ctx.needs_input_grad[0]:
             if N % 4 == 0 and K >= 128:                  # (dX contracts over N: the kernel's K % 4 == 0 rule applies to it here)
-                dx = _split_gemm(dy2, f16_weight_image(w, transpose=True, owners=ctx.owners), None, K, N, F16_PARTS,
-                                 a_part=_take_rs(dy, dy2.shape[0]))
+                dx = _split_gemm(dy2, f16_weight_image(w, transpose=True, owners=ctx.owners), None, K, N, F16_PARTS, a_part=ds)
             else:
                 dx = dy2 @ w
             dx = dx.view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
-            dw = dy2.t() @ x2
+            dw = f16_mm_tn(dy2, x2, ds, xs) if (tn and ds is not None) else dy2.t() @ x2
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = colsum(dy2)
         return dx, dw, db, None
@@ -1699,7 +1810,13 @@ class _GruLayerFn(torch.autograd.Function):
             # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
             if not want_dw:                    # (frozen recurrent weights, e.g. the discriminator inside the generator's step)
                 return dgi, None, None
-            dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
+            M = B * T
+            dgh2, hp2 = dgh.view(M, 2, 3 * H).transpose(0, 1), hprev.view(M, 2, H).transpose(0, 1)       # (2, M, 3H) / (2, M, H) views
+            if f16_mm_tn_ok(dgh2, hp2) and (6 * H) % 4 == 0:
+                # the states are bounded by 1: a constant scale; dgh: one pass over the (M, 6H) rows, shared by the two directions
+                dwhh = f16_mm_tn(dgh2, hp2, row_scales(dgh.view(M, 6 * H)), unit_row_scales(M, y.device))
+            else:
+                dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
             dbhh = colsum(dgh.view(B * T, 6 * H)).view(2, 3 * H)
         return dgi, dwhh, dbhh
 

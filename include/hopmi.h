@@ -319,6 +319,17 @@ int hopmi_bias_dropout_residual_layernorm_fwd_rs(const void* x, const float* bia
 int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
                                                  const float* gamma, void* dx, float* dres, float* row_scales, int M, int D, float p_drop,
                                                  unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
+/* ... and (round 5) the operand IMAGE itself: `image` (nullable; needs row_scales) receives `out` / `dx` times the row's power of two
+ * as fp16 hi / lo images [2][M][D] -- hopmi_rows_image_f16's layout, the A operand of hopmi_gemm_f16x2_ab(_ep): the GEMM behind the
+ * LayerNorm (QKV, FFN-in; in the backward the attention-output and FFN-out gradients) then stages both operands by LDS-DMA and
+ * splits nothing in its k-loop (69 vs 84 us at N = 2304, 84 vs 103 at N = 3072, M = 4352). */
+int hopmi_bias_dropout_residual_layernorm_fwd_im(const void* x, const float* bias, const float* res, int res_rows,
+                                                 const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
+                                                 float* rstd, float* row_scales, void* image, int M, int D, float eps, float p_drop,
+                                                 unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
+int hopmi_bias_dropout_residual_layernorm_bwd_im(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                 const float* gamma, void* dx, float* dres, float* row_scales, void* image, int M, int D,
+                                                 float p_drop, unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
 int hopmi_bert_attn_fwd_dt(const void* qkv, void* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev,
                            int dtype, void* stream);
 int hopmi_bert_attn_bwd_dt(const void* qkv, const void* d_out, void* dqkv, int B, int L, int H, float p_drop, unsigned seed,
@@ -449,6 +460,22 @@ int hopmi_gemm_f16x2(const float* A, const float* a_scales, int a_parts, const v
 int hopmi_rows_image_f16(const float* A, int M, int K, void* image, float* scales, void* stream);
 int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M, int N,
                         int K, void* stream);
+/* ... with hopmi_gemm_f16x2's epilogues (0 bias, 1 GELU (+ C2 = the pre-activation), 2 GELU gradient against aux) and c_rowmax. */
+int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
+                           const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream);
+
+/* The weight gradient of a linear layer in the same arithmetic (round 5; csrc/gemm_tn.hip):  C[N][K] (+)= A[M][N]^T . B[M][K]  -- both
+ * operands ACTIVATIONS (A = dY, B = X, row-major with leading dimensions lda / ldb), contraction over their M rows; `batch`
+ * independent products at element strides batch_stride_* (the two directions of a GRU's recurrent gradient, HOP.py:166-167).
+ * a_rows / b_rows: the operands' [2][M] row-scale pairs as hopmi_row_scales (or a fused producer) writes them -- the kernel takes the
+ * smallest row scale of each as the operand's ONE power-of-two scale (rows are the contraction index here).  Shapes with few output
+ * tiles split their rows over workgroups: `ws` = hopmi_gemm_f16x2_tn_ws_floats(M, N, K, batch) floats (0: not needed), summed in
+ * index order by a second launch (bitwise reproducible).  accumulate != 0: C += .
+ * Replaces: dW = dY^T X of every nn.Linear / nn.GRU weight of the generator (autograd of HOP.py:116-134,166-167,259-265). */
+size_t hopmi_gemm_f16x2_tn_ws_floats(int M, int N, int K, int batch);
+int hopmi_gemm_f16x2_tn(const float* A, int lda, long long batch_stride_a, const float* a_rows, const float* B, int ldb,
+                        long long batch_stride_b, const float* b_rows, float* C, int ldc, long long batch_stride_c, float* ws, int M, int N,
+                        int K, int batch, int accumulate, void* stream);
 
 /* The same product with BOTH operands as part images (Aimage = hopmi_gemm_split_prepare(A, M, K, parts, ...), i.e.
  * [parts][M][K] bf16; a producer may also write that layout itself): nothing is split inside the kernel, every tile is staged

@@ -1855,6 +1855,114 @@ def test_split_ffn_equals_unfused_composition(M, parts):
     assert rel_err(xa.grad.double(), xd.grad) <= tol
 
 
+def test_layernorm_operand_images_feed_the_lds_dma_gemm(monkeypatch):
+    """Round 5: the bias + dropout + residual + LayerNorm kernels also write the fp16 hi / lo IMAGE of what they hand to the next
+    GEMM (forward: their output; backward: dx), and that GEMM runs as hopmi_gemm_f16x2_ab_ep -- both operands staged by LDS-DMA,
+    nothing split in the k-loop.  Checked at the encoder's row count: the attached image equals hopmi_rows_image_f16 of the tensor
+    bit for bit; the products (plain, GELU epilogue with the kept pre-activation, GELU-gradient epilogue) and the gradient equal
+    the split form's bit for bit (HOPMI_IMG_FUSED off); a modified tensor's stale image is refused."""
+    from hopmi import ops, _lib
+    dev = _dev()
+    monkeypatch.setattr(ops, "GEMM_PARTS", 16)
+    g = torch.Generator().manual_seed(12)
+    M, D, N = 1088, 768, 2304
+    x = torch.randn(M, D, generator=g).to(dev)
+    res = torch.randn(M, D, generator=g).to(dev)
+    bias, gamma, beta = (torch.randn(D, generator=g).to(dev) for _ in range(3))
+    w = (torch.randn(N, D, generator=g) / D ** 0.5).to(dev)
+    w1 = (torch.randn(3072, D, generator=g) / D ** 0.5).to(dev)
+    w2 = (torch.randn(D, 3072, generator=g) / 3072 ** 0.5).to(dev)
+    b1 = torch.randn(3072, generator=g).to(dev)
+    img, imgt = ops.split_weight_image(w, 16), ops.split_weight_image(w.t().contiguous(), 16)
+    i1, i1t = ops.split_weight_image(w1, 16), ops.split_weight_image(w1.t().contiguous(), 16)
+    i2, i2t = ops.split_weight_image(w2, 16), ops.split_weight_image(w2.t().contiguous(), 16)
+    gy = (torch.randn(M, N, generator=g) * 1e-3).to(dev)
+    go = (torch.randn(M, D, generator=g) * 1e-3).to(dev)
+    L = _lib.lib()
+
+    def rows_image(t):
+        im = torch.empty(4 * M * D, dtype=torch.uint8, device=dev)
+        sc = torch.empty(2, M, dtype=torch.float32, device=dev)
+        _lib.check(L.hopmi_rows_image_f16(t.data_ptr(), M, D, im.data_ptr(), sc.data_ptr(), torch.cuda.current_stream().cuda_stream), "rows_image")
+        return im, sc
+
+    def run(fused):
+        monkeypatch.setattr(ops, "IMG_FUSED", fused)
+        seen = []
+        xx = x.detach().clone().requires_grad_()
+        xx.register_hook(lambda gr: seen.append(gr))
+        h, hr = ops.bias_dropout_residual_layernorm2(xx, bias, res, gamma, beta, 1e-12, 0.1, 77)
+        att = ops._take_img(h, M, D)
+        y = ops.split_linear(h, img, imgt, None, N, D, 16)                                       # QKV-shaped product
+        (y * gy).sum().backward()
+        h2, _ = ops.bias_dropout_residual_layernorm2(x.detach().clone().requires_grad_(), bias, res, gamma, beta, 1e-12, 0.0, 5)
+        f = ops.split_ffn(h2, i1, i1t, b1, i2, i2t, 3072, D, 16)                                 # GELU epilogue behind the image
+        f2, hr2 = ops.bias_dropout_residual_layernorm2(f, bias, h2, gamma, beta, 1e-12, 0.0, 6)  # its backward's dx feeds the GELU-gradient product
+        (f2 * go).sum().backward()
+        return h.detach(), att, y.detach(), xx.grad.clone(), seen[0], f.detach()
+
+    h1, att1, y1, gx1, dx1, f1 = run(True)
+    assert att1 is not None
+    im_ref, sc_ref = rows_image(h1)
+    assert torch.equal(att1[0], im_ref) and torch.equal(att1[1], sc_ref)
+    got = ops._take_img(dx1, M, D)
+    assert got is not None
+    im_ref, sc_ref = rows_image(dx1.contiguous())
+    assert torch.equal(got[0], im_ref) and torch.equal(got[1], sc_ref)
+    h0, att0, y0, gx0, dx0, f0 = run(False)
+    assert att0 is None
+    assert torch.equal(h1, h0) and torch.equal(y1, y0) and torch.equal(gx1, gx0) and torch.equal(f1, f0)
+    h1.add_(1.0)
+    assert ops._take_img(h1, M, D) is None
+
+
+@pytest.mark.parametrize("M,N,K", [(4352, 2100, 992), (4352, 768, 1536), (2048, 1700, 3400), (1000, 130, 70), (33, 5, 260)])
+def test_gemm_f16x2_tn_vs_float64(M, N, K):
+    """hopmi_gemm_f16x2_tn: dW = dY^T X (both operands activations, contraction over the rows; csrc/gemm_tn.hip) at the generator's
+    weight-gradient shapes (GRU input projection, align layer, beat MLP) and at ragged ones (no extent a multiple of the tile, M not a
+    multiple of the 32-row step): fp32-equivalent -- error against float64 within 3 x the library fp32 GEMM's, the bound the NT form
+    is held to -- with gradient rows of very different magnitude (1e-6 ... 1e2) and rows of zeros in dY; `accumulate`; run-to-run
+    bitwise reproducible (the row split's slabs are added in index order)."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randn(M, N, generator=g) * torch.logspace(-6, 2, M).unsqueeze(1)
+    dy[::7] = 0.0
+    x = torch.randn(M, K, generator=g)
+    ref = dy.double().t() @ x.double()
+    lib = (dy.to(dev).t() @ x.to(dev)).cpu()
+    dyd, xd = dy.to(dev), x.to(dev)
+    pad = lambda t: torch.nn.functional.pad(t, (0, (-t.shape[1]) % 4))            # (hopmi_row_scales wants K % 4 == 0: zero columns)
+    a_rs, b_rs = ops.row_scales(pad(dyd).contiguous()), ops.row_scales(pad(xd).contiguous())
+    out = ops.f16_mm_tn(dyd, xd, a_rs, b_rs)
+    out2 = ops.f16_mm_tn(dyd, xd, a_rs, b_rs)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    e_lib, e = rel_err(lib.double(), ref), rel_err(out.cpu().double(), ref)
+    assert e <= 3.0 * e_lib + 1.2e-7, f"TN GEMM: error vs float64 {e:.3e} > 3 x the library's {e_lib:.3e}"
+    acc = out.clone()
+    ops.f16_mm_tn(dyd, xd, a_rs, b_rs, out=acc, accumulate=True)
+    assert rel_err(acc.cpu().double(), 2 * ref) <= 3.0 * e_lib + 2.4e-7
+
+
+def test_gemm_f16x2_tn_batched_strided_views():
+    """The GRU's recurrent weight gradient as ops._GruLayerFn issues it: both directions in one call on strided views of dgh
+    (B T, 2, 3H) and of the shifted states (B T, 2, H), the states' scale a constant (|h| <= 1)."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    M, H = 4352, 350
+    dgh = (torch.randn(M, 2, 3 * H, generator=g) * 1e-3).to(dev)
+    hp = torch.tanh(torch.randn(M, 2, H, generator=g)).to(dev)
+    a, b = dgh.transpose(0, 1), hp.transpose(0, 1)
+    assert ops.f16_mm_tn_ok(a, b)
+    got = ops.f16_mm_tn(a, b, ops.row_scales(dgh.view(M, 6 * H)), ops.unit_row_scales(M, dev))
+    ref = torch.einsum("mdg,mdh->dgh", dgh.double(), hp.double())
+    lib = torch.einsum("mdg,mdh->dgh", dgh, hp)
+    e_lib, e = rel_err(lib.double(), ref), rel_err(got.double(), ref)
+    assert e <= 3.0 * e_lib + 1.2e-7, (e, e_lib)
+
+
 # ---- the three-term fp16 hi/lo kernels against float64, next to plain fp32 torch ----------------------------------------------
 # Since round 5 every hand-written contraction of the hot path carries its operands as two power-of-two-scaled fp16 numbers (hi + lo,
 # 22 significand bits; csrc/f16_dev.h) and sums three MFMA terms with fp32 accumulation: a product is good to a few 2^-23, i.e. at

@@ -57,4 +57,12 @@ for tag in (sys.argv[1:] or ["ted", "expr"]):
             t_dx = timed(lambda: ops._split_gemm(gy, imgt, None, K, N, 16, a_part=scg))
             t_imgt = timed(lambda: ops.f16_weight_image(w, transpose=True))
             line += f" | dX lib {t_libdx:6.1f} err {rel(gy @ w, refdx):.1e} | f16x2 {t_dx:6.1f} (image^T {t_imgt:4.1f}) err {rel(dx, refdx):.1e}"
+        # the weight gradient dW = dY^T X: library vs hopmi_gemm_f16x2_tn (the row scales of gy / x are at hand from the products above)
+        refdw = gy.double().t() @ x.double()
+        t_libdw = timed(lambda: gy.t() @ x)
+        if N % 4 == 0 and K % 4 == 0:
+            scg = ops.row_scales(gy)
+            dw = ops.f16_mm_tn(gy, x, scg, sc)
+            t_dw = timed(lambda: ops.f16_mm_tn(gy, x, scg, sc))
+            line += f" | dW lib {t_libdw:6.1f} err {rel(gy.t() @ x, refdw):.1e} | f16x2_tn {t_dw:6.1f} err {rel(dw, refdw):.1e}"
         print(line, flush=True)
