@@ -329,9 +329,10 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
 //     f16_dev.h: 22 significand bits per operand, fp32 accumulation -- fp32-equivalent; rounds 2-4: bf16 pairs, 2^-16): 27 MFMAs
 //     of 16 cycles per wave and step instead of the 72 exact-fp32 MFMAs of 32 cycles that were 32 % of a step
 //     (tools/probes/gru_stamps.py).  Scales (powers of two): the recurrent weights one per (gate, unit) row, found once at kernel
-//     start (lane maximum -> the row's 4 lanes -> the 4 K-quarter waves through LDS); the state h, bounded by 1: 2^14; in the
-//     backward the handed-off dgh rows one per (gate block, batch row) segment from the maximum of the segment as its staging wave
-//     loaded it, with one accumulator per gate block so that segments of different scale never meet before the epilogue.
+//     start (lane maximum -> the row's 4 lanes -> the 4 K-quarter waves through LDS; the backward: one per unit over the three
+//     gate blocks it contracts over); the state h, bounded by 1: 2^14; in the backward the handed-off dgh rows one per staging
+//     wave (its two batch rows x three gate blocks) from the maximum of what the wave loaded: a row's scale is the same in
+//     all gate blocks, so it leaves per accumulator row in the epilogue.
 //   * Hand-off without counters: the hand-off array is filled with a NaN bit pattern no computation produces before the
 //     kernel starts; a producer simply stores its values (sc1: write-through), a consumer loads the rows it needs with sc1
 //     loads (never served from a stale cache) and re-loads whatever still reads as the pattern.  One memory round trip
@@ -474,7 +475,8 @@ __device__ __forceinline__ Split8 load_w_frag(const float* row, int k0, int K, f
 // one power of two per (gate, unit) ROW: the row's maximum is taken over this lane's elements, its 4 lanes (q) and the 4 K-quarter
 // waves of the unit half (through `xch`: [8 waves][3][16] floats of LDS, two barriers; every lane ends with its row's scale).
 // `wrow(g)`: the row of gate g.  Returns the inverse scales in inv[3].
-template <int MAXK2, typename RowOf>
+// JOINT: one scale per unit over all three gate blocks (the backward contracts over them into ONE accumulator).
+template <int MAXK2, bool JOINT = false, typename RowOf>
 __device__ __forceinline__ void load_resident_w(u32x4 (&wh)[3][MAXK2], u32x4 (&wl)[3][MAXK2], float (&inv)[3], RowOf wrow, int H, int kq,
                                                 int ch, int q, int i, int w, float* xch) {
   // ONE pass over the rows (a lane's loads are row-strided: 64 cache lines per wave instruction -- the second pass of the first
@@ -496,11 +498,20 @@ __device__ __forceinline__ void load_resident_w(u32x4 (&wh)[3][MAXK2], u32x4 (&w
     if (q == 0) xch[(w * 3 + g) * 16 + i] = mm;
   }
   __syncthreads();
+  float mj = 0.f;
+  if (JOINT) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) mj = fmaxf(mj, xch[((ch * 4 + k2) * 3 + g) * 16 + i]);
+  }
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
-    float mm = m[g];
+    float mm = JOINT ? mj : m[g];
+    if (!JOINT) {
 #pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) mm = fmaxf(mm, xch[((ch * 4 + k2) * 3 + g) * 16 + i]);
+      for (int k2 = 0; k2 < 4; ++k2) mm = fmaxf(mm, xch[((ch * 4 + k2) * 3 + g) * 16 + i]);
+    }
     const float sc = scale_for_absmax(mm);
     inv[g] = inv_pow2(sc);
 #pragma unroll
@@ -738,7 +749,7 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
   unsigned* Ahi = reinterpret_cast<unsigned*>(smem);                   // [3 gate blocks][16][WS2]  dgh rows, hi parts
   unsigned* Alo = Ahi + 3 * GP_BM * WS2;
   float* red = reinterpret_cast<float*>(Alo + 3 * GP_BM * WS2);        // [4 K quarters][16][GP_RED_B]
-  float* SCA = red + 4 * GP_BM * GP_RED_B;                             // [3 gate blocks][16] inverse scale of the staged dgh segment
+  float* SCA = red + 4 * GP_BM * GP_RED_B;                             // [16] inverse scale of the staged dgh rows (rows w, w + 8: wave w's)
   const GpWork wk = gp_decode(nJ, nbb);
   if (!wk.valid) return;
   const int d = wk.d, bb = wk.bb, jb = wk.jb;
@@ -750,11 +761,11 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
   const int row = tid >> 5, b = b0 + row, bc = min(b, B - 1);
 
   u32x4 wh[3][MAXK2], wl[3][MAXK2];
-  float iw[3];                                                         // 1 / s of W_hh^T[unit 16 ch + i][gate block g]: this lane's accumulator column
+  float iw[3];                                                         // 1 / s of W_hh^T[unit 16 ch + i][:] (one scale over the 3 gate blocks: iw[0])
   {
     const int ju = j0 + 16 * ch + i;
-    load_resident_w<MAXK2>(wh, wl, iw, [&](int g) -> const float* { return ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr; },
-                           H, kq, ch, q, i, w, red);
+    load_resident_w<MAXK2, true>(wh, wl, iw, [&](int g) -> const float* { return ju < H ? whhT + ((size_t)d * H + ju) * K + g * H : nullptr; },
+                                 H, kq, ch, q, i, w, red);
   }
   float dhz_own = 0.f;                                                 // D_{p+1} z_{p+1} of this thread's element
   bool dead = false;
@@ -779,39 +790,39 @@ __global__ __launch_bounds__(512) void gru_bwd_persistent_kernel(const float* __
         return br < B ? dgh + (((size_t)br * T + tn) * 2 + d) * K + g * H : nullptr;
       }, H, lane, dead, status);
       GRU_STAMP(1);
-#pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        // one power-of-two scale per staged segment (gate block, batch row): the maximum of what this wave just loaded
+      {
+        // ONE power-of-two scale for the six segments this wave stages (rows w and w + 8 of the three gate blocks): the maximum
+        // of what it just loaded -- one wave reduction per step.  A row's scale is then the same in all three gate blocks, so the
+        // contraction over them stays ONE accumulator chain and the scale leaves in the epilogue per accumulator row.  (A scale per
+        // segment with one accumulator per gate block cost 0.8 us per step: six dependent wave reductions on the critical path
+        // between the hand-off's arrival and the commit.)
         float mm = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXK2; ++c) mm = fmaxf(mm, fmaxf(fabsf(v[m][c].x), fabsf(v[m][c].y)));
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+          for (int c = 0; c < MAXK2; ++c) mm = fmaxf(mm, fmaxf(fabsf(v[m][c].x), fabsf(v[m][c].y)));
         const float sc = scale_for_absmax(wave_max_nonneg(mm));
-        commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane, sc);
-        if (lane == 0) SCA[w + 8 * m] = inv_pow2(sc);                  // (segment index = gate block x 16 + row)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane, sc);
+        if (lane < 2) SCA[w + 8 * lane] = inv_pow2(sc);
       }
       __syncthreads();
       GRU_STAMP(2);
-      // one accumulator per gate block (its segments carry their own scales), the three chains interleaved; combined afterwards
-      f32x4 ag[3];
-#pragma unroll
-      for (int g = 0; g < 3; ++g) ag[g] = {0.f, 0.f, 0.f, 0.f};
-      const unsigned* ahp = Ahi + i * WS2 + 4 * q + kq * MAXK2 * 16;
-      const unsigned* alp = Alo + i * WS2 + 4 * q + kq * MAXK2 * 16;
-#pragma unroll
-      for (int kk = 0; kk < MAXK2; ++kk) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + g * GP_BM * WS2 + 16 * kk);
-          const u32x4 al = *reinterpret_cast<const u32x4*>(alp + g * GP_BM * WS2 + 16 * kk);
-          ag[g] = mfma_h3(ah, al, wh[g][kk], wl[g][kk], ag[g]);
-        }
-      }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        const float4 ia = *reinterpret_cast<const float4*>(SCA + g * GP_BM + 4 * q);     // rows 4 q + r of the accumulator
-        acc[0] += ag[g][0] * (ia.x * iw[g]); acc[1] += ag[g][1] * (ia.y * iw[g]); acc[2] += ag[g][2] * (ia.z * iw[g]);
-        acc[3] += ag[g][3] * (ia.w * iw[g]);
+        const unsigned* ahp = Ahi + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
+        const unsigned* alp = Alo + (g * GP_BM + i) * WS2 + 4 * q + kq * MAXK2 * 16;
+#pragma unroll
+        for (int kk = 0; kk < MAXK2; ++kk) {
+          const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + 16 * kk);
+          const u32x4 al = *reinterpret_cast<const u32x4*>(alp + 16 * kk);
+          acc = mfma_h3(ah, al, wh[g][kk], wl[g][kk], acc);
+        }
+      }
+      {
+        const float4 ia = *reinterpret_cast<const float4*>(SCA + 4 * q);       // rows 4 q + r of the accumulator
+        acc[0] *= ia.x * iw[0]; acc[1] *= ia.y * iw[0]; acc[2] *= ia.z * iw[0]; acc[3] *= ia.w * iw[0];
       }
       GRU_STAMP(3);
 #pragma unroll
@@ -1087,7 +1098,7 @@ static int gru_persistent_capacity(int H) {
       return gru_resident_capacity(reinterpret_cast<const void*>(&gru_fwd_persistent_kernel<MK_, TG>),                        \
                                    (size_t)2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_F * sizeof(float));  \
     return gru_resident_capacity(reinterpret_cast<const void*>(&gru_bwd_persistent_kernel<MK_, TG>),                          \
-                                 (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)(4 * GP_BM * GP_RED_B + 3 * GP_BM) * sizeof(float)); \
+                                 (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)(4 * GP_BM * GP_RED_B + GP_BM) * sizeof(float)); \
   }
   if (mk <= 1) HOPMI_GP_CAP(1)
   if (mk == 2) HOPMI_GP_CAP(2)
@@ -1181,7 +1192,7 @@ static void launch_gru_bwd_persistent(int grid, hipStream_t st, const float* dy,
                                       const float* whhT, TG* dgi, float* dgh, int* status, int B, int T, int H, int nJ,
                                       int nbb) {
   constexpr int WS2 = (128 * MAXK2 + 48) / 2;
-  const size_t lds = (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)(4 * GP_BM * GP_RED_B + 3 * GP_BM) * sizeof(float);
+  const size_t lds = (size_t)2 * 3 * GP_BM * WS2 * sizeof(unsigned) + (size_t)(4 * GP_BM * GP_RED_B + GP_BM) * sizeof(float);
   hipLaunchKernelGGL((gru_bwd_persistent_kernel<MAXK2, TG>), dim3(grid), dim3(512), lds, st, dy, y, gates, whhT, dgi, dgh, status, B,
                      T, H, nJ, nbb);
 }

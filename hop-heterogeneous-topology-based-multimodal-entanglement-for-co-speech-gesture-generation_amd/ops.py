@@ -325,27 +325,34 @@ def cut_point(t):
 
 # ------------------------------------------------------- frozen-weight linears on split-bf16 MFMA (hopmi_gemm_split)
 CAST_CACHE_ENABLED = __import__("os").environ.get("HOPMI_CAST_CACHE", "1") != "0"
-# ---- strict fp32 (A/B switch) ---------------------------------------------------------------------------------------------
-# The default path takes the contractions INSIDE three kernel families as three-term split-bf16 products (~2^-16 per product):
-# the fused WaveNet forward kernels (wn_stack / wn_layer), the reprogramming attention and the persistent GRU recurrences.
-# Everything else is exact fp32 or fp32-equivalent (WaveNet backward and BERT self-attention on the exact-fp32 MFMA, the fp16
-# hi/lo GEMM form, library GEMMs).  `strict_fp32(True)` (or HOPMI_STRICT_FP32=1) routes those three families to their
-# fp32-exact forms that the repository already carries: the WaveNet block as the composition of the graph-conv kernel
-# (exact-fp32 MFMA) with library fp32 GEMMs and torch's BatchNorm (gwnet.forward_cl's composed branch), the GRU recurrences as
-# per-time-step launches of the exact-fp32 kernel, the reprogramming attention as fp32 tensor operations (scores materialised).
-# It exists to say what the default owes to the 2^-16 products (bench.py --strict-fp32) -- an upper bound, since
-# the exact forms are also less fused.
+# ---- strict fp32 (test oracle) ------------------------------------------------------------------------------------------------
+# Rounds 2-4 took the contractions INSIDE three kernel families (fused WaveNet forward, reprogramming attention, persistent GRU
+# recurrences) as three-term split-bf16 products (~2^-16 per product), and this switch routed them to fp32-exact compositions the
+# repository also carries to say what the default owed to that.  Since round 5 the default kernels carry scaled fp16 hi/lo operands
+# (csrc/f16_dev.h: fp32-equivalent, tests/test_gpu_parity.py::test_*_vs_float64 hold them to 4 x plain fp32's error), so the switch
+# no longer changes the accuracy class.  It stays as an independently written second evaluation of the same operators for the tests:
+# the WaveNet block as the composition of the exact-fp32 graph-conv kernel with library GEMMs and torch's BatchNorm
+# (gwnet.forward_cl's composed branch), the GRU recurrences as per-time-step launches of the exact-fp32 kernel, the reprogramming
+# attention as fp32 tensor operations with materialised scores.
 STRICT_FP32 = False
+_GRU_SMALL_ENV = None          # the user's HOPMI_GRU_SMALL while the switch is on
 
 
 def strict_fp32(on=None):
-    """Switch the three-term kernel families to their fp32-exact forms (see above).  Returns the previous setting."""
-    global STRICT_FP32
+    """Route the WaveNet forward, reprogramming attention and GRU recurrences to their composed fp32-exact forms (see above).
+    Returns the previous setting."""
+    global STRICT_FP32, _GRU_SMALL_ENV
     prev = STRICT_FP32
-    if on is not None:
-        STRICT_FP32 = bool(on)
+    if on is not None and bool(on) != STRICT_FP32:
         import os
-        os.environ["HOPMI_GRU_SMALL"] = "0" if STRICT_FP32 else "1"       # (the small-hidden-size GRU kernels are three-term too)
+        STRICT_FP32 = bool(on)
+        if STRICT_FP32:                                    # (the small-hidden-size GRU kernels are the fused form too)
+            _GRU_SMALL_ENV = os.environ.get("HOPMI_GRU_SMALL")
+            os.environ["HOPMI_GRU_SMALL"] = "0"
+        elif _GRU_SMALL_ENV is None:
+            os.environ.pop("HOPMI_GRU_SMALL", None)
+        else:
+            os.environ["HOPMI_GRU_SMALL"] = _GRU_SMALL_ENV
         _lib.lib().hopmi_reload_env()
     return prev
 
@@ -1002,10 +1009,12 @@ def unit_row_scales(M, device):
     """The row-scale pairs of an operand whose magnitudes are bounded by 1 (no pass over it): s = 2^14 for every row."""
     key = (str(device), M)
     t = _UNIT_RS.get(key)
-    if t is None or (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+    if t is None:
         t = torch.empty(2, M, dtype=torch.float32, device=device)
         t[0].fill_(16384.0)
         t[1].fill_(1.0 / 16384.0)
+        # (a constant made by an eager call serves recordings too: this table keeps it alive; one first made under capture lives
+        # in the graph's pool and is filled by recorded launches -- not kept)
         if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
             _UNIT_RS[key] = t
     return t

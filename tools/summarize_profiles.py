@@ -55,11 +55,34 @@ with open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.csv"), "w") as f:
     nz = [r for r in rows if "wn_noop_kernel" in r["Name"]]
     if nz:
         f.write(f"# wn_noop_kernel (empty kernel, the timing floor): {nz[0]['Calls']} launches, average {float(nz[0]['AverageNs']) / 1e3:.2f} us\n")
+    # Which launches belong to a REPLAYED step (what bench.py times) and which to the set-up (model building, the eager kernel-region
+    # steps, the eager call(s) in front of the recording): every train_llm step launches hop_losses_fwd_kernel once, so the window
+    # between two consecutive launches of it is one step; the last `n_rep` windows are replays of the recorded step.  The columns
+    # ReplayCallsPerStep / ReplayNsPerStep are averages over those windows: their sum is the kernel time of one timed step and can be
+    # held against the bench line's ms_per_step (it must not exceed it).
+    rep_calls, rep_ns, n_rep = defaultdict(float), defaultdict(float), 0
+    try:
+        tr = list(csv.DictReader(open(find("prof_stats", "*kernel_trace.csv"))))
+        tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+        marks = [i for i, r in enumerate(tr) if "hop_losses_fwd_kernel" in r["Kernel_Name"]]
+        n_rep = min(6, max(0, len(marks) - 9))             # (7 kernel-region steps + set-up come first; the last replays are the timed ones)
+        for a, b in zip(marks[-n_rep - 1:-1], marks[-n_rep:]):
+            for r in tr[a:b]:
+                rep_calls[r["Kernel_Name"][:120]] += 1.0 / n_rep
+                rep_ns[r["Kernel_Name"][:120]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / n_rep
+        if n_rep:
+            f.write(f"# replayed steps: {n_rep} windows between consecutive hop_losses_fwd_kernel launches at the end of the run; kernel time per replayed step "
+                    f"{sum(rep_ns.values()) / 1e6:.3f} ms in {sum(rep_calls.values()):.0f} launches (hold against the bench line's ms_per_step); rows whose "
+                    f"ReplayCallsPerStep is 0 are set-up only (weight images of frozen weights, eager-only launches, the empty timing kernel)\n")
+    except SystemExit:
+        pass
     w = csv.writer(f)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "ReplayCallsPerStep", "ReplayNsPerStep"])
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
         if float(r["TotalDurationNs"]) >= 5e-4 * total:
-            w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+            k = r["Name"][:120]
+            w.writerow([k, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"],
+                        f"{rep_calls.get(k, 0.0):.2f}", f"{rep_ns.get(k, 0.0):.0f}"])
 
 # ---- PMC traffic
 KEYS = {"wn_stack_fwd": "wn_stack_fwd_kernel", "wn_layer_fwd": r"wn_layer_fwd_kernel<\d, (true|false), true[,>]", "wn_layer_regate": r"wn_layer_fwd_kernel<\d, (true|false), false[,>]",
@@ -68,7 +91,8 @@ KEYS = {"wn_stack_fwd": "wn_stack_fwd_kernel", "wn_layer_fwd": r"wn_layer_fwd_ke
         "bert_attn_fwd": "bert_attn_fwd_kernel", "bert_attn_bwd": "bert_attn_bwd_kernel",
         "bias_drop_res_ln_fwd": "bias_drop_res_ln_fwd", "bias_gelu_fwd": "bias_gelu_fwd",
         "gru_fwd_persistent": "gru_fwd_persistent_kernel", "gru_bwd_persistent": "gru_bwd_persistent_kernel",
-        "colsum_partial": "colsum_partial_kernel", "gemm_split": "gemm_split_kernel"}
+        "colsum_partial": "colsum_partial_kernel", "gemm_split_ab": "gemm_split_ab_kernel", "gemm_split": "gemm_split_kernel",
+        "gemm_f16_tn": "gemm_f16_tn_kernel"}
 
 
 def counter(sub, name):
