@@ -85,6 +85,7 @@ SIGNATURES = {
     "hopmi_row_scales": (_I, [_VP, _I, _I, _VP, _VP]),
     "hopmi_gemm_f16x2_image_bytes": (ctypes.c_size_t, [_I, _I]),
     "hopmi_gemm_f16x2_prepare": (_I, [_VP, _I, _I, _VP, _VP]),
+    "hopmi_rows_image_f16_bytes": (ctypes.c_size_t, [_I, _I]),
     "hopmi_rows_image_f16": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "hopmi_gemm_f16x2_ab": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "hopmi_gemm_f16x2_ab_ep": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),

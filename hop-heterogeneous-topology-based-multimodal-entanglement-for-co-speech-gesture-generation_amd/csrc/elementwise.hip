@@ -62,15 +62,20 @@ constexpr int LN_MAX4 = 4;            // float4 per lane: D <= 64 * 4 * 4 = 1024
 // reads by LDS-DMA (hopmi_rows_image_f16's layout): the GEMM behind this operator then needs neither the split in its k-loop nor a
 // pass of its own over the activations (round 5).
 __device__ __forceinline__ void ln_store_image(unsigned* __restrict__ image, const float4 (&v)[LN_MAX4], int M, int D4, int row, int lane, float sc) {
-  u32x2* hi = reinterpret_cast<u32x2*>(image) + (size_t)row * D4;
-  u32x2* lo = reinterpret_cast<u32x2*>(image) + ((size_t)M + row) * D4;
+  // tile-blocked layout (gemm.hip f16_blk): ((row / 128) * KB + k / 32) * 4096 + (row % 128) * 32 + k % 32 halves, part images of
+  // ceil128(M) rows
+  _Float16* hi = reinterpret_cast<_Float16*>(image);
+  _Float16* lo = hi + (size_t)((M + 127) / 128 * 128) * D4 * 4;
+  const int KB = D4 >> 3;
+  const size_t base = (size_t)(row >> 7) * KB * 4096 + (size_t)(row & 127) * 32;
 #pragma unroll
   for (int k = 0; k < LN_MAX4; ++k) {
     const int c4 = lane + 64 * k;
     if (c4 < D4) {
       const Split4 sp = split4h(v[k].x * sc, v[k].y * sc, v[k].z * sc, v[k].w * sc);
-      hi[c4] = sp.hi;
-      lo[c4] = sp.lo;
+      const size_t at = base + (size_t)(c4 >> 3) * 4096 + 4 * (c4 & 7);
+      *reinterpret_cast<u32x2*>(hi + at) = sp.hi;
+      *reinterpret_cast<u32x2*>(lo + at) = sp.lo;
     }
   }
 }
@@ -454,7 +459,7 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_im(const void* x, const
                                                             float* rstd, float* row_scales, void* image, int M, int D, float eps, float p_drop,
                                                             unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_fwd")) return e;
-  if (image != nullptr && !row_scales) { set_error("hopmi_bias_dropout_residual_layernorm_fwd_im: the image needs row_scales"); return HOPMI_EINVAL; }
+  if (image != nullptr && (!row_scales || D % 32)) { set_error("hopmi_bias_dropout_residual_layernorm_fwd_im: the image needs row_scales and D %% 32 == 0"); return HOPMI_EINVAL; }
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_fwd_dt", dtype)) return e;
   if (!x || !bias || !res || !gamma || !beta || !out) { set_error("hopmi_bias_dropout_residual_layernorm_fwd: null pointer argument"); return HOPMI_EINVAL; }
   if (D > 256 * LN_MAX4 || res_rows <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
@@ -496,7 +501,7 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_im(const float* dout, c
                                                             int D, float p_drop, unsigned seed, const unsigned* seed_dev, int dtype,
                                                             void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
-  if (image != nullptr && !row_scales) { set_error("hopmi_bias_dropout_residual_layernorm_bwd_im: the image needs row_scales"); return HOPMI_EINVAL; }
+  if (image != nullptr && (!row_scales || D % 32)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd_im: the image needs row_scales and D %% 32 == 0"); return HOPMI_EINVAL; }
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_bwd_dt", dtype)) return e;
   if (!dout || !xhat || !rstd || !gamma || !dx || !dres) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: null pointer argument"); return HOPMI_EINVAL; }
   if (D > 256 * LN_MAX4 || !(p_drop >= 0.f && p_drop < 1.f)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd: D=%d p_drop=%f", D, p_drop); return HOPMI_EINVAL; }

@@ -87,6 +87,14 @@ constexpr int F16_PARTS = 16;                      // the `parts` code of this f
 // W^T image -- may differ by orders of magnitude).
 __host__ __device__ inline int f16_np(int N) { return (N + GN - 1) / GN * GN; }
 __host__ __device__ inline int f16_kp(int K) { return (K + GK - 1) / GK * GK; }
+// TILE-BLOCKED image layout (round 5).  An operand tile of a k-step is 128 rows x 32 halves = 128 x 64 bytes.  In a row-major image
+// those 64 bytes are half of a 128-byte line of a K*2-byte row, 256 separate lines per operand and k-step: staging ALONE (LDS-DMA, no
+// MFMA) ran at 11 TB/s -- 43 us of the 69 us QKV product (tools/probes/dma_layout.hip).  Blocked, a tile's 8 KiB are contiguous:
+// 17-21 TB/s (28 us).  Element (row r, column k) of one part image with KB = Kp / 32 k-steps per row block:
+//     ((r / 128) * KB + k / 32) * 4096 + (r % 128) * 32 + k % 32           [halves]
+// rows padded to whole 128-row blocks.  Used by every fp16 hi/lo image: the weights' (hopmi_gemm_f16x2_prepare), the activations'
+// (hopmi_rows_image_f16, the LayerNorm kernels' image outputs).
+__host__ __device__ inline size_t f16_blk(int r, int k, int KB) { return ((size_t)(r >> 7) * KB + (k >> 5)) * 4096 + (size_t)(r & 127) * 32 + (k & 31); }
 
 // per-row power-of-two scales of A [M][K] (K % 4 == 0): out[row] = s, out[M + row] = 1 / s; one wave per row
 __global__ __launch_bounds__(256) void row_scales_kernel(const float* __restrict__ A, int M, int K, float* __restrict__ out) {
@@ -112,15 +120,18 @@ __global__ __launch_bounds__(256) void f16_rows_image_kernel(const float* __rest
   const unsigned sb = scale_bits_for_max(m);
   const float sc = __uint_as_float(sb);
   if (lane == 0) { scales[row] = sc; scales[M + row] = inv_scale(sb); }
-  u32x2* hi = reinterpret_cast<u32x2*>(img + (size_t)row * (K / 2));
-  u32x2* lo = reinterpret_cast<u32x2*>(img + (size_t)M * (K / 2) + (size_t)row * (K / 2));
+  // (tile-blocked layout, K % 32 == 0; the part images are Mp = ceil128(M) rows)
+  _Float16* hi = reinterpret_cast<_Float16*>(img);
+  _Float16* lo = hi + (size_t)((M + 127) / 128 * 128) * K;
+  const int KB = K >> 5;
   for (int i = lane; i < K / 4; i += 64) {
     const float4 v = src[i];
     unsigned p0[2], p1[2];
     split_pair_f16(v.x * sc, v.y * sc, p0);
     split_pair_f16(v.z * sc, v.w * sc, p1);
-    hi[i] = u32x2{p0[0], p1[0]};
-    lo[i] = u32x2{p0[1], p1[1]};
+    const size_t at = f16_blk(row, 4 * i, KB);
+    *reinterpret_cast<u32x2*>(hi + at) = u32x2{p0[0], p1[0]};
+    *reinterpret_cast<u32x2*>(lo + at) = u32x2{p0[1], p1[1]};
   }
 }
 
@@ -129,10 +140,15 @@ __global__ __launch_bounds__(256) void f16_prepare_rows_kernel(const float* __re
                                                                unsigned* __restrict__ img, float* __restrict__ inv_out) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= Np) return;
-  unsigned* hi = img + (size_t)n * (Kp / 2);
-  unsigned* lo = img + (size_t)Np * (Kp / 2) + (size_t)n * (Kp / 2);
+  _Float16* hi = reinterpret_cast<_Float16*>(img);                     // (tile-blocked layout)
+  _Float16* lo = hi + (size_t)Np * Kp;
+  const int KB = Kp >> 5;
   if (n >= N) {
-    for (int i = lane; i < Kp / 2; i += 64) { hi[i] = 0u; lo[i] = 0u; }
+    for (int i = lane; i < Kp / 2; i += 64) {
+      const size_t at = f16_blk(n, 2 * i, KB);
+      *reinterpret_cast<unsigned*>(hi + at) = 0u;
+      *reinterpret_cast<unsigned*>(lo + at) = 0u;
+    }
     if (lane == 0) inv_out[n] = 1.f;
     return;
   }
@@ -152,8 +168,9 @@ __global__ __launch_bounds__(256) void f16_prepare_rows_kernel(const float* __re
       const float2 v = src[i];
       split_pair_f16(v.x * sc, v.y * sc, parts);
     }
-    hi[i] = parts[0];
-    lo[i] = parts[1];
+    const size_t at = f16_blk(n, 2 * i, KB);
+    *reinterpret_cast<unsigned*>(hi + at) = parts[0];
+    *reinterpret_cast<unsigned*>(lo + at) = parts[1];
   }
 }
 
@@ -252,7 +269,8 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
     __syncthreads();
   }
   const float sa = F16 ? s_scale[arow] : 1.f;
-  const __bf16* b_src = Bimg + (size_t)(n0 + brow) * Kp + 8 * bq;
+  // (fp16 form: the weight image is tile-blocked, f16_blk: tile (tn, kt) is 8 KiB contiguous; bf16 forms: row-major)
+  const __bf16* b_src = F16 ? Bimg + (size_t)tn * (Kp >> 5) * 4096 + brow * 32 + 8 * bq : Bimg + (size_t)(n0 + brow) * Kp + 8 * bq;
   const size_t b_part = (size_t)Np * Kp;
   const int a_off = arow * GLD + acol, b_off = brow * GLD + 8 * bq;
 
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(GT, DB ? 1 : 2) void gemm_split_kernel(const float*
       else a_st[i] = reinterpret_cast<const float4*>(a_src + k0)[i];
     }
 #pragma unroll
-    for (int p = 0; p < NP; ++p) b_st[p] = *reinterpret_cast<const u32x4*>(b_src + p * b_part + k0);
+    for (int p = 0; p < NP; ++p) b_st[p] = *reinterpret_cast<const u32x4*>(b_src + p * b_part + (F16 ? (size_t)(k0 >> 5) * 4096 : (size_t)k0));
   };
   auto commit = [&](int buf) {
     __bf16* la = lds + buf * BUF + a_off;
@@ -471,14 +489,18 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 
   // staging: wave wv moves rows 16 wv .. +15 of every (operand, part) image; lane -> (row, LDS slot); source slot swizzled
   const int srow = 16 * wv + (lane >> 2), sslot = (lane & 3) ^ gswz(lane >> 2);
-  const __bf16* a_src = Aimg + (size_t)min(m0 + srow, M - 1) * K + 8 * sslot;
-  const __bf16* b_src = Bimg + (size_t)(n0 + srow) * K + 8 * sslot;
+  // (fp16 form: both images tile-blocked, f16_blk -- a k-step's tile is 8 KiB contiguous, a wave instruction one contiguous KiB;
+  // bf16 forms: row-major)
   const int Np = F16 ? f16_np(N) : N;
-  const size_t a_part = (size_t)M * K, b_part = (size_t)Np * K;
+  const int arow = min(m0 + srow, M - 1);
+  const __bf16* a_src = F16 ? Aimg + (size_t)tm * (K >> 5) * 4096 + (arow - m0) * 32 + 8 * sslot : Aimg + (size_t)arow * K + 8 * sslot;
+  const __bf16* b_src = F16 ? Bimg + (size_t)tn * (K >> 5) * 4096 + srow * 32 + 8 * sslot : Bimg + (size_t)(n0 + srow) * K + 8 * sslot;
+  const size_t a_part = F16 ? (size_t)tiles_m * 128 * K : (size_t)M * K, b_part = (size_t)Np * K;
+  const size_t kstride = F16 ? 4096 : GK;
   const float* inv_b = reinterpret_cast<const float*>(Bimg + (size_t)NP * Np * K);
   auto stage = [&](int kt) {
     unsigned char* dst = smem_raw + (kt % NBUF) * BUFB + wv * 1024;
-    const int k0 = kt * GK;
+    const size_t k0 = kt * kstride;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + p * a_part + k0),
@@ -669,9 +691,13 @@ extern "C" int hopmi_row_scales(const float* A, int M, int K, float* scales, voi
   return check_launch("hopmi_row_scales");
 }
 
+extern "C" size_t hopmi_rows_image_f16_bytes(int M, int K) {
+  return (M > 0 && K > 0 && K % GK == 0) ? (size_t)2 * ((M + 127) / 128 * 128) * K * sizeof(_Float16) : 0;
+}
+
 extern "C" int hopmi_rows_image_f16(const float* A, int M, int K, void* image, float* scales, void* stream) {
-  if (!A || !image || !scales || M <= 0 || K <= 0 || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) {
-    set_error("hopmi_rows_image_f16: need A (16-byte aligned), image [2][M][K] fp16, scales [2 M], K %% 4 == 0 (M=%d K=%d)", M, K);
+  if (!A || !image || !scales || M <= 0 || K <= 0 || (K % GK) || (reinterpret_cast<uintptr_t>(A) & 15)) {
+    set_error("hopmi_rows_image_f16: need A (16-byte aligned), image (hopmi_rows_image_f16_bytes), scales [2 M], K %% 32 == 0 (M=%d K=%d)", M, K);
     return HOPMI_EINVAL;
   }
   hipLaunchKernelGGL(f16_rows_image_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), A, M, K,
@@ -691,11 +717,11 @@ extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales,
     return HOPMI_EINVAL;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // tile buffers (tools/probes/bench_ab.py, M = 4352): two (64 KB: two workgroups per CU) where the output has many column tiles
-  // (N = 2304: 69 vs 75 us, N = 3072: 84 vs 100), three (one workgroup per CU) for long contractions over few tiles (N = 768: K = 768
-  // 26 vs 28, K = 2304 59 vs 65, K = 3072 77 vs 86)
+  // tile buffers: two (64 KB of LDS: two workgroups per CU) -- with the tile-blocked images the faster form at every BERT shape
+  // (tools/probes/bench_ab.py, M = 4352, us, two / three buffers: N = 2304 59 / 77, N = 3072 77 / 102, N = K = 768 26.6 / 27.0,
+  // K = 3072 74 / 79, K = 2304 58 / 60); HOPMI_GEMM_NBUF=3 keeps the three-buffer form reachable
   const int forced = env_int("HOPMI_GEMM_NBUF", 0);
-  const int nbuf = (forced == 2 || forced == 3) ? forced : (N >= 2048 ? 2 : 3);
+  const int nbuf = forced == 3 ? 3 : 2;
   if (nbuf == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   return check_launch("hopmi_gemm_f16x2_ab");

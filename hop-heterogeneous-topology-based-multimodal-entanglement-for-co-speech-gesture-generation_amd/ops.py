@@ -442,7 +442,8 @@ def _take_img(t, M, K):
     if hit is None or not IMG_FUSED:
         return None
     img, sc, ptr, ver = hit
-    if ptr != t.data_ptr() or ver != t._version or img.numel() != 4 * M * K or tuple(sc.shape) != (2, M) or img.device != t.device:
+    if (ptr != t.data_ptr() or ver != t._version or img.numel() != _lib.lib().hopmi_rows_image_f16_bytes(M, K) or tuple(sc.shape) != (2, M)
+            or img.device != t.device):
         return None
     return img, sc
 
@@ -546,7 +547,7 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
             # no scales at hand and a problem that one 128 x 128 tile per CU covers: the pass that would take the row scales writes the
             # operand's fp16 images as well, and the LDS-DMA form multiplies (bit-identical; tools/bench_gemm.py: 24 vs 30 us at
             # N = K = 768, 71 vs 92 at K = 3072, M = 4352)
-            img_a = torch.empty(4 * M * K, dtype=torch.uint8, device=a2d.device)
+            img_a = torch.empty(L.hopmi_rows_image_f16_bytes(M, K), dtype=torch.uint8, device=a2d.device)
             sc = torch.empty(2, M, dtype=torch.float32, device=a2d.device)
             _lib.check(L.hopmi_rows_image_f16(a2d.data_ptr(), M, K, img_a.data_ptr(), sc.data_ptr(), _stream()), "hopmi_rows_image_f16")
             _lib.check(_timed("gemm_split", 4 * (M * K + M * N) + 4 * N * K, 2 * M * N * K,
@@ -717,7 +718,7 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         sc = torch.empty(2, M, dtype=torch.float32, device=x.device) if ctx.rs else None
         # ... and, where the LDS-DMA form of that GEMM pays (enough rows, whole 32-wide k-steps), the operand's image itself
         ctx.im = bool(ctx.rs and IMG_FUSED and D % 32 == 0 and M >= IMG_MIN_ROWS)
-        im = torch.empty(4 * M * D, dtype=torch.uint8, device=x.device) if ctx.im else None
+        im = torch.empty(L.hopmi_rows_image_f16_bytes(M, D), dtype=torch.uint8, device=x.device) if ctx.im else None
         _lib.check(_timed("bias_drop_res_ln_fwd", 4 * x.numel() * (4 if need else 3), 0,
                           lambda: L.hopmi_bias_dropout_residual_layernorm_fwd_im(
                               x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
@@ -749,7 +750,7 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         dx, dres = torch.empty_like(xhat), torch.empty_like(xhat)
         L, st = _lib.lib(), _stream()
         sc = torch.empty(2, M, dtype=torch.float32, device=dx.device) if ctx.rs else None      # dx feeds the backward's next GEMM
-        im = torch.empty(4 * M * D, dtype=torch.uint8, device=dx.device) if ctx.im else None
+        im = torch.empty(L.hopmi_rows_image_f16_bytes(M, D), dtype=torch.uint8, device=dx.device) if ctx.im else None
         _lib.check(_timed("bias_drop_res_ln_bwd", (16 if d2 is None else 20) * xhat.numel(), 0,
                           lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_im(
                               dout.data_ptr(), _ptr(d2), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),

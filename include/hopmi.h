@@ -457,6 +457,7 @@ int hopmi_gemm_f16x2(const float* A, const float* a_scales, int a_parts, const v
  * [2][M] row-scale pairs in one pass (what hopmi_row_scales + the in-kernel split do together), hopmi_gemm_f16x2_ab multiplies
  * (K % 32 == 0, any N; bias epilogue only).  Bit-identical to hopmi_gemm_f16x2; faster where one 128 x 128 tile per CU covers the
  * problem (N = 768 at M = 4352: 24 vs 30 us, K = 3072: 71 vs 92). */
+size_t hopmi_rows_image_f16_bytes(int M, int K);     /* tile-blocked, rows padded to 128 (csrc/gemm.hip f16_blk); K % 32 == 0 */
 int hopmi_rows_image_f16(const float* A, int M, int K, void* image, float* scales, void* stream);
 int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M, int N,
                         int K, void* stream);

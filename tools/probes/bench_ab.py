@@ -27,7 +27,7 @@ for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 2304)):
     img = ops.split_weight_image(w, 16)
     sc = ops.row_scales(x)
     t_split = timed(lambda: ops._split_gemm(x, img, b, N, K, 16, a_part=sc))
-    img_a = torch.empty(4 * M * K, dtype=torch.uint8, device=dev)
+    img_a = torch.empty(L.hopmi_rows_image_f16_bytes(M, K), dtype=torch.uint8, device=dev)
     sc2 = torch.empty(2, M, dtype=torch.float32, device=dev)
     t_img = timed(lambda: L.hopmi_rows_image_f16(x.data_ptr(), M, K, img_a.data_ptr(), sc2.data_ptr(), st))
     out = torch.empty(M, N, device=dev)
