@@ -52,6 +52,7 @@ class FrozenBertEncoder:
         self.llm = llm
         self._qkv = {}
         self._img = {}
+        self._bounds = {}                        # layer -> (weight versions, norm bounds of the FFN weights)
         self._w16 = {}
 
     def _fused_qkv(self, i, att):
@@ -92,12 +93,29 @@ class FrozenBertEncoder:
             self._img[key] = hit
         return hit[1], hit[2]
 
+    def _ffn_bounds(self, i, lay):
+        """(largest row 2-norm of W1, largest |b1|, largest column 2-norm of W2) of the frozen FFN weights, as Python floats (one
+        host read per weight version, in the first -- eager -- call): what the image-emitting GEMM epilogues bound their outputs
+        with (ops._SplitFfnFn)."""
+        w1, b1, w2 = lay.intermediate.dense.weight, lay.intermediate.dense.bias, lay.output.dense.weight
+        ver = (w1._version, w1.data_ptr(), b1._version, w2._version, w2.data_ptr())
+        hit = self._bounds.get(i)
+        if hit is None or hit[0] != ver:
+            if w1.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None if hit is None else hit[1]       # (never read back under capture; the eager calls came first)
+            with torch.no_grad():
+                t = torch.stack([w1.float().norm(dim=1).max(), b1.float().abs().max(), w2.float().norm(dim=0).max()]).tolist()
+            hit = (ver, (t[0] * 1.000001, t[1], t[2] * 1.000001))
+            self._bounds[i] = hit
+        return hit[1]
+
     def _ffn(self, i, lay, h):
         """gelu(h W1^T + b1) W2^T of layer i (BertIntermediate + BertOutput.dense without its bias)."""
         w1, w2 = lay.intermediate.dense.weight, lay.output.dense.weight
         i1, i2 = self._images((i, "f1"), h, w1), self._images((i, "f2"), h, w2)
         if FUSED_FFN and i1 is not None and i2 is not None:
-            return ops.split_ffn(h, i1[0], i1[1], lay.intermediate.dense.bias, i2[0], i2[1], w1.shape[0], w1.shape[1], ops.GEMM_PARTS)
+            return ops.split_ffn(h, i1[0], i1[1], lay.intermediate.dense.bias, i2[0], i2[1], w1.shape[0], w1.shape[1], ops.GEMM_PARTS,
+                                 bounds=self._ffn_bounds(i, lay))
         f = ops.bias_gelu(self._linear((i, "f1"), h, w1, None), lay.intermediate.dense.bias)
         return self._linear((i, "f2"), f, w2, None)
 

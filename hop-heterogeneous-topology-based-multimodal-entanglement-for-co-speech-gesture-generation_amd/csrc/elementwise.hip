@@ -92,12 +92,14 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
                                                                    float* __restrict__ xhat, float* __restrict__ rstd_out, int M,
                                                                    int D, int res_rows, float eps, unsigned drop_thresh,
                                                                    float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev,
-                                                                   float* __restrict__ row_scales, unsigned* __restrict__ image) {
+                                                                   float* __restrict__ row_scales, unsigned* __restrict__ image,
+                                                                   float* __restrict__ row_norms) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
   unsigned amax = 0;                            // max |out| of the row (row_scales: the next GEMM's fp16-form operand scale)
+  float nrm = 0.f;                              // sum out^2 (row_norms: the a-priori bound of the next GEMM's image-emitting epilogue)
   float4 z[LN_MAX4];
   float s = 0.f;
 #pragma unroll
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
       if (out_t != nullptr) st4(out_t + ((size_t)row * D4 + c4) * 4, o);
       if (xhat != nullptr) reinterpret_cast<float4*>(xhat)[(size_t)row * D4 + c4] = h;
       amax = abs_bits_max4(amax, o);
+      nrm += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
       z[k] = o;                                 // (kept for the image below)
     }
   }
@@ -149,6 +152,10 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
     amax = wave_max_u32(amax);
     if (lane == 0) store_row_scale(row_scales, M, row, amax);
     if (image != nullptr) ln_store_image(image, z, M, D4, row, lane, __uint_as_float(scale_bits_for_max(amax)));
+  }
+  if (row_norms != nullptr) {
+    nrm = wave_sum(nrm);
+    if (lane == 0) row_norms[row] = sqrtf(nrm) * 1.0000005f;        // (rounded up: it feeds a bound)
   }
 }
 
@@ -160,11 +167,13 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
                                                                    const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                                    T* __restrict__ dx, float* __restrict__ dres, int M, int D,
                                                                    unsigned drop_thresh, float drop_scale, unsigned seed, const unsigned* __restrict__ seed_dev,
-                                                                   float* __restrict__ row_scales, unsigned* __restrict__ image) {
+                                                                   float* __restrict__ row_scales, unsigned* __restrict__ image,
+                                                                   float* __restrict__ row_norms) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
+  float nrm = 0.f;                              // sum dx^2 (row_norms)
   unsigned amax = 0;                            // max |dx| of the row (row_scales: the next GEMM's fp16-form operand scale)
   float4 dh[LN_MAX4], xh[LN_MAX4];
   float s1 = 0.f, s2 = 0.f;
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
       }
       st4(dx + ((size_t)row * D4 + c4) * 4, dz);
       amax = abs_bits_max4(amax, dz);
+      nrm += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
       dh[k] = dz;                               // (kept for the image below)
     }
   }
@@ -210,6 +220,10 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
     amax = wave_max_u32(amax);
     if (lane == 0) store_row_scale(row_scales, M, row, amax);
     if (image != nullptr) ln_store_image(image, dh, M, D4, row, lane, __uint_as_float(scale_bits_for_max(amax)));
+  }
+  if (row_norms != nullptr) {
+    nrm = wave_sum(nrm);
+    if (lane == 0) row_norms[row] = sqrtf(nrm) * 1.0000005f;
   }
 }
 
@@ -456,8 +470,9 @@ extern "C" int hopmi_bias_gelu_bwd(const float* x, const float* bias, const floa
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_im(const void* x, const float* bias, const float* res, int res_rows,
                                                             const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
-                                                            float* rstd, float* row_scales, void* image, int M, int D, float eps, float p_drop,
-                                                            unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
+                                                            float* rstd, float* row_scales, void* image, float* row_norms, int M, int D,
+                                                            float eps, float p_drop, unsigned seed, const unsigned* seed_dev, int dtype,
+                                                            void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_fwd")) return e;
   if (image != nullptr && (!row_scales || D % 32)) { set_error("hopmi_bias_dropout_residual_layernorm_fwd_im: the image needs row_scales and D %% 32 == 0"); return HOPMI_EINVAL; }
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_fwd_dt", dtype)) return e;
@@ -472,11 +487,11 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_im(const void* x, const
   if (dtype == HOPMI_BF16)
     hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const __bf16*>(x), bias, res,
                        gamma, beta, out, static_cast<__bf16*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales,
-                       static_cast<unsigned*>(image));
+                       static_cast<unsigned*>(image), row_norms);
   else
     hipLaunchKernelGGL(bias_drop_res_ln_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const float*>(x), bias, res,
                        gamma, beta, out, static_cast<float*>(out_t), xhat, rstd, M, D, res_rows, eps, thresh, dscale, seed, seed_dev, row_scales,
-                       static_cast<unsigned*>(image));
+                       static_cast<unsigned*>(image), row_norms);
   return check_launch("hopmi_bias_dropout_residual_layernorm_fwd");
 }
 
@@ -484,8 +499,8 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_rs(const void* x, const
                                                             const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
                                                             float* rstd, float* row_scales, int M, int D, float eps, float p_drop,
                                                             unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
-  return hopmi_bias_dropout_residual_layernorm_fwd_im(x, bias, res, res_rows, gamma, beta, out, out_t, xhat, rstd, row_scales, nullptr, M, D, eps,
-                                                      p_drop, seed, seed_dev, dtype, stream);
+  return hopmi_bias_dropout_residual_layernorm_fwd_im(x, bias, res, res_rows, gamma, beta, out, out_t, xhat, rstd, row_scales, nullptr, nullptr, M, D,
+                                                      eps, p_drop, seed, seed_dev, dtype, stream);
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const float* bias, const float* res, int res_rows,
@@ -497,9 +512,9 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_fwd_dt(const void* x, const
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_im(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
-                                                            const float* gamma, void* dx, float* dres, float* row_scales, void* image, int M,
-                                                            int D, float p_drop, unsigned seed, const unsigned* seed_dev, int dtype,
-                                                            void* stream) {
+                                                            const float* gamma, void* dx, float* dres, float* row_scales, void* image,
+                                                            float* row_norms, int M, int D, float p_drop, unsigned seed,
+                                                            const unsigned* seed_dev, int dtype, void* stream) {
   if (int e = ew_check(M, D, "hopmi_bias_dropout_residual_layernorm_bwd")) return e;
   if (image != nullptr && (!row_scales || D % 32)) { set_error("hopmi_bias_dropout_residual_layernorm_bwd_im: the image needs row_scales and D %% 32 == 0"); return HOPMI_EINVAL; }
   if (int e = ew_dtype_ok("hopmi_bias_dropout_residual_layernorm_bwd_dt", dtype)) return e;
@@ -510,18 +525,18 @@ extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_im(const float* dout, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == HOPMI_BF16)
     hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<__bf16>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const __bf16*>(dout_t), xhat,
-                       rstd, gamma, static_cast<__bf16*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales, static_cast<unsigned*>(image));
+                       rstd, gamma, static_cast<__bf16*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales, static_cast<unsigned*>(image), row_norms);
   else
     hipLaunchKernelGGL(bias_drop_res_ln_bwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, dout, static_cast<const float*>(dout_t), xhat,
-                       rstd, gamma, static_cast<float*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales, static_cast<unsigned*>(image));
+                       rstd, gamma, static_cast<float*>(dx), dres, M, D, thresh, dscale, seed, seed_dev, row_scales, static_cast<unsigned*>(image), row_norms);
   return check_launch("hopmi_bias_dropout_residual_layernorm_bwd");
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
                                                             const float* gamma, void* dx, float* dres, float* row_scales, int M, int D,
                                                             float p_drop, unsigned seed, const unsigned* seed_dev, int dtype, void* stream) {
-  return hopmi_bias_dropout_residual_layernorm_bwd_im(dout, dout_t, xhat, rstd, gamma, dx, dres, row_scales, nullptr, M, D, p_drop, seed, seed_dev,
-                                                      dtype, stream);
+  return hopmi_bias_dropout_residual_layernorm_bwd_im(dout, dout_t, xhat, rstd, gamma, dx, dres, row_scales, nullptr, nullptr, M, D, p_drop, seed,
+                                                      seed_dev, dtype, stream);
 }
 
 extern "C" int hopmi_bias_dropout_residual_layernorm_bwd_dt(const float* dout, const void* dout_t, const float* xhat, const float* rstd,

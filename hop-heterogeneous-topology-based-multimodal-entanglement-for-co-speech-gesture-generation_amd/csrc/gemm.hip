@@ -466,12 +466,21 @@ __device__ __forceinline__ int gswz(int row) { return (0x1230 >> (4 * ((row >> 2
 // F16: the fp16 hi/lo form (NP = 2) -- A image [2][M][K] of scaled fp16 parts + a_rows [2][M] scale pairs as hopmi_rows_image_f16
 // writes them, B image padded to Np rows with its Np inverse row scales behind it (f16_np / hopmi_gemm_f16x2_prepare); N may be
 // ragged (store guard), K % 32 == 0.  The same three terms in the same order as gemm_split_kernel<2, ., ., true>: bit-identical.
+// The product handed on as the NEXT fp16-form GEMM's operand image instead of (or beside) fp32 values: `image` = tile-blocked hi / lo
+// images of C times one power of two per row, `scales` its [2][M] pairs.  The row's scale has to be known before any column tile is
+// written and the row's maximum is not (it spans the other column tiles' workgroups): it is taken from an a-priori BOUND,
+// |C[row][:]| <= row_norm[row] * mul + add -- Cauchy-Schwarz on the product (row_norm = the 2-norm of the A operand's row, written by
+// the LayerNorm kernel that produced it; mul = the largest 2-norm of a row of the weight, times the epilogue's Lipschitz constant;
+// add = the largest |bias|).  Typical elements sit 2^3 ... 2^6 below such a bound, well inside the 2^17 window in which their lo parts
+// stay normal fp16 numbers (f16_dev.h).
+struct AbImageOut { _Float16* image; float* scales; const float* row_norm; float mul, add; };
+
 template <int NP, int NBUF, bool F16 = false>
 __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Bimg,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N,
                                                              int K, int tiles_m, int tiles_n, const float* __restrict__ a_rows, int ep,
                                                              float* __restrict__ C2, const float* __restrict__ aux,
-                                                             float* __restrict__ c_rowmax) {
+                                                             float* __restrict__ c_rowmax, AbImageOut io) {
   __shared__ unsigned s_cmax[F16 ? 128 : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int IMG = 128 * 64;                    // bytes of one part image of one operand tile
@@ -585,8 +594,18 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
             if (C2 != nullptr) C2[at] = h;
             out = gemm_gelu(h);
           } else out = h * gemm_gelu_grad(aux[at]);
-          C[at] = out;
+          if (C != nullptr) C[at] = out;
           if (F16) rmx[mi][r] = max(rmx[mi][r], __float_as_uint(out) & 0x7fffffffu);
+          if (F16 && io.image != nullptr) {
+            // (2-byte stores: the 16 lanes of a quarter write 32 contiguous bytes of the row's 64-byte tile segment)
+            const unsigned sbits = scale_bits_for_max(__float_as_uint(io.row_norm[row] * io.mul + io.add) & 0x7fffffffu);
+            const float xs = out * __uint_as_float(sbits);
+            const _Float16 hi = (_Float16)xs;
+            const size_t ia = f16_blk(row, col, f16_np(N) >> 5);
+            io.image[ia] = hi;
+            io.image[(size_t)tiles_m * 128 * f16_np(N) + ia] = (_Float16)(xs - (float)hi);
+            if (tn == 0 && ni == 0 && n == 0) { io.scales[row] = __uint_as_float(sbits); io.scales[M + row] = inv_scale(sbits); }
+          }
         }
       }
   }
@@ -608,7 +627,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 template <int NP, int NBUF, bool F16 = false>
 static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
                            const float* a_rows = nullptr, int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr,
-                           float* c_rowmax = nullptr) {
+                           float* c_rowmax = nullptr, AbImageOut io = AbImageOut{nullptr, nullptr, nullptr, 0.f, 0.f}) {
   const int tiles_m = (M + 127) / 128, tiles_n = (N + GN - 1) / GN;
   const size_t lds = (size_t)NBUF * 2 * NP * 128 * 64;
   static bool attr_done = false;
@@ -621,7 +640,7 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF, F16>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
-                     static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n, a_rows, ep, C2, aux, c_rowmax);
+                     static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n, a_rows, ep, C2, aux, c_rowmax, io);
 }
 
 // Tile choice by the number of 128 x 128 tiles, measured at the frozen BERT's shapes for M = 4352 (TED, batch 128) and M = 2176
@@ -725,6 +744,25 @@ extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales,
   if (nbuf == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   return check_launch("hopmi_gemm_f16x2_ab");
+}
+
+extern "C" int hopmi_gemm_f16x2_ab_img(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
+                                       const float* aux, int M, int N, int K, int epilogue, void* out_image, float* out_scales,
+                                       const float* row_norm, float bound_mul, float bound_add, void* stream) {
+  if (!Aimage || !a_scales || !Bimage || !out_image || !out_scales || !row_norm) { set_error("hopmi_gemm_f16x2_ab_img: null pointer argument"); return HOPMI_EINVAL; }
+  if (M <= 0 || N <= 0 || K <= 0 || K % GK || N % GK) {
+    set_error("hopmi_gemm_f16x2_ab_img: need K %% 32 == 0 and N %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+    return HOPMI_EINVAL;
+  }
+  if (epilogue < EP_BIAS || epilogue > EP_GELU_GRAD || (epilogue == EP_GELU_GRAD && !aux) || !(bound_mul >= 0.f) || !(bound_add >= 0.f)) {
+    set_error("hopmi_gemm_f16x2_ab_img: epilogue %d / bound (%g, %g)", epilogue, (double)bound_mul, (double)bound_add);
+    return HOPMI_EINVAL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const AbImageOut io{static_cast<_Float16*>(out_image), out_scales, row_norm, bound_mul, bound_add};
+  if (env_int("HOPMI_GEMM_NBUF", 0) == 3) launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
+  else launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
+  return check_launch("hopmi_gemm_f16x2_ab_img");
 }
 
 extern "C" int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M,

@@ -429,19 +429,26 @@ def _take_rs(t, M):
     return sc
 
 
-def _attach_img(t, img, sc):
-    """Remember the fp16 hi / lo operand image `img` ([2][M][K] halves as bytes) and its row scales `sc` of tensor `t` ON the tensor
-    object (as _attach_rs does for the scales alone): the LayerNorm kernels write it beside `t`, the GEMM that consumes `t` asks
-    `_take_img` and runs the LDS-DMA form (hopmi_gemm_f16x2_ab_ep)."""
-    t._hopmi_img = (img, sc, t.data_ptr(), t._version)
+def _attach_img(t, img, sc, norms=None):
+    """Remember the fp16 hi / lo operand image `img` (tile-blocked, hopmi_rows_image_f16_bytes) and its row scales `sc` of tensor `t` ON
+    the tensor object (as _attach_rs does for the scales alone): the LayerNorm kernels write it beside `t`, the GEMM that consumes `t`
+    asks `_take_img` and runs the LDS-DMA form (hopmi_gemm_f16x2_ab_ep).  `norms`: the rows' 2-norms ([M], `_take_norms`)."""
+    t._hopmi_img = (img, sc, t.data_ptr(), t._version, norms)
     _attach_rs(t, sc)
+
+
+def _take_norms(t, M):
+    hit = getattr(t, "_hopmi_img", None)
+    if hit is None or hit[4] is None or hit[2] != t.data_ptr() or hit[3] != t._version or tuple(hit[4].shape) != (M,):
+        return None
+    return hit[4]
 
 
 def _take_img(t, M, K):
     hit = getattr(t, "_hopmi_img", None)
     if hit is None or not IMG_FUSED:
         return None
-    img, sc, ptr, ver = hit
+    img, sc, ptr, ver, _ = hit
     if (ptr != t.data_ptr() or ver != t._version or img.numel() != _lib.lib().hopmi_rows_image_f16_bytes(M, K) or tuple(sc.shape) != (2, M)
             or img.device != t.device):
         return None
@@ -451,6 +458,8 @@ def _take_img(t, M, K):
 RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"
 # the LayerNorm operators also write the fp16 hi/lo image of what they hand to the next GEMM (A/B: HOPMI_IMG_FUSED=0)
 IMG_FUSED = __import__("os").environ.get("HOPMI_IMG_FUSED", "1") != "0"
+# BertIntermediate's product hands its output to BertOutput.dense as an operand image (and the backward likewise): A/B HOPMI_FFN_IMG=0
+FFN_IMG = __import__("os").environ.get("HOPMI_FFN_IMG", "1") != "0"
 IMG_MIN_ROWS = 1024     # row scales from the producing kernels (0: always a pass of their own)
 # the LDS-DMA form of the fp16 GEMM (_split_gemm_ep): faster back to back (24 vs 30 us, 71 vs 92), bit-identical -- and no gain in
 # the step (15.96 vs 15.96 ms, A/B twice on one box: the image pass it needs costs what the k-loop split it saves did), so off
@@ -520,10 +529,10 @@ def split_linear(x, img_w, img_wt, bias, N, K, parts):
     return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
 
 
-def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None, rowmax=None, a_img=None):
+def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None, rowmax=None, a_img=None, rows=None):
     """hopmi_gemm_split_ep / hopmi_gemm_f16x2: epilogue 0 -> a2d W^T + bias; 1 -> (gelu(h), h if keep else None) with
     h = a2d W^T + bias; 2 -> (a2d W^T) * gelu'(aux).  `a_part`: the fp16 form's per-row scales of a2d (row_scales) when the caller has them."""
-    M = a2d.shape[0]
+    M = a2d.shape[0] if rows is None else rows          # (`rows`: the operand only exists as its image, a2d is a shape-less stand-in)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
     elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a2d.device:
@@ -576,24 +585,50 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
     return out, h
 
 
+def _gemm_ab_img(a_img, M, img, bias, N, K, epilogue, norms, mul, add, keep=False, aux=None):
+    """hopmi_gemm_f16x2_ab_img: (image, scales) of the product (no fp32 output) and, epilogue 1 with `keep`, the pre-activation."""
+    L = _lib.lib()
+    img_a, sc = a_img
+    dev = img_a.device
+    h = torch.empty(M, N, dtype=torch.float32, device=dev) if (epilogue == 1 and keep) else None
+    oi = torch.empty(L.hopmi_rows_image_f16_bytes(M, N), dtype=torch.uint8, device=dev)
+    osc = torch.empty(2, M, dtype=torch.float32, device=dev)
+    _lib.check(_timed("gemm_split", 4 * (M * K + (2 if (h is not None or aux is not None) else 1) * M * N) + 4 * N * K, 2 * M * N * K,
+                      lambda: L.hopmi_gemm_f16x2_ab_img(img_a.data_ptr(), sc.data_ptr(), img.data_ptr(), _ptr(bias), None, _ptr(h), _ptr(aux), M, N, K,
+                                                        epilogue, oi.data_ptr(), osc.data_ptr(), norms.data_ptr(), float(mul), float(add), _stream())),
+               "hopmi_gemm_f16x2_ab_img")
+    return (oi, osc), h
+
+
 class _SplitFfnFn(torch.autograd.Function):
     """BertIntermediate + the dense of BertOutput against FROZEN weights: o = gelu(x W1^T + b1) W2^T (the bias of the second
     linear is added by the LayerNorm operator behind it).  The activation is the epilogue of the first product and its gradient
     the epilogue of the backward's first product (hopmi_gemm_split_ep): the values of split_linear -> bias_gelu -> split_linear
-    bit for bit, without the two launches that re-read and re-write the M x 3072 tensor."""
+    bit for bit, without the two launches that re-read and re-write the M x 3072 tensor.
+    Round 5, `bounds` = (largest row 2-norm of W1, largest |b1|, largest column 2-norm of W2) and an input that arrives with its
+    operand image and row norms (a LayerNorm output / LayerNorm-backward dx): the first product hands its result to the second as an
+    operand IMAGE (hopmi_gemm_f16x2_ab_img: no fp32 gelu output at all, its row scales from the Cauchy-Schwarz bound), and both run
+    the LDS-DMA form; the backward likewise.  Same three-term arithmetic; the results differ from the split form's by the choice of
+    the intermediate's row scale (a power of two) only where lo parts are subnormal."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, img1, img1t, b1, img2, img2t, N1, K, parts):
+    def forward(ctx, x, img1, img1t, b1, img2, img2t, N1, K, parts, bounds=None):
         x = _dev_f32(x, "x")
-        rs = _take_rs(x, x.numel() // K) if parts == F16_PARTS else None
-        ai = _take_img(x, x.numel() // K, K) if parts == F16_PARTS else None
-        fmax = [] if (parts == F16_PARTS and RS_FUSED) else None           # the GELU epilogue leaves its output's row maxima
-        f, h = _split_gemm_ep(x.reshape(-1, K), img1, _dev_f32(b1.detach(), "bias"), N1, K, parts, 1, keep=ctx.needs_input_grad[0], a_part=rs,
-                              rowmax=fmax, a_img=ai)
-        o = _split_gemm(f, img2, None, K, N1, parts, a_part=fmax[0] if fmax else None)
+        M = x.numel() // K
+        rs = _take_rs(x, M) if parts == F16_PARTS else None
+        ai = _take_img(x, M, K) if parts == F16_PARTS else None
+        nr = _take_norms(x, M) if (ai is not None and bounds is not None and FFN_IMG and N1 % 32 == 0) else None
+        ctx.imgs, ctx.dims, ctx.bounds = (img1t, img2t), (N1, K, parts), bounds
+        b1d = _dev_f32(b1.detach(), "bias")
+        if nr is not None:
+            fi, h = _gemm_ab_img(ai, M, img1, b1d, N1, K, 1, nr, bounds[0], bounds[1], keep=ctx.needs_input_grad[0])
+            o = _split_gemm_ep(x.reshape(-1, K)[:, :0], img2, None, K, N1, parts, 0, a_img=fi, rows=M)[0]
+        else:
+            fmax = [] if (parts == F16_PARTS and RS_FUSED) else None           # the GELU epilogue leaves its output's row maxima
+            f, h = _split_gemm_ep(x.reshape(-1, K), img1, b1d, N1, K, parts, 1, keep=ctx.needs_input_grad[0], a_part=rs, rowmax=fmax, a_img=ai)
+            o = _split_gemm(f, img2, None, K, N1, parts, a_part=fmax[0] if fmax else None)
         ctx.save_for_backward(h)
-        ctx.imgs, ctx.dims = (img1t, img2t), (N1, K, parts)
         return o.view(*x.shape[:-1], K)
 
     @staticmethod
@@ -603,16 +638,23 @@ class _SplitFfnFn(torch.autograd.Function):
         img1t, img2t = ctx.imgs
         N1, K, parts = ctx.dims
         do = _dev_f32(do, "do")
-        rs = _take_rs(do, do.numel() // K) if parts == F16_PARTS else None
-        ai = _take_img(do, do.numel() // K, K) if parts == F16_PARTS else None
-        dmax = [] if (parts == F16_PARTS and RS_FUSED) else None
-        dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h, a_part=rs, rowmax=dmax, a_img=ai)   # (dO W2) * gelu'(h)
-        dx = _split_gemm(dh, img1t, None, K, N1, parts, a_part=dmax[0] if dmax else None)                         # dH W1
-        return dx.view(*do.shape), None, None, None, None, None, None, None, None
+        M = do.numel() // K
+        rs = _take_rs(do, M) if parts == F16_PARTS else None
+        ai = _take_img(do, M, K) if parts == F16_PARTS else None
+        nr = _take_norms(do, M) if (ai is not None and ctx.bounds is not None and FFN_IMG and N1 % 32 == 0) else None
+        if nr is not None:
+            # |(dO W2) gelu'(h)| <= ||dO_row|| max_n ||W2[:, n]|| max |gelu'| (1.1290)
+            di, _ = _gemm_ab_img(ai, M, img2t, None, N1, K, 2, nr, 1.13 * ctx.bounds[2], 0.0, aux=h)
+            dx = _split_gemm_ep(do.reshape(-1, K)[:, :0], img1t, None, K, N1, parts, 0, a_img=di, rows=M)[0]
+        else:
+            dmax = [] if (parts == F16_PARTS and RS_FUSED) else None
+            dh, _ = _split_gemm_ep(do.reshape(-1, K), img2t, None, N1, K, parts, 2, aux=h, a_part=rs, rowmax=dmax, a_img=ai)   # (dO W2) * gelu'(h)
+            dx = _split_gemm(dh, img1t, None, K, N1, parts, a_part=dmax[0] if dmax else None)                         # dH W1
+        return dx.view(*do.shape), None, None, None, None, None, None, None, None, None
 
 
-def split_ffn(x, img1, img1t, b1, img2, img2t, N1, K, parts):
-    return _SplitFfnFn.apply(x, img1, img1t, b1, img2, img2t, N1, K, parts)
+def split_ffn(x, img1, img1t, b1, img2, img2t, N1, K, parts, bounds=None):
+    return _SplitFfnFn.apply(x, img1, img1t, b1, img2, img2t, N1, K, parts, bounds)
 
 
 # ------------------------------------------------------- fused BERT epilogues (frozen LLM: no parameter grads)
@@ -719,10 +761,11 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         # ... and, where the LDS-DMA form of that GEMM pays (enough rows, whole 32-wide k-steps), the operand's image itself
         ctx.im = bool(ctx.rs and IMG_FUSED and D % 32 == 0 and M >= IMG_MIN_ROWS)
         im = torch.empty(L.hopmi_rows_image_f16_bytes(M, D), dtype=torch.uint8, device=x.device) if ctx.im else None
+        nr = torch.empty(M, dtype=torch.float32, device=x.device) if ctx.im else None
         _lib.check(_timed("bias_drop_res_ln_fwd", 4 * x.numel() * (4 if need else 3), 0,
                           lambda: L.hopmi_bias_dropout_residual_layernorm_fwd_im(
                               x.data_ptr(), bias.data_ptr(), res.data_ptr(), res_rows, gamma.data_ptr(), beta.data_ptr(),
-                              out.data_ptr(), None, _ptr(xhat), _ptr(rstd), _ptr(sc), _ptr(im), M, D, float(eps), float(p_drop),
+                              out.data_ptr(), None, _ptr(xhat), _ptr(rstd), _ptr(sc), _ptr(im), _ptr(nr), M, D, float(eps), float(p_drop),
                               int(seed) & _M32, sp, 0, st)),
                    "hopmi_bias_dropout_residual_layernorm_fwd")
         if need:
@@ -732,12 +775,12 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         if sc is not None:
             ctx.mark_non_differentiable(sc)
         if im is not None:
-            ctx.mark_non_differentiable(im)
-        return out, out.detach(), sc, im
+            ctx.mark_non_differentiable(im, nr)
+        return out, out.detach(), sc, im, nr
 
     @staticmethod
     @_bwd32
-    def backward(ctx, dout, dout2, _dsc=None, _dim=None):
+    def backward(ctx, dout, dout2, _dsc=None, _dim=None, _dnr=None):
         xhat, rstd, gamma = ctx.saved_tensors
         if dout is None:
             dout, dout2 = dout2, None
@@ -751,13 +794,14 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
         L, st = _lib.lib(), _stream()
         sc = torch.empty(2, M, dtype=torch.float32, device=dx.device) if ctx.rs else None      # dx feeds the backward's next GEMM
         im = torch.empty(L.hopmi_rows_image_f16_bytes(M, D), dtype=torch.uint8, device=dx.device) if ctx.im else None
+        nr = torch.empty(M, dtype=torch.float32, device=dx.device) if ctx.im else None
         _lib.check(_timed("bias_drop_res_ln_bwd", (16 if d2 is None else 20) * xhat.numel(), 0,
                           lambda: L.hopmi_bias_dropout_residual_layernorm_bwd_im(
                               dout.data_ptr(), _ptr(d2), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
-                              dres.data_ptr(), _ptr(sc), _ptr(im), M, D, ctx.p_drop, ctx.seed, ctx.sp, 0, st)),
+                              dres.data_ptr(), _ptr(sc), _ptr(im), _ptr(nr), M, D, ctx.p_drop, ctx.seed, ctx.sp, 0, st)),
                    "hopmi_bias_dropout_residual_layernorm_bwd_dt")
         if im is not None:
-            _attach_img(dx, im, sc)
+            _attach_img(dx, im, sc, nr)
         elif sc is not None:
             _attach_rs(dx, sc)
         if tuple(ctx.res_shape) != tuple(dres.shape):            # broadcast residual (e.g. position embeddings)
@@ -767,9 +811,9 @@ class _BiasDropResLn2Fn(torch.autograd.Function):
 
 def bias_dropout_residual_layernorm2(x, bias, res, gamma, beta, eps, p_drop=0.0, seed=0):
     """(out, out again on the same storage): see _BiasDropResLn2Fn."""
-    out, out2, sc, im = _BiasDropResLn2Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
+    out, out2, sc, im, nr = _BiasDropResLn2Fn.apply(x, bias, res, gamma, beta, eps, p_drop, seed)
     if im is not None:
-        _attach_img(out, im, sc)
+        _attach_img(out, im, sc, nr)
     elif sc is not None:
         _attach_rs(out, sc)
     return out, out2

@@ -322,14 +322,16 @@ int hopmi_bias_dropout_residual_layernorm_bwd_rs(const float* dout, const void* 
 /* ... and (round 5) the operand IMAGE itself: `image` (nullable; needs row_scales) receives `out` / `dx` times the row's power of two
  * as fp16 hi / lo images [2][M][D] -- hopmi_rows_image_f16's layout, the A operand of hopmi_gemm_f16x2_ab(_ep): the GEMM behind the
  * LayerNorm (QKV, FFN-in; in the backward the attention-output and FFN-out gradients) then stages both operands by LDS-DMA and
- * splits nothing in its k-loop (69 vs 84 us at N = 2304, 84 vs 103 at N = 3072, M = 4352). */
+ * splits nothing in its k-loop (59 vs 79 us at N = 2304, 77 vs 99 at N = 3072, M = 4352).  `row_norms` (nullable): [M] 2-norms of the
+ * rows (rounded up) -- what hopmi_gemm_f16x2_ab_img's a-priori bound is made of. */
 int hopmi_bias_dropout_residual_layernorm_fwd_im(const void* x, const float* bias, const float* res, int res_rows,
                                                  const float* gamma, const float* beta, float* out, void* out_t, float* xhat,
-                                                 float* rstd, float* row_scales, void* image, int M, int D, float eps, float p_drop,
-                                                 unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
-int hopmi_bias_dropout_residual_layernorm_bwd_im(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
-                                                 const float* gamma, void* dx, float* dres, float* row_scales, void* image, int M, int D,
+                                                 float* rstd, float* row_scales, void* image, float* row_norms, int M, int D, float eps,
                                                  float p_drop, unsigned seed, const unsigned* seed_dev, int dtype, void* stream);
+int hopmi_bias_dropout_residual_layernorm_bwd_im(const float* dout, const void* dout_t, const float* xhat, const float* rstd,
+                                                 const float* gamma, void* dx, float* dres, float* row_scales, void* image,
+                                                 float* row_norms, int M, int D, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                                 int dtype, void* stream);
 int hopmi_bert_attn_fwd_dt(const void* qkv, void* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev,
                            int dtype, void* stream);
 int hopmi_bert_attn_bwd_dt(const void* qkv, const void* d_out, void* dqkv, int B, int L, int H, float p_drop, unsigned seed,
@@ -464,6 +466,13 @@ int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* B
 /* ... with hopmi_gemm_f16x2's epilogues (0 bias, 1 GELU (+ C2 = the pre-activation), 2 GELU gradient against aux) and c_rowmax. */
 int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
                            const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream);
+/* ... handing its result on as the NEXT fp16-form GEMM's operand image: out_image (hopmi_rows_image_f16_bytes(M, N), N % 32 == 0) and
+ * out_scales [2][M]; C may be NULL (nothing else reads the fp32 values: BertIntermediate's output only feeds BertOutput.dense, the
+ * GELU-gradient product only the FFN-in activation gradient).  The row scales come from the bound |C[row][:]| <= row_norm[row] *
+ * bound_mul + bound_add (csrc/gemm.hip AbImageOut). */
+int hopmi_gemm_f16x2_ab_img(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
+                            const float* aux, int M, int N, int K, int epilogue, void* out_image, float* out_scales,
+                            const float* row_norm, float bound_mul, float bound_add, void* stream);
 
 /* The weight gradient of a linear layer in the same arithmetic (round 5; csrc/gemm_tn.hip):  C[N][K] (+)= A[M][N]^T . B[M][K]  -- both
  * operands ACTIVATIONS (A = dY, B = X, row-major with leading dimensions lda / ldb), contraction over their M rows; `batch`

@@ -1915,6 +1915,25 @@ def test_layernorm_operand_images_feed_the_lds_dma_gemm(monkeypatch):
     h1.add_(1.0)
     assert ops._take_img(h1, M, D) is None
 
+    # ---- the FFN with the intermediate handed over as an IMAGE (hopmi_gemm_f16x2_ab_img: row scales from the Cauchy-Schwarz bound,
+    # no fp32 gelu output): against float64, next to the split form -- forward and the gradient through both products
+    monkeypatch.setattr(ops, "IMG_FUSED", True)
+    bounds = (float(w1.norm(dim=1).max()) * 1.000001, float(b1.abs().max()), float(w2.norm(dim=0).max()) * 1.000001)
+    res_d = {}
+    for tag, bnd in (("image", bounds), ("split", None)):
+        xx = x.detach().clone().requires_grad_()
+        hh, _ = ops.bias_dropout_residual_layernorm2(xx, bias, res, gamma, beta, 1e-12, 0.0, 5)
+        assert ops._take_norms(hh, M) is not None
+        f = ops.split_ffn(hh, i1, i1t, b1, i2, i2t, 3072, D, 16, bounds=bnd)
+        f2, _ = ops.bias_dropout_residual_layernorm2(f, bias, hh, gamma, beta, 1e-12, 0.0, 6)
+        (f2 * go).sum().backward()
+        res_d[tag] = (hh.detach(), f.detach(), xx.grad.clone())
+    hh = res_d["split"][0].double()
+    f64 = torch.nn.functional.gelu(hh @ w1.double().t() + b1.double()) @ w2.double().t()
+    e_img, e_split = rel_err(res_d["image"][1].double(), f64), rel_err(res_d["split"][1].double(), f64)
+    assert e_img <= 2.0 * e_split + 1.2e-7, (e_img, e_split)
+    assert rel_err(res_d["image"][2], res_d["split"][2]) <= 2e-6
+
 
 @pytest.mark.parametrize("M,N,K", [(4352, 2100, 992), (4352, 768, 1536), (2048, 1700, 3400), (1000, 130, 70), (33, 5, 260)])
 def test_gemm_f16x2_tn_vs_float64(M, N, K):
