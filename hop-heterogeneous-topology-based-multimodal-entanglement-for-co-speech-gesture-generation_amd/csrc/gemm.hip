@@ -475,16 +475,21 @@ __device__ __forceinline__ int gswz(int row) { return (0x1230 >> (4 * ((row >> 2
 // stay normal fp16 numbers (f16_dev.h).
 struct AbImageOut { _Float16* image; float* scales; const float* row_norm; float mul, add; };
 
-template <int NP, int NBUF, bool F16 = false>
+// BM = 64 (fp16 form): 64-row tiles (8 waves of 32 x 32) for shapes whose 128-row tiling leaves most CUs idle (N = 768 at M = 2176:
+// 102 tiles -> 204).
+template <int NP, int NBUF, bool F16 = false, int BM = 128>
 __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Bimg,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N,
                                                              int K, int tiles_m, int tiles_n, const float* __restrict__ a_rows, int ep,
                                                              float* __restrict__ C2, const float* __restrict__ aux,
                                                              float* __restrict__ c_rowmax, AbImageOut io) {
-  __shared__ unsigned s_cmax[F16 ? 128 : 1];
+  static_assert(BM == 128 || (BM == 64 && F16), "64-row tiles: fp16 form only");
+  __shared__ unsigned s_cmax[F16 ? BM : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int IMG = 128 * 64;                    // bytes of one part image of one operand tile
-  constexpr int BUFB = 2 * NP * IMG;               // [A parts | B parts]
+  constexpr int IMG = 128 * 64;                    // bytes of one part image of the B operand tile
+  constexpr int IMGA = BM * 64;                    // ... of the A operand tile
+  constexpr int MI = BM / 32;                      // 16-row MFMA tiles per wave (wave rows = BM / 2)
+  constexpr int BUFB = NP * (IMGA + IMG);          // [A parts | B parts]
   int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wv >> 2, wc = wv & 3;
   const int lane = tid & 63, q = lane >> 4, n = lane & 15;
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   const int tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
   if (idx >= per + (xcd < rem ? 1 : 0)) return;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * 128, n0 = tn * GN;
+  const int m0 = tm * BM, n0 = tn * GN;
 
   // staging: wave wv moves rows 16 wv .. +15 of every (operand, part) image; lane -> (row, LDS slot); source slot swizzled
   const int srow = 16 * wv + (lane >> 2), sslot = (lane & 3) ^ gswz(lane >> 2);
@@ -502,9 +507,10 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   // bf16 forms: row-major)
   const int Np = F16 ? f16_np(N) : N;
   const int arow = min(m0 + srow, M - 1);
-  const __bf16* a_src = F16 ? Aimg + (size_t)tm * (K >> 5) * 4096 + (arow - m0) * 32 + 8 * sslot : Aimg + (size_t)arow * K + 8 * sslot;
+  // (a 64-row tile is half of a 128-row block of the image: rows (m0 & 127) .. + 63)
+  const __bf16* a_src = F16 ? Aimg + (size_t)(m0 >> 7) * (K >> 5) * 4096 + (arow - (m0 & ~127)) * 32 + 8 * sslot : Aimg + (size_t)arow * K + 8 * sslot;
   const __bf16* b_src = F16 ? Bimg + (size_t)tn * (K >> 5) * 4096 + srow * 32 + 8 * sslot : Bimg + (size_t)(n0 + srow) * K + 8 * sslot;
-  const size_t a_part = F16 ? (size_t)tiles_m * 128 * K : (size_t)M * K, b_part = (size_t)Np * K;
+  const size_t a_part = F16 ? (size_t)((M + 127) / 128) * 128 * K : (size_t)M * K, b_part = (size_t)Np * K;
   const size_t kstride = F16 ? 4096 : GK;
   const float* inv_b = reinterpret_cast<const float*>(Bimg + (size_t)NP * Np * K);
   auto stage = [&](int kt) {
@@ -512,44 +518,48 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
     const size_t k0 = kt * kstride;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + p * a_part + k0),
-                                       (__attribute__((address_space(3))) void*)(dst + p * IMG), 16, 0, 0);
+      if (BM == 128 || wv < 4)                         // (64-row tiles: waves 0-3 move the A rows; wave-uniform)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + p * a_part + k0),
+                                         (__attribute__((address_space(3))) void*)(dst + p * IMGA), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + p * b_part + k0),
-                                       (__attribute__((address_space(3))) void*)(dst + (NP + p) * IMG), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + NP * IMGA + p * IMG), 16, 0, 0);
     }
   };
 
-  f32x4 acc[4][2];
+  f32x4 acc[MI][2];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
+  // (64-row tiles: waves 4-7 issue half the DMA instructions of waves 0-3; the counted waits below assume 2 NP per tile, which
+  // over-waits for those waves -- harmless)
+  constexpr int PER_TILE = 2 * NP;
 
   const int nk = K / GK;
 #pragma unroll
   for (int pre = 0; pre < NBUF - 1; ++pre)
     if (pre < nk) stage(pre);
-  if (nk > NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * (NBUF - 2)) : "memory");
+  if (nk > NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BM == 128 ? PER_TILE : NP) * (NBUF - 2)) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  const int fa_off = (64 * wr + n) * 64 + ((q ^ gswz(n)) << 4);          // (the swizzle only depends on n: row = 16 k + n)
-  const int fb_off = NP * IMG + (32 * wc + n) * 64 + ((q ^ gswz(n)) << 4);
+  const int fa_off = ((BM / 2) * wr + n) * 64 + ((q ^ gswz(n)) << 4);          // (the swizzle only depends on n: row = 16 k + n)
+  const int fb_off = NP * IMGA + (32 * wc + n) * 64 + ((q ^ gswz(n)) << 4);
   for (int kt = 0; kt < nk; ++kt) {
     const bool ahead = kt + NBUF - 1 < nk;
     if (ahead) stage(kt + NBUF - 1);
     const unsigned char* buf = smem_raw + (kt % NBUF) * BUFB;
-    u32x4 af[4][NP];
+    u32x4 af[MI][NP];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) af[mi][p] = *reinterpret_cast<const u32x4*>(buf + fa_off + p * IMG + mi * 16 * 64);
+      for (int p = 0; p < NP; ++p) af[mi][p] = *reinterpret_cast<const u32x4*>(buf + fa_off + p * IMGA + mi * 16 * 64);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       u32x4 bf[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const u32x4*>(buf + fb_off + p * IMG + ni * 16 * 64);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
         f32x4 c = acc[mi][ni];
 #pragma unroll
         for (int s = NP - 1; s >= 0; --s)
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
       }
     }
     // tile kt + 1 must have landed (the NBUF - 2 youngest tiles may stay in flight); every wave is done reading tile kt
-    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * (NBUF - 2)) : "memory");
+    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BM == 128 ? PER_TILE : NP) * (NBUF - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -567,11 +577,11 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 
   // epilogue (the split form's, gemm_split_kernel: bias / GELU (+ the pre-activation) / GELU gradient; the row maxima of what is
   // written per column tile for the GEMM that consumes C)
-  if (F16 && c_rowmax != nullptr && tid < 128) s_cmax[tid] = 0u;
+  if (F16 && c_rowmax != nullptr && tid < BM) s_cmax[tid] = 0u;
   if (F16 && c_rowmax != nullptr) __syncthreads();
-  unsigned rmx[F16 ? 4 : 1][4];
+  unsigned rmx[F16 ? MI : 1][4];
 #pragma unroll
-  for (int mi = 0; mi < (F16 ? 4 : 1); ++mi)
+  for (int mi = 0; mi < (F16 ? MI : 1); ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) rmx[mi][r] = 0u;
 #pragma unroll
@@ -581,10 +591,10 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
     const float bv = bias != nullptr ? bias[col] : 0.f;
     const float sb = F16 ? inv_b[col] : 1.f;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + 64 * wr + 16 * mi + 4 * q + r;
+        const int row = m0 + (BM / 2) * wr + 16 * mi + 4 * q + r;
         if (row < M) {
           const size_t at = (size_t)row * N + col;
           const float h = F16 ? acc[mi][ni][r] * a_rows[M + row] * sb + bv : acc[mi][ni][r] + bv;
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
             const _Float16 hi = (_Float16)xs;
             const size_t ia = f16_blk(row, col, f16_np(N) >> 5);
             io.image[ia] = hi;
-            io.image[(size_t)tiles_m * 128 * f16_np(N) + ia] = (_Float16)(xs - (float)hi);
+            io.image[(size_t)((M + 127) / 128) * 128 * f16_np(N) + ia] = (_Float16)(xs - (float)hi);
             if (tn == 0 && ni == 0 && n == 0) { io.scales[row] = __uint_as_float(sbits); io.scales[M + row] = inv_scale(sbits); }
           }
         }
@@ -611,35 +621,35 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   }
   if (F16 && c_rowmax != nullptr) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         unsigned v = rmx[mi][r];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
-        if (n == 0) atomicMax(&s_cmax[64 * wr + 16 * mi + 4 * q + r], v);
+        if (n == 0) atomicMax(&s_cmax[(BM / 2) * wr + 16 * mi + 4 * q + r], v);
       }
     __syncthreads();
-    if (tid < 128 && m0 + tid < M) c_rowmax[(size_t)tn * M + m0 + tid] = __uint_as_float(s_cmax[tid]);
+    if (tid < BM && m0 + tid < M) c_rowmax[(size_t)tn * M + m0 + tid] = __uint_as_float(s_cmax[tid]);
   }
 }
 
-template <int NP, int NBUF, bool F16 = false>
+template <int NP, int NBUF, bool F16 = false, int BM = 128>
 static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
                            const float* a_rows = nullptr, int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr,
                            float* c_rowmax = nullptr, AbImageOut io = AbImageOut{nullptr, nullptr, nullptr, 0.f, 0.f}) {
-  const int tiles_m = (M + 127) / 128, tiles_n = (N + GN - 1) / GN;
-  const size_t lds = (size_t)NBUF * 2 * NP * 128 * 64;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + GN - 1) / GN;
+  const size_t lds = (size_t)NBUF * NP * (BM + 128) * 64;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<NP, NBUF, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<NP, NBUF, F16, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF, F16>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
+  hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF, F16, BM>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
                      static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n, a_rows, ep, C2, aux, c_rowmax, io);
 }
 
@@ -741,7 +751,10 @@ extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales,
   // K = 3072 74 / 79, K = 2304 58 / 60); HOPMI_GEMM_NBUF=3 keeps the three-buffer form reachable
   const int forced = env_int("HOPMI_GEMM_NBUF", 0);
   const int nbuf = forced == 3 ? 3 : 2;
-  if (nbuf == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
+  // 64-row tiles when 128-row tiles would leave most of the chip idle (as the split form's mode 3)
+  const bool half = ((M + 127) / 128) * ((N + GN - 1) / GN) < 160 && env_int("HOPMI_GEMM_AB_BM64", 1) != 0;
+  if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
+  else if (nbuf == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   return check_launch("hopmi_gemm_f16x2_ab");
 }
@@ -760,7 +773,9 @@ extern "C" int hopmi_gemm_f16x2_ab_img(const void* Aimage, const float* a_scales
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const AbImageOut io{static_cast<_Float16*>(out_image), out_scales, row_norm, bound_mul, bound_add};
-  if (env_int("HOPMI_GEMM_NBUF", 0) == 3) launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
+  const bool half = ((M + 127) / 128) * ((N + GN - 1) / GN) < 160 && env_int("HOPMI_GEMM_AB_BM64", 1) != 0;
+  if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
+  else if (env_int("HOPMI_GEMM_NBUF", 0) == 3) launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   else launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   return check_launch("hopmi_gemm_f16x2_ab_img");
 }

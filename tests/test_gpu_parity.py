@@ -1714,7 +1714,7 @@ def test_gemm_f16x2_epilogue_row_maxima(M, N, K, ep):
         assert torch.equal(ops._split_gemm(c, img2, None, 256, N, 16, a_part=(cm, P)), ops._split_gemm(c, img2, None, 256, N, 16))
 
 
-@pytest.mark.parametrize("M,N,K", [(4352, 768, 768), (4352, 768, 3072), (1100, 700, 2304), (1030, 130, 64)])
+@pytest.mark.parametrize("M,N,K", [(4352, 768, 768), (4352, 768, 3072), (2176, 768, 3072), (1100, 700, 2304), (1030, 130, 64)])
 def test_gemm_f16x2_lds_dma_form_equals_the_split_form(M, N, K, monkeypatch):
     """hopmi_rows_image_f16 + hopmi_gemm_f16x2_ab (both operands as fp16 hi / lo images, tiles staged by LDS-DMA) against
     hopmi_row_scales + hopmi_gemm_f16x2 (activations split in the k-loop): the same scales, the same three terms in the same order
