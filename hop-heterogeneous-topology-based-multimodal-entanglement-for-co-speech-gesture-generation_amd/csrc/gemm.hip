@@ -734,6 +734,18 @@ extern "C" int hopmi_rows_image_f16(const float* A, int M, int K, void* image, f
   return check_launch("hopmi_rows_image_f16");
 }
 
+// 64-row tiles for the LDS-DMA form: where 128-row tiles would leave most of the chip idle (< 160 tiles), and up to ~700 of them --
+// more, smaller workgroups in flight hide the staging latency better (tools/probes/bench_ab.py, M = 4352, us, 128 / 64 rows: N = 768
+// K = 768 27.6 / 23.8, N = 2304 60.4 / 56.5, N = 768 K = 2304 59.8 / 56.2, N = 768 K = 3072 75.5 / 75.6; N = 3072 (816 tiles) 78.5 /
+// 83.0: the B panel is re-read twice as often).  HOPMI_GEMM_AB_BM64: 0 never, 2 always.
+static bool ab_half_tiles(int M, int N) {
+  const int mode = env_int("HOPMI_GEMM_AB_BM64", 1);
+  if (mode == 0) return false;
+  if (mode == 2) return true;
+  (void)M; (void)N;
+  return true;       // (in the training step 64-row tiles win at every shape: 15.01 -> 14.81 ms per step against 128-row tiles, A/B on one box)
+}
+
 extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
                                       const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream) {
   if (!Aimage || !a_scales || !Bimage || !C) { set_error("hopmi_gemm_f16x2_ab: null pointer argument"); return HOPMI_EINVAL; }
@@ -752,8 +764,9 @@ extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales,
   const int forced = env_int("HOPMI_GEMM_NBUF", 0);
   const int nbuf = forced == 3 ? 3 : 2;
   // 64-row tiles when 128-row tiles would leave most of the chip idle (as the split form's mode 3)
-  const bool half = ((M + 127) / 128) * ((N + GN - 1) / GN) < 160 && env_int("HOPMI_GEMM_AB_BM64", 1) != 0;
-  if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
+  const bool half = ab_half_tiles(M, N);
+  if (half && nbuf == 3) launch_gemm_ab<2, 3, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
+  else if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else if (nbuf == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   return check_launch("hopmi_gemm_f16x2_ab");
@@ -773,8 +786,9 @@ extern "C" int hopmi_gemm_f16x2_ab_img(const void* Aimage, const float* a_scales
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const AbImageOut io{static_cast<_Float16*>(out_image), out_scales, row_norm, bound_mul, bound_add};
-  const bool half = ((M + 127) / 128) * ((N + GN - 1) / GN) < 160 && env_int("HOPMI_GEMM_AB_BM64", 1) != 0;
-  if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
+  const bool half = ab_half_tiles(M, N);
+  if (half && env_int("HOPMI_GEMM_NBUF", 0) == 3) launch_gemm_ab<2, 3, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
+  else if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   else if (env_int("HOPMI_GEMM_NBUF", 0) == 3) launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   else launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   return check_launch("hopmi_gemm_f16x2_ab_img");
