@@ -473,6 +473,10 @@ __device__ __forceinline__ int gswz(int row) { return (0x1230 >> (4 * ((row >> 2
 // the LayerNorm kernel that produced it; mul = the largest 2-norm of a row of the weight, times the epilogue's Lipschitz constant;
 // add = the largest |bias|).  Typical elements sit 2^3 ... 2^6 below such a bound, well inside the 2^17 window in which their lo parts
 // stay normal fp16 numbers (f16_dev.h).
+// (HOPMI_AB_EXP: compile-time timing experiments on the k-loop -- wrong results, same schedule; tools/probes/ab_limits.py)
+#ifndef HOPMI_AB_EXP
+#define HOPMI_AB_EXP 0
+#endif
 struct AbImageOut { _Float16* image; float* scales; const float* row_norm; float mul, add; };
 
 // BM = 64 (fp16 form): 64-row tiles (8 waves of 32 x 32) for shapes whose 128-row tiling leaves most CUs idle (N = 768 at M = 2176:
@@ -546,25 +550,46 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   const int fb_off = NP * IMGA + (32 * wc + n) * 64 + ((q ^ gswz(n)) << 4);
   for (int kt = 0; kt < nk; ++kt) {
     const bool ahead = kt + NBUF - 1 < nk;
+#if HOPMI_AB_EXP == 1                                  // (timing experiment: no DMA in the k-loop)
+    if (ahead && K < 0) stage(kt + NBUF - 1);
+#else
     if (ahead) stage(kt + NBUF - 1);
+#endif
     const unsigned char* buf = smem_raw + (kt % NBUF) * BUFB;
     u32x4 af[MI][NP];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) af[mi][p] = *reinterpret_cast<const u32x4*>(buf + fa_off + p * IMGA + mi * 16 * 64);
+      for (int p = 0; p < NP; ++p) {
+#if HOPMI_AB_EXP == 3                                  // (timing experiment: no fragment reads)
+        af[mi][p] = u32x4{(unsigned)(lane + kt), (unsigned)mi, (unsigned)p, 0x3c003c00u};
+#else
+        af[mi][p] = *reinterpret_cast<const u32x4*>(buf + fa_off + p * IMGA + mi * 16 * 64);
+#endif
+      }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       u32x4 bf[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const u32x4*>(buf + fb_off + p * IMG + ni * 16 * 64);
+      for (int p = 0; p < NP; ++p) {
+#if HOPMI_AB_EXP == 3
+        bf[p] = u32x4{(unsigned)(lane ^ kt), (unsigned)ni, (unsigned)p, 0x3c003c00u};
+#else
+        bf[p] = *reinterpret_cast<const u32x4*>(buf + fb_off + p * IMG + ni * 16 * 64);
+#endif
+      }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         f32x4 c = acc[mi][ni];
+#if HOPMI_AB_EXP == 2                                  // (timing experiment: no matrix instructions)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) c[p] += __uint_as_float(af[mi][p][0] ^ bf[p][1]);
+#else
 #pragma unroll
         for (int s = NP - 1; s >= 0; --s)
 #pragma unroll
           for (int i = 0; i <= s; ++i) c = F16 ? mfma_f16(af[mi][i], bf[s - i], c) : mfma_bf16(af[mi][i], bf[s - i], c);
+#endif
         acc[mi][ni] = c;
       }
     }
