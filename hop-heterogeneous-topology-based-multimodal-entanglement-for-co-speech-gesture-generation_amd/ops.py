@@ -461,10 +461,13 @@ IMG_FUSED = __import__("os").environ.get("HOPMI_IMG_FUSED", "1") != "0"
 # BertIntermediate's product hands its output to BertOutput.dense as an operand image (and the backward likewise): A/B HOPMI_FFN_IMG=0
 FFN_IMG = __import__("os").environ.get("HOPMI_FFN_IMG", "1") != "0"
 IMG_MIN_ROWS = 1024     # row scales from the producing kernels (0: always a pass of their own)
-# the LDS-DMA form of the fp16 GEMM (_split_gemm_ep): faster back to back (24 vs 30 us, 71 vs 92), bit-identical -- and no gain in
-# the step (15.96 vs 15.96 ms, A/B twice on one box: the image pass it needs costs what the k-loop split it saves did), so off
-GEMM_AB = __import__("os").environ.get("HOPMI_GEMM_AB", "0") == "1"
-GEMM_AB_MAX_N = 1024
+# An operand nobody wrote an image of (the attention's output and gradient, the embedding LayerNorm's output): ONE pass takes the row
+# scales and writes the fp16 images (hopmi_rows_image_f16: 6.6 us at K = 768, 19 us at K = 2304, M = 4352) and the LDS-DMA form
+# multiplies -- bit-identical to row scales + the split form.  Round 4 measured no gain in the step; with the tile-blocked images and
+# 64-row tiles of round 5 it is 50-90 us per configs[1] step (kernel time 14.41 -> 14.36 ms, the step 14.81 -> 14.74 ms, A/B on one
+# box), so it is on, for N up to the QKV width.  HOPMI_GEMM_AB=0: row scales + split form.
+GEMM_AB = __import__("os").environ.get("HOPMI_GEMM_AB", "1") == "1"
+GEMM_AB_MAX_N = int(__import__("os").environ.get("HOPMI_GEMM_AB_MAX_N", "2304"))
 
 
 def _split_gemm(a2d, img, bias, N, K, parts, a_part=None, out=None, a_img=None):
