@@ -91,6 +91,8 @@ SIGNATURES = {
     "hopmi_gemm_f16x2_ab": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "hopmi_gemm_f16x2_ab_ep": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gemm_f16x2_tiles_n": (_I, [_I]),
+    "hopmi_gemm_f16x2_ab_splitk_ws_floats": (ctypes.c_size_t, [_I, _I, _I]),
+    "hopmi_gemm_f16x2_ab_splitk": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "hopmi_gemm_f16x2_tn_ws_floats": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "hopmi_gemm_f16x2_tn": (_I, [_VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _I, _I, _I, _I, _I,
                                 _VP]),

@@ -135,6 +135,72 @@ __global__ __launch_bounds__(256) void f16_rows_image_kernel(const float* __rest
   }
 }
 
+// ... for any even K and 8-byte aligned rows (the mapping layer's weight: K = 30522): 8-byte loads, columns padded with zeros to Kp =
+// K rounded up to the 32-wide k-step.  Workgroup = 4 rows: pass 1 one wave per row (maximum); pass 2 every wave instruction covers
+// the 4 rows x one 32-column block -- 4 x 64 contiguous bytes of the tile-blocked image, whole 128-byte lines (a wave per row would
+// write 64-byte pieces whose neighbours belong to other waves: 242 us for the 183 MB mapping weight, now ~100)
+__global__ __launch_bounds__(256) void f16_rows_image_ragged_kernel(const float* __restrict__ A, int M, int K, int Kp, unsigned* __restrict__ img,
+                                                                    float* __restrict__ scales) {
+  __shared__ float s_sc[4];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row0 = blockIdx.x * 4;
+  {
+    const int row = row0 + wv;
+    unsigned m = 0;
+    if (row < M) {
+      const float2* src = reinterpret_cast<const float2*>(A + (size_t)row * K);
+      for (int i = lane; i < K / 2; i += 64) {
+        const float2 v = src[i];
+        m = max(m, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu));
+      }
+      m = wave_max_u32(m);
+    }
+    const unsigned sb = scale_bits_for_max(m);
+    if (lane == 0) {
+      s_sc[wv] = __uint_as_float(sb);
+      if (row < M) { scales[row] = __uint_as_float(sb); scales[M + row] = inv_scale(sb); }
+    }
+  }
+  __syncthreads();
+  _Float16* hi = reinterpret_cast<_Float16*>(img);
+  _Float16* lo = hi + (size_t)((M + 127) / 128 * 128) * Kp;
+  const int KB = Kp >> 5;
+  const int r = lane >> 4, c2 = (lane & 15) * 2;         // lane -> (row of the four, column pair of the block)
+  const int row = row0 + r;
+  if (row >= M) return;
+  const float sc = s_sc[r];
+  const float* src = A + (size_t)row * K;
+  for (int kb = wv; kb < KB; kb += 4) {
+    const int k = 32 * kb + c2;
+    unsigned parts[2] = {0u, 0u};
+    if (k < K) {
+      const float2 v = *reinterpret_cast<const float2*>(src + k);
+      split_pair_f16(v.x * sc, v.y * sc, parts);
+    }
+    const size_t at = f16_blk(row, k, KB);
+    *reinterpret_cast<unsigned*>(hi + at) = parts[0];
+    *reinterpret_cast<unsigned*>(lo + at) = parts[1];
+  }
+}
+
+// C[m][n] = slab 0 + slab 1 + ... (index order) + row_bias[m]: the split-K partial products of the LDS-DMA form
+__global__ __launch_bounds__(256) void gemm_splitk_sum_kernel(const float* __restrict__ slabs, int splits, const float* __restrict__ row_bias,
+                                                              float* __restrict__ C, int M, int N) {
+  const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const size_t total = (size_t)M * N;
+  if (idx >= total) return;
+  float4 v = *reinterpret_cast<const float4*>(slabs + idx);
+  for (int p = 1; p < splits; ++p) {
+    const float4 t = *reinterpret_cast<const float4*>(slabs + (size_t)p * total + idx);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  if (row_bias != nullptr) {
+    const float b = row_bias[idx / N];                // (N % 4 == 0: the four values share a row)
+    v.x += b; v.y += b; v.z += b; v.w += b;
+  }
+  *reinterpret_cast<float4*>(C + idx) = v;
+}
+
 // W [N][K] (row-major, K % 2 == 0) -> its image: one wave per image row n < Np (two passes over the row: maximum, then split)
 __global__ __launch_bounds__(256) void f16_prepare_rows_kernel(const float* __restrict__ W, int N, int K, int Np, int Kp,
                                                                unsigned* __restrict__ img, float* __restrict__ inv_out) {
@@ -512,8 +578,9 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   const int Np = F16 ? f16_np(N) : N;
   const int arow = min(m0 + srow, M - 1);
   // (a 64-row tile is half of a 128-row block of the image: rows (m0 & 127) .. + 63)
-  const __bf16* a_src = F16 ? Aimg + (size_t)(m0 >> 7) * (K >> 5) * 4096 + (arow - (m0 & ~127)) * 32 + 8 * sslot : Aimg + (size_t)arow * K + 8 * sslot;
-  const __bf16* b_src = F16 ? Bimg + (size_t)tn * (K >> 5) * 4096 + srow * 32 + 8 * sslot : Bimg + (size_t)(n0 + srow) * K + 8 * sslot;
+  const __bf16* a_src0 = F16 ? Aimg + (size_t)(m0 >> 7) * (K >> 5) * 4096 + (arow - (m0 & ~127)) * 32 + 8 * sslot : Aimg + (size_t)arow * K + 8 * sslot;
+  const __bf16* b_src0 = F16 ? Bimg + (size_t)tn * (K >> 5) * 4096 + srow * 32 + 8 * sslot : Bimg + (size_t)(n0 + srow) * K + 8 * sslot;
+  const __bf16 *a_src = a_src0, *b_src = b_src0;
   const size_t a_part = F16 ? (size_t)((M + 127) / 128) * 128 * K : (size_t)M * K, b_part = (size_t)Np * K;
   const size_t kstride = F16 ? 4096 : GK;
   const float* inv_b = reinterpret_cast<const float*>(Bimg + (size_t)NP * Np * K);
@@ -539,7 +606,12 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   // over-waits for those waves -- harmless)
   constexpr int PER_TILE = 2 * NP;
 
-  const int nk = K / GK;
+  // split-K (gridDim.y > 1; hopmi_gemm_f16x2_ab_splitk): slab y multiplies k-steps [nk_all y / S, nk_all (y + 1) / S) into C + y M N
+  const int nk_all = K / GK, ksp = gridDim.y, ky = blockIdx.y;
+  const int kt0 = (int)((long long)nk_all * ky / ksp), nk = (int)((long long)nk_all * (ky + 1) / ksp) - kt0;
+  a_src += (size_t)kt0 * kstride;
+  b_src += (size_t)kt0 * kstride;
+  if (C != nullptr) C += (size_t)ky * M * N;
 #pragma unroll
   for (int pre = 0; pre < NBUF - 1; ++pre)
     if (pre < nk) stage(pre);
@@ -746,17 +818,71 @@ extern "C" int hopmi_row_scales(const float* A, int M, int K, float* scales, voi
 }
 
 extern "C" size_t hopmi_rows_image_f16_bytes(int M, int K) {
-  return (M > 0 && K > 0 && K % GK == 0) ? (size_t)2 * ((M + 127) / 128 * 128) * K * sizeof(_Float16) : 0;
+  // (K % 32 == 0: the image has K columns; any other even K: f16_kp(K) columns, the pad zero)
+  return (M > 0 && K > 0 && K % 2 == 0) ? (size_t)2 * ((M + 127) / 128 * 128) * f16_kp(K) * sizeof(_Float16) : 0;
 }
 
 extern "C" int hopmi_rows_image_f16(const float* A, int M, int K, void* image, float* scales, void* stream) {
-  if (!A || !image || !scales || M <= 0 || K <= 0 || (K % GK) || (reinterpret_cast<uintptr_t>(A) & 15)) {
-    set_error("hopmi_rows_image_f16: need A (16-byte aligned), image (hopmi_rows_image_f16_bytes), scales [2 M], K %% 32 == 0 (M=%d K=%d)", M, K);
+  if (!A || !image || !scales || M <= 0 || K <= 0 || (K & 1) || (reinterpret_cast<uintptr_t>(A) & 7)) {
+    set_error("hopmi_rows_image_f16: need A (8-byte aligned), image (hopmi_rows_image_f16_bytes), scales [2 M], even K (M=%d K=%d)", M, K);
     return HOPMI_EINVAL;
   }
-  hipLaunchKernelGGL(f16_rows_image_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), A, M, K,
-                     static_cast<unsigned*>(image), scales);
+  if (K % GK == 0 && !(reinterpret_cast<uintptr_t>(A) & 15))
+    hipLaunchKernelGGL(f16_rows_image_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), A, M, K,
+                       static_cast<unsigned*>(image), scales);
+  else
+    hipLaunchKernelGGL(f16_rows_image_ragged_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), A, M, K, f16_kp(K),
+                       static_cast<unsigned*>(image), scales);
   return check_launch("hopmi_rows_image_f16");
+}
+
+// Split-K of the LDS-DMA form for a product with few tiles and a huge contraction (the mapping layer's S = W_map E + b: 1500 x 768
+// outputs, K = 30522): C = A Bt^T + row_bias[:, None], A and Bt as images with f16_kp(K) columns.  `splits` slabs of partial products in
+// `workspace`, added in index order by a second launch (bitwise reproducible).
+static int ab_splits(int M, int N, int K) {
+  const int forced = env_int("HOPMI_GEMM_AB_SPLITS", 0);
+  const int nk = f16_kp(K) / GK;
+  const int tiles = ((M + 63) / 64) * ((N + GN - 1) / GN);
+  int sp = forced > 0 ? forced : (768 + tiles - 1) / tiles;          // about one round of three workgroups per CU
+  if (sp > nk / 16) sp = nk / 16;                                    // at least 16 k-steps per slab
+  if (sp < 1) sp = 1;
+  if (sp > 64) sp = 64;
+  return sp;
+}
+
+extern "C" size_t hopmi_gemm_f16x2_ab_splitk_ws_floats(int M, int N, int K) {
+  return (M > 0 && N > 0 && K > 0) ? (size_t)ab_splits(M, N, K) * M * N : 0;
+}
+
+extern "C" int hopmi_gemm_f16x2_ab_splitk(const void* Aimage, const float* a_scales, const void* Bimage, const float* row_bias, float* C,
+                                          int M, int N, int K, float* workspace, void* stream) {
+  if (!Aimage || !a_scales || !Bimage || !C || !workspace) { set_error("hopmi_gemm_f16x2_ab_splitk: null pointer argument"); return HOPMI_EINVAL; }
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 1) || (N & 3)) {
+    set_error("hopmi_gemm_f16x2_ab_splitk: need even K and N %% 4 == 0 (M=%d N=%d K=%d)", M, N, K);
+    return HOPMI_EINVAL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int Kp = f16_kp(K), sp = ab_splits(M, N, K);
+  {
+    constexpr int BM = 64;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + GN - 1) / GN;
+    const size_t lds = (size_t)2 * 2 * (BM + 128) * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<2, 2, true, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        (void)hipGetLastError();
+      attr_done = true;
+    }
+    const int grid = ((tiles_m * tiles_n + 7) / 8) * 8;
+    hipLaunchKernelGGL((gemm_split_ab_kernel<2, 2, true, BM>), dim3(grid, sp), dim3(GT), lds, st, static_cast<const __bf16*>(Aimage),
+                       static_cast<const __bf16*>(Bimage), static_cast<const float*>(nullptr), workspace, M, N, Kp, tiles_m, tiles_n, a_scales,
+                       (int)EP_BIAS, static_cast<float*>(nullptr), static_cast<const float*>(nullptr), static_cast<float*>(nullptr),
+                       AbImageOut{nullptr, nullptr, nullptr, 0.f, 0.f});
+  }
+  if (int e = check_launch("hopmi_gemm_f16x2_ab_splitk")) return e;
+  hipLaunchKernelGGL(gemm_splitk_sum_kernel, dim3((unsigned)(((size_t)M * N / 4 + 255) / 256)), dim3(256), 0, st, workspace, sp, row_bias, C, M, N);
+  return check_launch("hopmi_gemm_f16x2_ab_splitk(sum)");
 }
 
 // 64-row tiles for the LDS-DMA form: where 128-row tiles would leave most of the chip idle (< 160 tiles), and up to ~700 of them --

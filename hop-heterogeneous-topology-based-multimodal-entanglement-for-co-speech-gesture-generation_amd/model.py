@@ -78,9 +78,13 @@ class _SplitKAffine(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, W, E, b, ks):
-        kc = W.shape[1] // ks
-        S = torch.bmm(W.view(W.shape[0], ks, kc).transpose(0, 1), E.view(ks, kc, E.shape[1])).sum(0)
-        S += b.unsqueeze(1)
+        if ops.f16_affine_splitk_ok(W, E):
+            # (round 5) the fp16 hi/lo form with the contraction cut into slabs: E^T's image cached under the frozen E
+            S = ops.f16_affine_splitk(W, E, b)
+        else:
+            kc = W.shape[1] // ks
+            S = torch.bmm(W.view(W.shape[0], ks, kc).transpose(0, 1), E.view(ks, kc, E.shape[1])).sum(0)
+            S += b.unsqueeze(1)
         ctx.save_for_backward(W, E)
         ctx.E_obj = E                       # (the object itself: the cached fp16-form image of the frozen E is keyed on it)
         return S

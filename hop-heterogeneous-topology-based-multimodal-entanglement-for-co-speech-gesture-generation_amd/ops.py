@@ -1046,6 +1046,44 @@ def f16_mm_nt(a2d, w, owners, out=None):
 
 F16_LINEAR_MIN_ROWS = 1024          # below: the 128-row tiles leave the chip empty
 
+
+# The mapping layer's forward S = W_map E + b[:, None] (HOP.py:200; 1500 x 768 outputs, K = vocab = 30522) on the LDS-DMA form with
+# the contraction split into slabs (hopmi_gemm_f16x2_ab_splitk) instead of the library's strided-batched fp32 GEMM.  Built, parity-
+# tested (test_mapping_forward_split_k_vs_float64) and OFF by default: back to back 523 us against the library path's 605
+# (tools/probes/bench_mapfwd.py: image of W 189, product + slab sum 228), kernel time per step 14.36 -> 14.24 ms under the profiler --
+# but the RECORDED step is slower with it, reproducibly (14.84 / 14.87 / 14.93 -> 15.47 / 15.39 / 15.39 ms, A/B on two boxes; the
+# eager step does not move): W's image is 183 MB written and read back inside every step, and the idle time between the step's
+# kernels grows by more than the kernels shrink.  Not understood further; HOPMI_F16_SPLITK=1 enables it.
+F16_SPLITK = __import__("os").environ.get("HOPMI_F16_SPLITK", "0") == "1"
+
+
+def f16_affine_splitk_ok(W, E) -> bool:
+    """W (M, K) trainable, E (K, N) frozen: does W @ E + b[:, None] go to hopmi_gemm_f16x2_ab_splitk?"""
+    return bool(F16_SPLITK and F16_LINEAR and GEMM_PARTS == F16_PARTS and W.is_cuda and W.dtype == torch.float32 and E.dtype == torch.float32
+                and W.dim() == 2 and E.dim() == 2 and not E.requires_grad and not torch.is_autocast_enabled("cuda")
+                and W.shape[1] % 2 == 0 and E.shape[1] % 4 == 0 and W.stride(1) == 1 and W.stride(0) == W.shape[1]
+                and W.data_ptr() % 8 == 0 and float(W.numel()) * E.shape[1] >= 4 * F16_LINEAR_MIN_MNK and W.shape[1] >= 4096)
+
+
+def f16_affine_splitk(W, E, b):
+    """W (M, K) @ E (K, N) + b[:, None] (no autograd): one pass writes the fp16 hi/lo image of W's rows (W changes every optimizer
+    step), E^T's image is cached under the frozen E, the split-K LDS-DMA form multiplies."""
+    M, K = W.shape
+    N = E.shape[1]
+    L = _lib.lib()
+    Wd = _dev_f32(W.detach(), "W")
+    img_b = f16_weight_image(E, transpose=True, owners=(E,))
+    img_a = torch.empty(L.hopmi_rows_image_f16_bytes(M, K), dtype=torch.uint8, device=W.device)
+    sc = torch.empty(2, M, dtype=torch.float32, device=W.device)
+    _lib.check(L.hopmi_rows_image_f16(Wd.data_ptr(), M, K, img_a.data_ptr(), sc.data_ptr(), _stream()), "hopmi_rows_image_f16")
+    ws = torch.empty(L.hopmi_gemm_f16x2_ab_splitk_ws_floats(M, N, K), dtype=torch.float32, device=W.device)
+    out = torch.empty(M, N, dtype=torch.float32, device=W.device)
+    bd = None if b is None else _dev_f32(b.detach(), "b")
+    _lib.check(_timed("gemm_split", 4 * (M * K + N * K + M * N), 2 * M * N * K,
+                      lambda: L.hopmi_gemm_f16x2_ab_splitk(img_a.data_ptr(), sc.data_ptr(), img_b.data_ptr(), _ptr(bd), out.data_ptr(), M, N, K,
+                                                           ws.data_ptr(), _stream())), "hopmi_gemm_f16x2_ab_splitk")
+    return out
+
 # dW = dY^T X on hopmi_gemm_f16x2_tn (csrc/gemm_tn.hip) instead of the library's fp32 GEMM: from M N K = 2e9 on (below, the row-scale
 # passes and the slab sum eat the gain)
 F16_TN = __import__("os").environ.get("HOPMI_F16_TN", "1") != "0"

@@ -459,7 +459,8 @@ int hopmi_gemm_f16x2(const float* A, const float* a_scales, int a_parts, const v
  * [2][M] row-scale pairs in one pass (what hopmi_row_scales + the in-kernel split do together), hopmi_gemm_f16x2_ab multiplies
  * (K % 32 == 0, any N; bias epilogue only).  Bit-identical to hopmi_gemm_f16x2; faster where one 128 x 128 tile per CU covers the
  * problem (N = 768 at M = 4352: 24 vs 30 us, K = 3072: 71 vs 92). */
-size_t hopmi_rows_image_f16_bytes(int M, int K);     /* tile-blocked, rows padded to 128 (csrc/gemm.hip f16_blk); K % 32 == 0 */
+size_t hopmi_rows_image_f16_bytes(int M, int K);     /* tile-blocked, rows padded to 128 (csrc/gemm.hip f16_blk); even K: columns padded
+                                                         with zeros to the 32-wide k-step (8-byte loads when K % 32 != 0) */
 int hopmi_rows_image_f16(const float* A, int M, int K, void* image, float* scales, void* stream);
 int hopmi_gemm_f16x2_ab(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, int M, int N,
                         int K, void* stream);
@@ -473,6 +474,15 @@ int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales, const void
 int hopmi_gemm_f16x2_ab_img(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
                             const float* aux, int M, int N, int K, int epilogue, void* out_image, float* out_scales,
                             const float* row_norm, float bound_mul, float bound_add, void* stream);
+/* Split-K of the same kernel for a product with few output tiles and a huge contraction: C[M][N] = A Bt^T + row_bias[M][:, None]
+ * (row_bias nullable), A = hopmi_rows_image_f16 image, Bt = hopmi_gemm_f16x2_prepare image, any even K, N % 4 == 0.  The k-steps are
+ * cut into slabs (about one round of three workgroups per CU), each slab's partial product goes to `workspace`
+ * (hopmi_gemm_f16x2_ab_splitk_ws_floats floats) and a second launch adds the slabs in index order (bitwise reproducible).
+ * Replaces: the mapping layer's forward S = mapping_layer(word_embeddings^T)^T = W_map E + b (model/HOP.py:116,200; 1500 x 768
+ * outputs, K = 30522 -- the last large library GEMM of the fp32 step: 534 -> 3xx us). */
+size_t hopmi_gemm_f16x2_ab_splitk_ws_floats(int M, int N, int K);
+int hopmi_gemm_f16x2_ab_splitk(const void* Aimage, const float* a_scales, const void* Bimage, const float* row_bias, float* C, int M,
+                               int N, int K, float* workspace, void* stream);
 
 /* The weight gradient of a linear layer in the same arithmetic (round 5; csrc/gemm_tn.hip):  C[N][K] (+)= A[M][N]^T . B[M][K]  -- both
  * operands ACTIVATIONS (A = dY, B = X, row-major with leading dimensions lda / ldb), contraction over their M rows; `batch`

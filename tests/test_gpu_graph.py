@@ -508,11 +508,14 @@ def test_graphed_step_baseline_size_vs_reference(V, B, epoch, monkeypatch):
     # Tolerance per step.  Step 1 is the north_star's 1e-3 (what test_train_llm_baseline_size_vs_reference holds the eager step
     # to).  From step 2 on the forward sees parameters that Adam has moved: an element whose gradient is at rounding level steps
     # by +-lr in a direction that rounding decides, differently on the two sides (tools/probes/grad_sensitivity.py),
-    # and the outputs drift apart by a few 1e-4 per step on that account alone -- measured 1.7e-3 / 1.9e-3 at step 5.  Allowed:
-    # 1e-3 + 4e-4 per Adam step taken.  That the recorded step itself adds nothing to the eager step's error is the soak test's
-    # business (bit-identical gradients, 52 steps, this size); a wrong launch, a stale buffer or a reset optimizer state shows
-    # up here as per cent, not as 1e-3.
-    tol = lambda it: RTOL + 4e-4 * it
+    # and the outputs drift apart by a few 1e-4 per step on that account alone.  Rounds 3-4 (three-term split-bf16 products, ~2^-16,
+    # in the WaveNet / attention / GRU kernels) measured 1.7e-3 / 1.9e-3 at step 5 and allowed 1e-3 + 4e-4 per Adam step; with
+    # every contraction fp32-class (round 5) the same runs measure 2.7e-4, 6.1e-4, 2.3e-4, 4.6e-4 (V = 9) and 2.2e-4, 3.1e-4, 4.6e-4,
+    # 8.6e-4 (V = 42) at steps 2-5 (gpurun_out/graphed_vs_reference_drift.txt): about half of the old drift was the narrow
+    # products', the rest is Adam's.  Allowed now: 1e-3 + 1.5e-4 per Adam step taken.  That the recorded step itself adds nothing
+    # to the eager step's error is the soak test's business (bit-identical gradients, 52 steps, this size); a wrong launch, a
+    # stale buffer or a reset optimizer state shows up here as per cent, not as 1e-3.
+    tol = lambda it: RTOL + 1.5e-4 * it
     try:                                               # (the measured drift, kept for DESIGN.md 2)
         from conftest import ROOT
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

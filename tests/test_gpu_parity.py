@@ -1935,6 +1935,51 @@ def test_layernorm_operand_images_feed_the_lds_dma_gemm(monkeypatch):
     assert rel_err(res_d["image"][2], res_d["split"][2]) <= 2e-6
 
 
+@pytest.mark.parametrize("M,K,N", [(1500, 30522, 768), (188, 30522, 768), (130, 4610, 36), (64, 66, 4)])
+def test_mapping_forward_split_k_vs_float64(M, K, N):
+    """hopmi_gemm_f16x2_ab_splitk: S = W E + b[:, None] (the mapping layer's forward, HOP.py:200: 1500 x 768 outputs, K = vocab =
+    30522 -- not a multiple of 4, rows of W only 8-byte aligned) with W's rows as a per-step fp16 hi/lo image (ragged K padded with
+    zeros), E^T's image cached under the frozen E and the contraction cut into slabs that a second launch adds in index order.
+    fp32-equivalent: error against float64 within 3 x the fp32 library product's; bitwise run-to-run; a rank's row range (188 rows:
+    1500 / 8) and ragged small shapes included; rows of W of very different magnitude."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(K + M)
+    W = (torch.randn(M, K, generator=g) * torch.logspace(-3, 1, M).unsqueeze(1) / K ** 0.5).to(dev)
+    E = torch.randn(K, N, generator=g).to(dev)
+    b = torch.randn(M, generator=g).to(dev)
+    got = ops.f16_affine_splitk(W, E, b)
+    again = ops.f16_affine_splitk(W, E, b)
+    assert torch.equal(got, again)
+    ref64 = W.double() @ E.double() + b.double().unsqueeze(1)
+    lib = torch.addmm(b.unsqueeze(1), W, E)
+    # row-wise: every row against its own largest magnitude (the rows span four orders of magnitude)
+    den = ref64.abs().amax(dim=1, keepdim=True)
+    e_got = ((got.double() - ref64).abs() / den).max().item()
+    e_lib = ((lib.double() - ref64).abs() / den).max().item()
+    assert e_got <= 3.0 * e_lib + 1e-7, (e_got, e_lib)
+
+
+def test_mapping_forward_uses_the_split_k_form(monkeypatch):
+    """model._SplitKAffine (the prototype branch of HOP.Model): forward through hopmi_gemm_f16x2_ab_splitk, same values (2e-6) and
+    the same gradients as the library path it replaces."""
+    from hopmi import model as hmodel, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    E = torch.randn(30522, 768, generator=g).to(dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "F16_SPLITK", on)
+        W = (torch.randn(1500, 30522, generator=torch.Generator().manual_seed(6)) / 170).to(dev).requires_grad_()
+        b = torch.randn(1500, generator=torch.Generator().manual_seed(7)).to(dev).requires_grad_()
+        assert ops.f16_affine_splitk_ok(W, E) == on
+        S = hmodel._SplitKAffine.apply(W, E, b, 6)
+        (S * torch.linspace(-1, 1, 768, device=dev)).sum().backward()
+        res[on] = (S.detach(), W.grad.clone(), b.grad.clone())
+    assert rel_err(res[True][0], res[False][0]) <= 2e-6
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+
+
 @pytest.mark.parametrize("M,N,K", [(4352, 2100, 992), (4352, 768, 1536), (2048, 1700, 3400), (1000, 130, 70), (33, 5, 260)])
 def test_gemm_f16x2_tn_vs_float64(M, N, K):
     """hopmi_gemm_f16x2_tn: dW = dY^T X (both operands activations, contraction over the rows; csrc/gemm_tn.hip) at the generator's
