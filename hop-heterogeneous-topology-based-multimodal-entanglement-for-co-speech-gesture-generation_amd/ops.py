@@ -470,6 +470,37 @@ GEMM_AB = __import__("os").environ.get("HOPMI_GEMM_AB", "1") == "1"
 GEMM_AB_MAX_N = int(__import__("os").environ.get("HOPMI_GEMM_AB_MAX_N", "2304"))
 
 
+# the trainable linears (GRU input projections, align layer, beat MLP, reprogramming projections): one pass writes the operand's image
+# AND its row scales (which the weight-gradient GEMM needs anyway), the LDS-DMA form multiplies -- also where K is not a multiple of
+# 32 (GRU: K = 700, 2100): A/B HOPMI_F16_LINEAR_IMG=0 (row scales + split form)
+F16_LINEAR_IMG = __import__("os").environ.get("HOPMI_F16_LINEAR_IMG", "1") != "0"
+
+
+def rows_image(a2d):
+    """(image, scales) of a contiguous fp32 (M, K) operand, K even: hopmi_rows_image_f16 (tile-blocked fp16 hi / lo images with the
+    columns padded to a multiple of 32, [2][M] row-scale pairs) -- the `a_img` of _split_gemm."""
+    M, K = a2d.shape
+    L = _lib.lib()
+    img_a = torch.empty(L.hopmi_rows_image_f16_bytes(M, K), dtype=torch.uint8, device=a2d.device)
+    sc = torch.empty(2, M, dtype=torch.float32, device=a2d.device)
+    _lib.check(L.hopmi_rows_image_f16(a2d.data_ptr(), M, K, img_a.data_ptr(), sc.data_ptr(), _stream()), "hopmi_rows_image_f16")
+    return img_a, sc
+
+
+def _linear_operand(t, t2):
+    """The fp16-form operand of a trainable linear: (row scales, image or None) of the 2-D view t2 of tensor t -- from the producer
+    when it left them, else one pass."""
+    M, K = t2.shape
+    rs = _take_rs(t, M)
+    im = _take_img(t, M, K) if K % 32 == 0 else None
+    if im is not None:
+        return im[1], im
+    if rs is None and F16_LINEAR_IMG and M >= IMG_MIN_ROWS and K % 2 == 0 and K >= 128 and t2.is_contiguous() and t2.data_ptr() % 8 == 0:
+        im = rows_image(t2)
+        return im[1], im
+    return (rs if rs is not None else row_scales(t2)), None
+
+
 def _split_gemm(a2d, img, bias, N, K, parts, a_part=None, out=None, a_img=None):
     """`a_part` (fp16 form): the A operand's [2][M] row-scale pairs, or a ([P][M] partial row maxima, P) pair as a producing GEMM's
     `rowmax` left them; None: a hopmi_row_scales pass.  `a_img`: (image, scales) of a2d as `_take_img` returns them."""
@@ -542,11 +573,13 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
         raise _lib.HopmiError(f"hopmi _split_gemm: `out` must be a contiguous float32 ({M}, {N}) tensor on {a2d.device}")
     h = torch.empty_like(out) if (epilogue == 1 and keep) else None
     L = _lib.lib()
-    if parts == F16_PARTS and a_img is not None and K % 32 == 0:
-        # the producer (a LayerNorm kernel) wrote the operand's image: both operands by LDS-DMA, nothing split in the k-loop
+    if parts == F16_PARTS and a_img is not None and K % 2 == 0:
+        # the producer (a LayerNorm kernel, rows_image) wrote the operand's image: both operands by LDS-DMA, nothing split in the
+        # k-loop.  (K % 32 != 0: both images carry zero columns up to the next multiple of 32 -- the kernel is told that K)
         img_a, sc = a_img
+        K_log, K = K, (K + 31) // 32 * 32
         cm = torch.empty(L.hopmi_gemm_f16x2_tiles_n(N), M, dtype=torch.float32, device=a2d.device) if rowmax is not None else None
-        _lib.check(_timed("gemm_split", 4 * (M * K + (3 if (h is not None or aux is not None) else 2) * M * N) + 4 * N * K, 2 * M * N * K,
+        _lib.check(_timed("gemm_split", 4 * (M * K_log + (3 if (h is not None or aux is not None) else 2) * M * N) + 4 * N * K_log, 2 * M * N * K_log,
                           lambda: L.hopmi_gemm_f16x2_ab_ep(img_a.data_ptr(), sc.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(h),
                                                            _ptr(aux), _ptr(cm), M, N, K, epilogue, _stream())),
                    "hopmi_gemm_f16x2_ab_ep")
@@ -1149,11 +1182,9 @@ class _F16LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, owners):
         N, K = w.shape
         x2 = _dev_f32(x.detach(), "x").reshape(-1, K)
-        xs = _take_rs(x, x2.shape[0])
-        if xs is None:
-            xs = row_scales(x2)                        # (kept: the weight gradient takes its operand scale from them)
+        xs, xi = _linear_operand(x, x2)                # (the scales are kept: the weight gradient takes its operand scale from them)
         y = _split_gemm(x2, f16_weight_image(w, owners=owners), None if b is None else _dev_f32(b.detach(), "bias"), N, K, F16_PARTS,
-                        a_part=xs)
+                        a_part=xs, a_img=xi)
         ctx.save_for_backward(x2, w, xs)
         ctx.x_shape, ctx.has_b, ctx.owners = x.shape, b is not None, owners
         return torch.ops.aten._unsafe_view(y, list(x.shape[:-1]) + [N])
@@ -1165,12 +1196,13 @@ class _F16LinearFn(torch.autograd.Function):
         dy2 = _dev_f32(dy, "dy").reshape(-1, N)
         dx = dw = db = None
         tn = ctx.needs_input_grad[1] and f16_mm_tn_ok(dy2, x2)
-        ds = _take_rs(dy, dy2.shape[0])
-        if ds is None and (tn or (ctx.needs_input_grad[0] and N % 4 == 0 and K >= 128)) and N % 4 == 0:
-            ds = row_scales(dy2)                       # one pass serves both gradient products
+        ds, di = _take_rs(dy, dy2.shape[0]), None
+        if (tn or (ctx.needs_input_grad[0] and N % 4 == 0 and K >= 128)) and N % 4 == 0:
+            if ds is None or ctx.needs_input_grad[0]:
+                ds, di = _linear_operand(dy, dy2)      # one pass serves both gradient products
         if ctx.needs_input_grad[0]:
             if N % 4 == 0 and K >= 128:                  # (dX contracts over N: the kernel's K % 4 == 0 rule applies to it here)
-                dx = _split_gemm(dy2, f16_weight_image(w, transpose=True, owners=ctx.owners), None, K, N, F16_PARTS, a_part=ds)
+                dx = _split_gemm(dy2, f16_weight_image(w, transpose=True, owners=ctx.owners), None, K, N, F16_PARTS, a_part=ds, a_img=di)
             else:
                 dx = dy2 @ w
             dx = dx.view(ctx.x_shape)
@@ -1191,8 +1223,9 @@ def linear(x, w, b=None, owners=None):
         if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad))):
             N, K = w.shape
             x2 = _dev_f32(x.detach(), "x").reshape(-1, K)
+            xs, xi = _linear_operand(x, x2)
             y = _split_gemm(x2, f16_weight_image(w, owners=owners), None if b is None else _dev_f32(b.detach(), "bias"), N, K, F16_PARTS,
-                            a_part=_take_rs(x, x2.shape[0]))
+                            a_part=xs, a_img=xi)
             return y.view(*x.shape[:-1], N)
         return _F16LinearFn.apply(x, w, b, owners)
     if b is None or not (torch.is_grad_enabled() and b.requires_grad):
