@@ -1013,7 +1013,7 @@ class _LinearFn(torch.autograd.Function):
 F16_LINEAR = __import__("os").environ.get("HOPMI_F16_LINEAR", "1") != "0"
 # From M N K = 5e9 on (tools/bench_linear.py, against the TUNED library kernels: GRU input projections 120 -> 80 us + 9 us of row
 # scales, align layer 96 -> 60, beat MLP 214 -> 134; below, the row-scales pass and the weight images eat the gain)
-F16_LINEAR_MIN_MNK = 5.0e9
+F16_LINEAR_MIN_MNK = float(__import__("os").environ.get("HOPMI_F16_LINEAR_MIN_MNK", "5.0e9"))
 _F16_IMG = {}                       # (ids of the owner parameters, N, K, transpose) -> (weak references, versions, image, made under capture)
 _F16_IMG_FROZEN = {}                # the same for owners that take no gradient (never reset by a recording)
 
@@ -1074,6 +1074,8 @@ def f16_mm_nt(a2d, w, owners, out=None):
     layer's weight gradient dW = dS E^T against the FROZEN word embeddings E (30522 x 768: E itself is the row-major Bt operand)."""
     N, K = w.shape
     a2d = _dev_f32(a2d.detach(), "a")
+    # (the split form: with N = 30522 column tiles the LDS-DMA form's 64-row tiles re-read the weight image once more per row tile --
+    # image pass + LDS-DMA form measured 0.16 ms per step slower here, A/B twice on one box)
     return _split_gemm(a2d, f16_weight_image(w, owners=tuple(owners)), None, N, K, F16_PARTS, a_part=_take_rs(a2d, a2d.shape[0]), out=out)
 
 
@@ -1120,7 +1122,7 @@ def f16_affine_splitk(W, E, b):
 # dW = dY^T X on hopmi_gemm_f16x2_tn (csrc/gemm_tn.hip) instead of the library's fp32 GEMM: from M N K = 2e9 on (below, the row-scale
 # passes and the slab sum eat the gain)
 F16_TN = __import__("os").environ.get("HOPMI_F16_TN", "1") != "0"
-F16_TN_MIN_MNK = 2.0e9
+F16_TN_MIN_MNK = float(__import__("os").environ.get("HOPMI_F16_TN_MIN_MNK", "2.0e9"))
 _UNIT_RS = {}                       # (device, M) -> [2][M] row-scale pairs {2^14, 2^-14}: operands bounded by 1 (GRU states)
 
 
