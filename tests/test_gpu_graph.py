@@ -516,6 +516,9 @@ def test_graphed_step_baseline_size_vs_reference(V, B, epoch, monkeypatch):
     # to the eager step's error is the soak test's business (bit-identical gradients, 52 steps, this size); a wrong launch, a
     # stale buffer or a reset optimizer state shows up here as per cent, not as 1e-3.
     tol = lambda it: RTOL + 1.5e-4 * it
+    # (the BatchNorm running statistics and the parameters after five Adam steps keep the allowance of rounds 3-4: they integrate the
+    # sign-undetermined steps of the rounding-level gradients directly -- running_var of V = 42 measures 1.0e-3 elementwise at step 5)
+    tol_state = lambda it: RTOL + 4e-4 * it
     try:                                               # (the measured drift, kept for DESIGN.md 2)
         from conftest import ROOT
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -538,11 +541,11 @@ def test_graphed_step_baseline_size_vs_reference(V, B, epoch, monkeypatch):
             # the graph-conv bias in front of this BatchNorm has an analytically zero gradient: Adam walks it by +-lr per step on
             # rounding noise, differently on the two sides, and the batch mean moves with it (the normalised output does not)
             diff = (sd[k].cpu() - v).abs().max().item()
-            assert diff <= tol(n_steps - 1) * v.abs().max().item() + n_steps * 1e-3, (k, diff)
+            assert diff <= tol_state(n_steps - 1) * v.abs().max().item() + n_steps * 1e-3, (k, diff)
         else:
-            assert_close(sd[k], v, tol(n_steps - 1), what=k)
+            assert_close(sd[k], v, tol_state(n_steps - 1), what=k)
     # (the absolute slack of n_steps sign-undetermined Adam steps is given to the analytically-zero-gradient tensors only)
-    g.check_params(sd, d.state_dict(), "last", tol(n_steps - 1), n_steps, gan)
+    g.check_params(sd, d.state_dict(), "last", tol_state(n_steps - 1), n_steps, gan)
     if gan:
         for p in d.parameters():
             assert float(d_opt.state[p]["step"]) == n_steps
