@@ -460,7 +460,11 @@ RS_FUSED = __import__("os").environ.get("HOPMI_RS_FUSED", "1") != "0"
 IMG_FUSED = __import__("os").environ.get("HOPMI_IMG_FUSED", "1") != "0"
 # BertIntermediate's product hands its output to BertOutput.dense as an operand image (and the backward likewise): A/B HOPMI_FFN_IMG=0
 FFN_IMG = __import__("os").environ.get("HOPMI_FFN_IMG", "1") != "0"
-IMG_MIN_ROWS = 1024     # row scales from the producing kernels (0: always a pass of their own)
+# Operand IMAGES (LayerNorm / GEMM-epilogue / rows_image producers + the LDS-DMA GEMM form) pay from about 3 000 rows on: at M = 4352
+# (TED, batch 128) the step gains 1.1 ms over row scales + the split form, at M = 2176 (TED-Expressive, batch 64) it LOSES 0.3 ms
+# (13.24 vs 12.94 ms, A/B on one box: with half the row tiles the LDS-DMA form's workgroups no longer cover one another's staging
+# latency, and the image stores are a fixed cost).  Below the threshold: row scales from the producing kernels and the split form.
+IMG_MIN_ROWS = int(__import__("os").environ.get("HOPMI_IMG_MIN_ROWS", "3072"))
 # An operand nobody wrote an image of (the attention's output and gradient, the embedding LayerNorm's output): ONE pass takes the row
 # scales and writes the fp16 images (hopmi_rows_image_f16: 6.6 us at K = 768, 19 us at K = 2304, M = 4352) and the LDS-DMA form
 # multiplies -- bit-identical to row scales + the split form.  Round 4 measured no gain in the step; with the tile-blocked images and
@@ -588,7 +592,7 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
         return out, h
     if parts == F16_PARTS:
         if (a_part is None and GEMM_AB and epilogue == 0 and rowmax is None and N <= GEMM_AB_MAX_N and K % 32 == 0
-                and M >= F16_LINEAR_MIN_ROWS):
+                and M >= max(F16_LINEAR_MIN_ROWS, IMG_MIN_ROWS)):
             # no scales at hand and a problem that one 128 x 128 tile per CU covers: the pass that would take the row scales writes the
             # operand's fp16 images as well, and the LDS-DMA form multiplies (bit-identical; tools/bench_gemm.py: 24 vs 30 us at
             # N = K = 768, 71 vs 92 at K = 3072, M = 4352)

@@ -1727,6 +1727,7 @@ def test_gemm_f16x2_lds_dma_form_equals_the_split_form(M, N, K, monkeypatch):
     b = torch.randn(N, generator=g).to(dev)
     img = ops.split_weight_image(w, 16)
     monkeypatch.setattr(ops, "GEMM_AB", True)
+    monkeypatch.setattr(ops, "IMG_MIN_ROWS", 0)           # (the default only takes the image pass from 3072 rows on)
     y_ab = ops._split_gemm(x, img, b, N, K, 16)
     monkeypatch.setattr(ops, "GEMM_AB", False)
     y_split = ops._split_gemm(x, img, b, N, K, 16)
@@ -1861,6 +1862,7 @@ def test_layernorm_operand_images_feed_the_lds_dma_gemm(monkeypatch):
     nothing split in the k-loop.  Checked at the encoder's row count: the attached image equals hopmi_rows_image_f16 of the tensor
     bit for bit; the products (plain, GELU epilogue with the kept pre-activation, GELU-gradient epilogue) and the gradient equal
     the split form's bit for bit (HOPMI_IMG_FUSED off); a modified tensor's stale image is refused."""
+    monkeypatch.setattr(__import__('hopmi').ops, "IMG_MIN_ROWS", 1024)      # (the default threshold is 3072 rows; M = 1152 here)
     from hopmi import ops, _lib
     dev = _dev()
     monkeypatch.setattr(ops, "GEMM_PARTS", 16)

@@ -71,8 +71,19 @@ with open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.csv"), "w") as f:
                 rep_calls[r["Kernel_Name"][:120]] += 1.0 / n_rep
                 rep_ns[r["Kernel_Name"][:120]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / n_rep
         if n_rep:
+            # the profiled run's own bench line (kernels run a few per cent slower under the tracer: hold the sum against THIS number)
+            own = ""
+            try:
+                import json as _json, os as _os
+                line = [l for l in open(_os.path.join(root, "prof_stats.log")) if l.startswith("{")][-1]
+                d = _json.loads(line)
+                span = [int(tr[b]["Start_Timestamp"]) - int(tr[a]["Start_Timestamp"]) for a, b in zip(marks[-n_rep - 1:-1], marks[-n_rep:])]
+                own = (f"; the SAME run's bench line: ms_per_step {d['ms_per_step']:.3f} (median {d.get('median_ms_per_step', 0):.3f}); wall time of those windows "
+                       f"{sum(span) / len(span) / 1e6:.3f} ms")
+            except Exception:          # noqa: BLE001
+                pass
             f.write(f"# replayed steps: {n_rep} windows between consecutive hop_losses_fwd_kernel launches at the end of the run; kernel time per replayed step "
-                    f"{sum(rep_ns.values()) / 1e6:.3f} ms in {sum(rep_calls.values()):.0f} launches (hold against the bench line's ms_per_step); rows whose "
+                    f"{sum(rep_ns.values()) / 1e6:.3f} ms in {sum(rep_calls.values()):.0f} launches{own}; rows whose "
                     f"ReplayCallsPerStep is 0 are set-up only (weight images of frozen weights, eager-only launches, the empty timing kernel)\n")
     except SystemExit:
         pass
