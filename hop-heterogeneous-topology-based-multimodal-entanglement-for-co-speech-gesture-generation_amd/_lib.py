@@ -96,6 +96,8 @@ SIGNATURES = {
     "hopmi_gemm_f16x2_tn_ws_floats": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "hopmi_gemm_f16x2_tn": (_I, [_VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _I, _I, _I, _I, _I,
                                 _VP]),
+    "hopmi_gemm_f16x2_tn_cs": (_I, [_VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _VP, _I, ctypes.c_longlong, _VP, _I, _I, _I, _I, _I,
+                                   _VP, _VP]),
     "hopmi_gemm_f16x2": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "hopmi_gemm_split_ep": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "hopmi_gru_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),

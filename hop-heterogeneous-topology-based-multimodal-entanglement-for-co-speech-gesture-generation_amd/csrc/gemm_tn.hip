@@ -31,6 +31,8 @@ struct TnArgs {
   int M, N, K;
   int tiles_n, tiles_k, splits, steps_per_split;
   int accumulate;                                // C += (single-split form only; the slab sum takes it otherwise)
+  float* colsum;                                 // nullable: [N] column sums of A (the bias gradient of the same linear), batch == 1
+  float* cs_slabs;                               // ... [splits][N] partial sums when the rows are split
 };
 
 __device__ __forceinline__ float tn_tensor_scale(const float* rows, int M, float* red) {
@@ -92,7 +94,12 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_f16_tn_kernel(TnArgs P) {
       bv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, b_voff, (step * TN_MS + e) * P.ldb * 4, 0));
     }
   };
+  // (the bias gradient of the same linear is the column sum of A = dY: the workgroups of the first k-tile column add up what they
+  // stage anyway -- thread (c, o) owns column c, rows 8 o .. 8 o + 7 of every step)
+  const bool want_cs = P.colsum != nullptr && tk == 0;
+  float asum = 0.f;
   auto commit = [&]() {
+    if (want_cs) asum += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
     const Split8 sa = split8h(make_float4(av[0], av[1], av[2], av[3]), make_float4(av[4], av[5], av[6], av[7]), sA);
     const Split8 sb = split8h(make_float4(bv[0], bv[1], bv[2], bv[3]), make_float4(bv[4], bv[5], bv[6], bv[7]), sB);
     *reinterpret_cast<u32x4*>(At + st_off) = sa.hi;
@@ -164,12 +171,28 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_f16_tn_kernel(TnArgs P) {
         }
       }
     }
+  if (want_cs) {                                       // (wave-uniform; the loop's last barrier is behind every LDS read)
+    float* r = reinterpret_cast<float*>(lds);
+    r[o * TN_T + c] = asum;
+    __syncthreads();
+    if (tid < TN_T && n0 + tid < P.N) {
+      const float v = (r[tid] + r[TN_T + tid]) + (r[2 * TN_T + tid] + r[3 * TN_T + tid]);
+      if (P.splits > 1) P.cs_slabs[(size_t)split * P.N + n0 + tid] = v;
+      else P.colsum[n0 + tid] = v;
+    }
+  }
 }
 
 // C[n][k] (+)= slab 0 + slab 1 + ... (index order)
 __global__ __launch_bounds__(256) void gemm_tn_sum_kernel(const float* __restrict__ slabs, int splits, long long batchS, float* __restrict__ C,
-                                                          int ldc, long long batchC, int N, int K, int accumulate) {
+                                                          int ldc, long long batchC, int N, int K, int accumulate,
+                                                          const float* __restrict__ cs_slabs, float* __restrict__ colsum) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (colsum != nullptr && idx < (size_t)N && blockIdx.y == 0) {       // the column sums of A ride along (index order too)
+    float v = cs_slabs[idx];
+    for (int p = 1; p < splits; ++p) v += cs_slabs[(size_t)p * N + idx];
+    colsum[idx] = v;
+  }
   if (idx >= (size_t)N * K) return;
   const float* s = slabs + (size_t)blockIdx.y * batchS + idx;
   float v = s[0];
@@ -200,12 +223,24 @@ using namespace hopmi;
 extern "C" size_t hopmi_gemm_f16x2_tn_ws_floats(int M, int N, int K, int batch) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
   const int s = tn_splits(M, N, K, batch);
-  return s > 1 ? (size_t)s * N * K * batch : 0;
+  return s > 1 ? (size_t)s * N * K * batch + (size_t)s * N : 0;        // (+ the column-sum slabs of hopmi_gemm_f16x2_tn_cs)
 }
+
+extern "C" int hopmi_gemm_f16x2_tn_cs(const float* A, int lda, long long batch_stride_a, const float* a_rows, const float* B, int ldb,
+                                      long long batch_stride_b, const float* b_rows, float* C, int ldc, long long batch_stride_c, float* ws,
+                                      int M, int N, int K, int batch, int accumulate, float* a_colsum, void* stream);
 
 extern "C" int hopmi_gemm_f16x2_tn(const float* A, int lda, long long batch_stride_a, const float* a_rows, const float* B, int ldb,
                                    long long batch_stride_b, const float* b_rows, float* C, int ldc, long long batch_stride_c, float* ws,
                                    int M, int N, int K, int batch, int accumulate, void* stream) {
+  return hopmi_gemm_f16x2_tn_cs(A, lda, batch_stride_a, a_rows, B, ldb, batch_stride_b, b_rows, C, ldc, batch_stride_c, ws, M, N, K, batch,
+                                accumulate, nullptr, stream);
+}
+
+extern "C" int hopmi_gemm_f16x2_tn_cs(const float* A, int lda, long long batch_stride_a, const float* a_rows, const float* B, int ldb,
+                                      long long batch_stride_b, const float* b_rows, float* C, int ldc, long long batch_stride_c, float* ws,
+                                      int M, int N, int K, int batch, int accumulate, float* a_colsum, void* stream) {
+  if (a_colsum && batch != 1) { set_error("hopmi_gemm_f16x2_tn_cs: the column sums are for batch == 1"); return HOPMI_EINVAL; }
   if (!A || !B || !C || !a_rows || !b_rows) { set_error("hopmi_gemm_f16x2_tn: null pointer argument (operands, their row scales, C)"); return HOPMI_EINVAL; }
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || lda < N || ldb < K || ldc < K) {
     set_error("hopmi_gemm_f16x2_tn: bad extents M=%d N=%d K=%d batch=%d lda=%d ldb=%d ldc=%d", M, N, K, batch, lda, ldb, ldc);
@@ -228,13 +263,15 @@ extern "C" int hopmi_gemm_f16x2_tn(const float* A, int lda, long long batch_stri
     if (!ws) { set_error("hopmi_gemm_f16x2_tn: this shape splits its rows %d ways and needs the workspace (hopmi_gemm_f16x2_tn_ws_floats)", P.splits); return HOPMI_EINVAL; }
     P.slabs = ws;
     P.batchS = (long long)P.splits * N * K;
+    P.cs_slabs = ws + (size_t)P.splits * N * K * batch;
   }
+  P.colsum = a_colsum;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gemm_f16_tn_kernel, dim3(P.tiles_n * P.tiles_k * P.splits, batch), dim3(TN_THREADS), 0, st, P);
   if (int e = check_launch("hopmi_gemm_f16x2_tn")) return e;
   if (P.splits > 1) {
     hipLaunchKernelGGL(gemm_tn_sum_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256), batch), dim3(256), 0, st, P.slabs, P.splits, P.batchS,
-                       C, ldc, batch_stride_c, N, K, accumulate);
+                       C, ldc, batch_stride_c, N, K, accumulate, P.cs_slabs, a_colsum);
     return check_launch("hopmi_gemm_f16x2_tn(sum)");
   }
   return HOPMI_OK;

@@ -1126,6 +1126,7 @@ def f16_affine_splitk(W, E, b):
 # dW = dY^T X on hopmi_gemm_f16x2_tn (csrc/gemm_tn.hip) instead of the library's fp32 GEMM: from M N K = 2e9 on (below, the row-scale
 # passes and the slab sum eat the gain)
 F16_TN = __import__("os").environ.get("HOPMI_F16_TN", "1") != "0"
+TN_COLSUM = __import__("os").environ.get("HOPMI_TN_COLSUM", "1") != "0"      # bias gradients as a by-product of the TN weight gradient
 F16_TN_MIN_MNK = float(__import__("os").environ.get("HOPMI_F16_TN_MIN_MNK", "2.0e9"))
 _UNIT_RS = {}                       # (device, M) -> [2][M] row-scale pairs {2^14, 2^-14}: operands bounded by 1 (GRU states)
 
@@ -1152,10 +1153,11 @@ def f16_mm_tn_ok(a, b) -> bool:
                 and float(a.shape[-2]) * a.shape[-1] * b.shape[-1] * (a.shape[0] if a.dim() == 3 else 1) >= F16_TN_MIN_MNK)
 
 
-def f16_mm_tn(a, b, a_rs, b_rs, out=None, accumulate=False):
+def f16_mm_tn(a, b, a_rs, b_rs, out=None, accumulate=False, colsum=False):
     """a^T b on hopmi_gemm_f16x2_tn (no autograd): a (M, N) and b (M, K) fp32, unit stride along the last axis, any row stride; or
     (batch, M, N) / (batch, M, K) with one batch stride each.  a_rs / b_rs: the operands' [2][M] row-scale pairs (row_scales,
-    _take_rs, unit_row_scales; shared by the batch members).  Returns (N, K) or (batch, N, K)."""
+    _take_rs, unit_row_scales; shared by the batch members).  Returns (N, K) or (batch, N, K); with `colsum` (unbatched) the pair
+    (a^T b, column sums of a) -- with a = dY the weight AND the bias gradient of a linear from one pass over dY."""
     batched = a.dim() == 3
     bt = a.shape[0] if batched else 1
     M, N = a.shape[-2:]
@@ -1173,13 +1175,16 @@ def f16_mm_tn(a, b, a_rs, b_rs, out=None, accumulate=False):
     L = _lib.lib()
     nws = L.hopmi_gemm_f16x2_tn_ws_floats(M, N, K, bt)
     ws = torch.empty(nws, dtype=torch.float32, device=a.device) if nws else None
+    if colsum and batched:
+        raise _lib.HopmiError("hopmi f16_mm_tn: `colsum` is for unbatched operands")
+    cs = torch.empty(N, dtype=torch.float32, device=a.device) if colsum else None
     _lib.check(_timed("gemm_tn", 4 * bt * (M * N + M * K + N * K), 2 * bt * M * N * K,
-                      lambda: L.hopmi_gemm_f16x2_tn(a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, a_rs.data_ptr(),
-                                                    b.data_ptr(), b.stride(-2), b.stride(0) if batched else 0, b_rs.data_ptr(),
-                                                    out.data_ptr(), out.stride(-2), out.stride(0) if batched else 0, _ptr(ws), M, N, K, bt,
-                                                    1 if accumulate else 0, _stream())),
+                      lambda: L.hopmi_gemm_f16x2_tn_cs(a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, a_rs.data_ptr(),
+                                                       b.data_ptr(), b.stride(-2), b.stride(0) if batched else 0, b_rs.data_ptr(),
+                                                       out.data_ptr(), out.stride(-2), out.stride(0) if batched else 0, _ptr(ws), M, N, K, bt,
+                                                       1 if accumulate else 0, _ptr(cs), _stream())),
                "hopmi_gemm_f16x2_tn")
-    return out
+    return (out, cs) if colsum else out
 
 
 
@@ -1212,9 +1217,13 @@ class _F16LinearFn(torch.autograd.Function):
             else:
                 dx = dy2 @ w
             dx = dx.view(ctx.x_shape)
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = f16_mm_tn(dy2, x2, ds, xs) if (tn and ds is not None) else dy2.t() @ x2
-        if ctx.has_b and ctx.needs_input_grad[2]:
+            if tn and ds is not None and want_db and TN_COLSUM:
+                dw, db = f16_mm_tn(dy2, x2, ds, xs, colsum=True)      # (the bias gradient rides on the weight gradient's pass over dY)
+            else:
+                dw = f16_mm_tn(dy2, x2, ds, xs) if (tn and ds is not None) else dy2.t() @ x2
+        if want_db and db is None:
             db = colsum(dy2)
         return dx, dw, db, None
 

@@ -496,6 +496,12 @@ size_t hopmi_gemm_f16x2_tn_ws_floats(int M, int N, int K, int batch);
 int hopmi_gemm_f16x2_tn(const float* A, int lda, long long batch_stride_a, const float* a_rows, const float* B, int ldb,
                         long long batch_stride_b, const float* b_rows, float* C, int ldc, long long batch_stride_c, float* ws, int M, int N,
                         int K, int batch, int accumulate, void* stream);
+/* ... also leaving a_colsum [N] = the column sums of A (batch == 1): with A = dY that is the bias gradient of the same linear, a
+ * by-product of the rows the first k-tile column of workgroups stages anyway (replaces a hopmi_colsum pass: 2 launches, one more
+ * read of dY).  Fixed summation order: bitwise run-to-run. */
+int hopmi_gemm_f16x2_tn_cs(const float* A, int lda, long long batch_stride_a, const float* a_rows, const float* B, int ldb,
+                           long long batch_stride_b, const float* b_rows, float* C, int ldc, long long batch_stride_c, float* ws, int M,
+                           int N, int K, int batch, int accumulate, float* a_colsum, void* stream);
 
 /* The same product with BOTH operands as part images (Aimage = hopmi_gemm_split_prepare(A, M, K, parts, ...), i.e.
  * [parts][M][K] bf16; a producer may also write that layout itself): nothing is split inside the kernel, every tile is staged

@@ -2011,6 +2011,26 @@ def test_gemm_f16x2_tn_vs_float64(M, N, K):
     assert rel_err(acc.cpu().double(), 2 * ref) <= 3.0 * e_lib + 2.4e-7
 
 
+@pytest.mark.parametrize("M,N,K", [(4352, 2100, 700), (4352, 768, 1536), (1000, 132, 72)])
+def test_gemm_f16x2_tn_column_sums_ride_along(M, N, K):
+    """hopmi_gemm_f16x2_tn_cs: the column sums of A (= the bias gradient when A = dY) as a by-product of the weight-gradient pass --
+    against a float64 sum next to the hopmi_colsum kernel it replaces; the product itself is bit-identical with and without; bitwise
+    run-to-run."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + K)
+    dy = (torch.randn(M, N, generator=g) * torch.logspace(-3, 1, M).unsqueeze(1)).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    rs_a, rs_b = ops.row_scales(dy), ops.row_scales(x)
+    dw0 = ops.f16_mm_tn(dy, x, rs_a, rs_b)
+    dw1, db1 = ops.f16_mm_tn(dy, x, rs_a, rs_b, colsum=True)
+    dw2, db2 = ops.f16_mm_tn(dy, x, rs_a, rs_b, colsum=True)
+    assert torch.equal(dw0, dw1) and torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    want = dy.double().sum(0)
+    e_new, e_old = rel_err(db1.double(), want), rel_err(ops.colsum(dy).double(), want)
+    assert e_new <= 3.0 * e_old + 2.4e-7, (e_new, e_old)
+
+
 def test_gemm_f16x2_tn_batched_strided_views():
     """The GRU's recurrent weight gradient as ops._GruLayerFn issues it: both directions in one call on strided views of dgh
     (B T, 2, 3H) and of the shifted states (B T, 2, H), the states' scale a constant (|h| <= 1)."""
