@@ -76,6 +76,7 @@ SIGNATURES = {
                                                          _I, _VP]),
     "hopmi_gemm_f16x2_ab_img": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, ctypes.c_float, ctypes.c_float, _VP]),
     "hopmi_bert_attn_fwd_dt": (_I, [_VP, _VP, _I, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
+    "hopmi_bert_attn_fwd_im": (_I, [_VP, _VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _VP]),
     "hopmi_bert_attn_bwd_dt": (_I, [_VP, _VP, _VP, _I, _I, _I, ctypes.c_float, ctypes.c_uint, _VP, _I, _VP]),
     "hopmi_bn_cl_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, ctypes.c_float, ctypes.c_float, _I, _VP]),
     "hopmi_bn_cl_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),

@@ -66,14 +66,15 @@ class FrozenBertEncoder:
             self._qkv[i] = hit
         return hit[1], hit[2]
 
-    def _linear(self, key, x, weight, bias):
+    def _linear(self, key, x, weight, bias, rowmax=None):
         """x W^T (+ bias) for one of the module's frozen linears: the library's fp32 GEMM, or -- ops.gemm_parts(2 | 3) --
-        hopmi_gemm_split on images of W and W^T that are built once per weight version."""
+        hopmi_gemm_split on images of W and W^T that are built once per weight version.  `rowmax` (a list, fp16 form): receives
+        the product's partial row maxima."""
         imgs = self._images(key, x, weight)
         if imgs is None:
             return F.linear(x, weight, bias)
         N, K = weight.shape
-        return ops.split_linear(x, imgs[0], imgs[1], bias, N, K, ops.GEMM_PARTS)
+        return ops.split_linear(x, imgs[0], imgs[1], bias, N, K, ops.GEMM_PARTS, rowmax=rowmax)
 
     def _images(self, key, x, weight):
         """Part images of a frozen weight and of its transpose (built once per weight version), or None where the linear
@@ -185,9 +186,13 @@ class FrozenBertEncoder:
         for i, lay in enumerate(llm.encoder.layer):
             att = lay.attention
             wqkv, bqkv = self._fused_qkv(i, att.self)
-            qkv = self._linear((i, "qkv"), h, wqkv, bqkv).view(B, L, 3, H, D // H)
+            # (fp16 form, enough rows for the LDS-DMA path: the QKV product leaves its partial row maxima, from which the attention
+            # kernel scales the operand image it writes for the attention-output product -- no image pass in between)
+            rm = [] if (ops.ATTN_IMG and ops.IMG_FUSED and ops.GEMM_PARTS == ops.F16_PARTS and B * L >= ops.IMG_MIN_ROWS
+                        and D // H == 64 and L <= 64 and D % 128 == 0) else None
+            qkv = self._linear((i, "qkv"), h, wqkv, bqkv, rowmax=rm).view(B, L, 3, H, D // H)
             if D // H == 64 and L <= 64:
-                a = ops.bert_attention(qkv, p_a, self._seed())                                   # (B,L,D), HIP
+                a = ops.bert_attention(qkv, p_a, self._seed(), v_rowmax=rm[0] if rm else None)   # (B,L,D), HIP
             else:                                                                                # other head sizes
                 qkv = qkv.permute(2, 0, 3, 1, 4)                                                 # (3,B,H,L,dh)
                 a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p_a)

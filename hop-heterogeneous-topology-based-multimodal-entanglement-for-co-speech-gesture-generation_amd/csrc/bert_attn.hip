@@ -14,6 +14,7 @@
 // (seed,row,head,key) hash of attn.hip.
 #include "attn_dev.h"
 #include "io_dev.h"
+#include "f16_dev.h"
 
 namespace hopmi {
 
@@ -62,11 +63,21 @@ __device__ __forceinline__ void xt_product(f32x4 (&o)[4], const float* X, const 
 // Forward.  Workgroup = (b, h), MT = ceil(L / 16) waves; wave w owns query rows [16w, 16w + 16) end to end:
 // its score strip stays in accumulator registers, the softmax reduces over the 16 lanes of a DPP row, the
 // dropped-out probabilities pass through a wave-private LDS tile to become an MFMA operand.  One barrier.
+// (round 5) The output handed on as the attention-output GEMM's operand IMAGE (hopmi_gemm_f16x2_ab_ep; gemm.hip f16_blk layout) beside
+// the fp32 values: a row of the output spans the H workgroups of its clip, so its scale cannot come from its maximum -- it comes from a
+// BOUND every one of them can compute: O = dropout(P) V is a sub-convex combination of V's rows times 1 / (1 - p), so
+// |O[b, :, :]| <= max |V[b, :, :]| / (1 - p), and max |V| of the clip is the maximum of the QKV product's partial row maxima
+// (c_rowmax of hopmi_gemm_f16x2(_ab_ep): [tiles][M], the V columns are tiles vt0 .. vt1 - 1) over the clip's L rows.  One scale per
+// clip: typical outputs sit 2^1 ... 2^4 below it.
+struct BertAttnImage { const float* v_rowmax; int vt0, vt1, M; _Float16* image; float* scales; };
+
 template <int MT, typename T>
 __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H,
-                                                                unsigned thresh, float dscale, unsigned seed, const unsigned* __restrict__ seed_dev) {
+                                                                unsigned thresh, float dscale, unsigned seed, const unsigned* __restrict__ seed_dev,
+                                                                BertAttnImage im) {
   if (seed_dev != nullptr) seed += *seed_dev;   // device-side stream position (hipGraph replays advance it)
   constexpr int LP = 16 * MT, PLD = LP + 4, NT = 64 * MT;
+  __shared__ unsigned s_vmax[MT];
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
   float* Vs = Ks + LP * BLD;
@@ -82,6 +93,17 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const T* __restr
     const T* qp = base + (size_t)min(16 * w + j, L - 1) * rs + 4 * q;
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) qf[ii] = ld4(qp + 16 * ii);
+  }
+  if (im.image != nullptr) {                     // the clip's max |V| from the QKV product's partial row maxima (in front of the barrier)
+    unsigned m = 0u;
+    const int nv = (im.vt1 - im.vt0) * L;
+    for (int i = tid; i < nv; i += NT) {
+      const int t = im.vt0 + i / L, r = i - (i / L) * L;
+      m = max(m, __float_as_uint(im.v_rowmax[(size_t)t * im.M + (size_t)(blockIdx.x / H) * L + r]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((tid & 63) == 0) s_vmax[tid >> 6] = m;
   }
   __syncthreads();
   f32x4 s[MT];
@@ -125,6 +147,28 @@ __global__ __launch_bounds__(64 * MT) void bert_attn_fwd_kernel(const T* __restr
     T* op = out + ((size_t)(b * L + row) * H + h) * BD + 4 * q;
 #pragma unroll
     for (int di = 0; di < 4; ++di) st4(op + 16 * di, make_float4(o[di][0], o[di][1], o[di][2], o[di][3]));
+  }
+  if (im.image != nullptr) {
+    unsigned m = s_vmax[0];
+#pragma unroll
+    for (int k = 1; k < MT; ++k) m = max(m, s_vmax[k]);
+    // (1 / (1 - p) <= 2 and the fp32 accumulation's rounding: the bound times 1.001)
+    const unsigned sb = scale_bits_for_max(__float_as_uint(__uint_as_float(m) * dscale * 1.001f) & 0x7fffffffu);
+    const float sc = __uint_as_float(sb);
+    if (row < L) {
+      const int D = H * BD, grow = b * L + row;
+      _Float16* hi = im.image;
+      _Float16* lo = hi + (size_t)((im.M + 127) / 128 * 128) * D;
+#pragma unroll
+      for (int di = 0; di < 4; ++di) {
+        const Split4 sp = split4h(o[di][0] * sc, o[di][1] * sc, o[di][2] * sc, o[di][3] * sc);
+        const size_t at = ((size_t)(grow >> 7) * (D >> 5) + ((h * BD + 16 * di + 4 * q) >> 5)) * 4096 + (size_t)(grow & 127) * 32 +
+                          ((h * BD + 16 * di + 4 * q) & 31);
+        *reinterpret_cast<u32x2*>(hi + at) = sp.hi;
+        *reinterpret_cast<u32x2*>(lo + at) = sp.lo;
+      }
+    }
+    if (h == 0 && tid < L) { im.scales[b * L + tid] = sc; im.scales[im.M + b * L + tid] = inv_scale(sb); }
   }
 }
 
@@ -292,7 +336,7 @@ using namespace hopmi;
 
 template <typename T>
 static void launch_bert_attn_fwd(const void* qkv, void* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev,
-                                 hipStream_t st) {
+                                 hipStream_t st, BertAttnImage im = BertAttnImage{nullptr, 0, 0, 0, nullptr, nullptr}) {
   const int MT = (L + 15) / 16, LP = 16 * MT;
   const size_t lds = ((size_t)2 * LP * BLD + (size_t)LP * (LP + 4)) * sizeof(float);
   const unsigned thresh = p_drop > 0.f ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
@@ -300,10 +344,10 @@ static void launch_bert_attn_fwd(const void* qkv, void* out, int B, int L, int H
   const T* x = static_cast<const T*>(qkv);
   T* o = static_cast<T*>(out);
   switch (MT) {
-    case 1: hipLaunchKernelGGL((bert_attn_fwd_kernel<1, T>), dim3(B * H), dim3(64), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
-    case 2: hipLaunchKernelGGL((bert_attn_fwd_kernel<2, T>), dim3(B * H), dim3(128), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
-    case 3: hipLaunchKernelGGL((bert_attn_fwd_kernel<3, T>), dim3(B * H), dim3(192), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
-    default: hipLaunchKernelGGL((bert_attn_fwd_kernel<4, T>), dim3(B * H), dim3(256), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev); break;
+    case 1: hipLaunchKernelGGL((bert_attn_fwd_kernel<1, T>), dim3(B * H), dim3(64), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev, im); break;
+    case 2: hipLaunchKernelGGL((bert_attn_fwd_kernel<2, T>), dim3(B * H), dim3(128), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev, im); break;
+    case 3: hipLaunchKernelGGL((bert_attn_fwd_kernel<3, T>), dim3(B * H), dim3(192), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev, im); break;
+    default: hipLaunchKernelGGL((bert_attn_fwd_kernel<4, T>), dim3(B * H), dim3(256), lds, st, x, o, L, H, thresh, dscale, seed, seed_dev, im); break;
   }
 }
 
@@ -339,6 +383,18 @@ extern "C" int hopmi_bert_attn_fwd_dt(const void* qkv, void* out, int B, int L, 
   if (dtype == HOPMI_BF16) launch_bert_attn_fwd<__bf16>(qkv, out, B, L, H, p_drop, seed, seed_dev, st);
   else launch_bert_attn_fwd<float>(qkv, out, B, L, H, p_drop, seed, seed_dev, st);
   return check_launch("hopmi_bert_attn_fwd");
+}
+
+extern "C" int hopmi_bert_attn_fwd_im(const float* qkv, float* out, const float* v_rowmax, int vt0, int vt1, void* image, float* scales, int B,
+                                      int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+  if (int e = bert_attn_validate("hopmi_bert_attn_fwd_im", B, L, H, p_drop)) return e;
+  if (!qkv || !out || !v_rowmax || !image || !scales || vt0 < 0 || vt1 <= vt0 || (H * BD) % 32) {
+    set_error("hopmi_bert_attn_fwd_im: null pointer argument / V tile range [%d, %d) / H * 64 %% 32", vt0, vt1);
+    return HOPMI_EINVAL;
+  }
+  launch_bert_attn_fwd<float>(qkv, out, B, L, H, p_drop, seed, seed_dev, static_cast<hipStream_t>(stream),
+                              BertAttnImage{v_rowmax, vt0, vt1, B * L, static_cast<_Float16*>(image), scales});
+  return check_launch("hopmi_bert_attn_fwd_im");
 }
 
 extern "C" int hopmi_bert_attn_bwd_dt(const void* qkv, const void* d_out, void* dqkv, int B, int L, int H, float p_drop, unsigned seed,

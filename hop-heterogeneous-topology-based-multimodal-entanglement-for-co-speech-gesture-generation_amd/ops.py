@@ -545,11 +545,15 @@ class _SplitLinearFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, img_w, img_wt, bias, N, K, parts):
+    def forward(ctx, x, img_w, img_wt, bias, N, K, parts, rowmax=None):
         x = _dev_f32(x, "x")
         rs = _take_rs(x, x.numel() // K) if parts == F16_PARTS else None
         ai = _take_img(x, x.numel() // K, K) if parts == F16_PARTS else None
-        y = _split_gemm(x.reshape(-1, K), img_w, None if bias is None else _dev_f32(bias.detach(), "bias"), N, K, parts, a_part=rs, a_img=ai)
+        bd = None if bias is None else _dev_f32(bias.detach(), "bias")
+        if rowmax is not None and parts == F16_PARTS:   # (the product's partial row maxima for its consumer: a list that receives them)
+            y = _split_gemm_ep(x.reshape(-1, K), img_w, bd, N, K, parts, 0, a_part=rs, a_img=ai, rowmax=rowmax)[0]
+        else:
+            y = _split_gemm(x.reshape(-1, K), img_w, bd, N, K, parts, a_part=rs, a_img=ai)
         ctx.img_wt, ctx.N, ctx.K, ctx.parts = img_wt, N, K, parts
         return y.view(*x.shape[:-1], N)
 
@@ -560,11 +564,11 @@ class _SplitLinearFn(torch.autograd.Function):
         rs = _take_rs(dy, dy.numel() // ctx.N) if ctx.parts == F16_PARTS else None
         ai = _take_img(dy, dy.numel() // ctx.N, ctx.N) if ctx.parts == F16_PARTS else None
         dx = _split_gemm(dy.reshape(-1, ctx.N), ctx.img_wt, None, ctx.K, ctx.N, ctx.parts, a_part=rs, a_img=ai)      # dX = dY . W = dY . (W^T)^T
-        return dx.view(*dy.shape[:-1], ctx.K), None, None, None, None, None, None
+        return dx.view(*dy.shape[:-1], ctx.K), None, None, None, None, None, None, None
 
 
-def split_linear(x, img_w, img_wt, bias, N, K, parts):
-    return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts)
+def split_linear(x, img_w, img_wt, bias, N, K, parts, rowmax=None):
+    return _SplitLinearFn.apply(x, img_w, img_wt, bias, N, K, parts, rowmax)
 
 
 def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, a_part=None, out=None, rowmax=None, a_img=None, rows=None):
@@ -591,18 +595,11 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
             rowmax.append((cm, cm.shape[0]))
         return out, h
     if parts == F16_PARTS:
-        if (a_part is None and GEMM_AB and epilogue == 0 and rowmax is None and N <= GEMM_AB_MAX_N and K % 32 == 0
+        if (a_part is None and GEMM_AB and epilogue == 0 and N <= GEMM_AB_MAX_N and K % 32 == 0
                 and M >= max(F16_LINEAR_MIN_ROWS, IMG_MIN_ROWS)):
-            # no scales at hand and a problem that one 128 x 128 tile per CU covers: the pass that would take the row scales writes the
-            # operand's fp16 images as well, and the LDS-DMA form multiplies (bit-identical; tools/bench_gemm.py: 24 vs 30 us at
-            # N = K = 768, 71 vs 92 at K = 3072, M = 4352)
-            img_a = torch.empty(L.hopmi_rows_image_f16_bytes(M, K), dtype=torch.uint8, device=a2d.device)
-            sc = torch.empty(2, M, dtype=torch.float32, device=a2d.device)
-            _lib.check(L.hopmi_rows_image_f16(a2d.data_ptr(), M, K, img_a.data_ptr(), sc.data_ptr(), _stream()), "hopmi_rows_image_f16")
-            _lib.check(_timed("gemm_split", 4 * (M * K + M * N) + 4 * N * K, 2 * M * N * K,
-                              lambda: L.hopmi_gemm_f16x2_ab(img_a.data_ptr(), sc.data_ptr(), img.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K,
-                                                            _stream())), "hopmi_gemm_f16x2_ab")
-            return out, None
+            # no scales at hand: the pass that would take the row scales writes the operand's fp16 images as well, and the LDS-DMA form
+            # multiplies (bit-identical to row scales + the split form)
+            return _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=keep, aux=aux, out=out, rowmax=rowmax, a_img=rows_image(a2d))
         if a_part is None:
             a_part = row_scales(a2d)
             _attach_rs(a2d, a_part)                    # (a later consumer of the same tensor object -- the weight-gradient GEMM -- takes them)
@@ -1434,23 +1431,36 @@ class _BertAttnFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, qkv, p_drop, seed):
+    def forward(ctx, qkv, p_drop, seed, vmax=None):
         qkv = _dev_f32(qkv, "qkv")
         B, L, three, H, dh = qkv.shape
         if three != 3 or dh != 64 or L > 64:
             raise _lib.HopmiError(f"hopmi bert_attn: unsupported qkv shape {tuple(qkv.shape)} (need (B, L<=64, 3, H, 64))")
         out = torch.empty(B, L, H * dh, dtype=torch.float32, device=qkv.device)
         Lb, st, sp = _lib.lib(), _stream(), _seed_ptr()
-        _lib.check(_timed("bert_attn_fwd", 4 * 4 * B * L * H * dh, 4 * B * H * L * L * dh,
-                          lambda: Lb.hopmi_bert_attn_fwd(qkv.data_ptr(), out.data_ptr(), B, L, H, float(p_drop), int(seed), sp, st)),
-                   "hopmi_bert_attn_fwd")
+        img = sc = None
+        D, M = H * dh, B * L
+        if vmax is not None and D % 128 == 0 and tuple(vmax[0].shape) == (3 * D // 128, M) and vmax[0].is_contiguous():
+            # the output's operand image for the attention-output GEMM, scaled per clip from the QKV product's row maxima of V
+            img = torch.empty(Lb.hopmi_rows_image_f16_bytes(M, D), dtype=torch.uint8, device=qkv.device)
+            sc = torch.empty(2, M, dtype=torch.float32, device=qkv.device)
+            _lib.check(_timed("bert_attn_fwd", 4 * 5 * B * L * H * dh, 4 * B * H * L * L * dh,
+                              lambda: Lb.hopmi_bert_attn_fwd_im(qkv.data_ptr(), out.data_ptr(), vmax[0].data_ptr(), 2 * D // 128, 3 * D // 128,
+                                                                img.data_ptr(), sc.data_ptr(), B, L, H, float(p_drop), int(seed), sp, st)),
+                       "hopmi_bert_attn_fwd_im")
+        else:
+            _lib.check(_timed("bert_attn_fwd", 4 * 4 * B * L * H * dh, 4 * B * H * L * L * dh,
+                              lambda: Lb.hopmi_bert_attn_fwd(qkv.data_ptr(), out.data_ptr(), B, L, H, float(p_drop), int(seed), sp, st)),
+                       "hopmi_bert_attn_fwd")
         ctx.save_for_backward(qkv)
         ctx.p_drop, ctx.seed, ctx.sp = float(p_drop), int(seed), sp
-        return out
+        if img is not None:
+            ctx.mark_non_differentiable(img, sc)
+        return out, img, sc
 
     @staticmethod
     @_bwd32
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         (qkv,) = ctx.saved_tensors
         dout = _dev_f32(dout, "dout")
         B, L, _, H, dh = qkv.shape
@@ -1459,12 +1469,20 @@ class _BertAttnFn(torch.autograd.Function):
         _lib.check(_timed("bert_attn_bwd", 4 * 7 * B * L * H * dh, 10 * B * H * L * L * dh,
                           lambda: Lb.hopmi_bert_attn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, L, H,
                                                          ctx.p_drop, ctx.seed, ctx.sp, st)), "hopmi_bert_attn_bwd")
-        return dqkv, None, None
+        return dqkv, None, None, None
 
 
-def bert_attention(qkv: torch.Tensor, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
-    """dropout(softmax(q k^T / 8)) v for every (clip, head) of qkv (B,L,3,H,64) -> (B,L,H*64)."""
-    return _BertAttnFn.apply(qkv, p_drop, seed)
+ATTN_IMG = __import__("os").environ.get("HOPMI_ATTN_IMG", "1") != "0"     # the attention kernel writes the next GEMM's operand image
+
+
+def bert_attention(qkv: torch.Tensor, p_drop: float = 0.0, seed: int = 0, v_rowmax=None) -> torch.Tensor:
+    """dropout(softmax(q k^T / 8)) v for every (clip, head) of qkv (B,L,3,H,64) -> (B,L,H*64).  `v_rowmax`: the (c_rowmax, tiles)
+    pair the QKV product left (`rowmax` of split_linear): the kernel then also writes the output's fp16 hi / lo operand image for
+    the attention-output GEMM."""
+    out, img, sc = _BertAttnFn.apply(qkv, p_drop, seed, v_rowmax)
+    if img is not None:
+        _attach_img(out, img, sc)
+    return out
 
 
 class _ReprogAttnFn(torch.autograd.Function):

@@ -274,6 +274,12 @@ int hopmi_colsum(const void* x, int dtype, int M, int N, float* out, float* ws, 
  *   recomputed, nothing is saved.  Dropout keeps (b*L + l, h, key) iff hash(seed, b*L + l, h, key) >= p_drop * 2^32
  *   (same stateless hash as hopmi_reprog_attn_fwd).  One workgroup per (b, h): no atomics, reproducible. */
 int hopmi_bert_attn_fwd(const float* qkv, float* out, int B, int L, int H, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
+/* ... (round 5, fp32) also writing `out`'s fp16 hi / lo operand image (hopmi_rows_image_f16_bytes(B L, 64 H)) and its [2][B L] row
+ * scales for the attention-output GEMM (hopmi_gemm_f16x2_ab_ep).  A row spans the H workgroups of its clip, so the scale is one per
+ * clip from a bound: |dropout(P) V| <= max |V[clip]| / (1 - p); max |V| is read from v_rowmax = the QKV product's c_rowmax
+ * [tiles][B L] (hopmi_gemm_f16x2 / _ab_ep), V's columns being tiles vt0 .. vt1 - 1. */
+int hopmi_bert_attn_fwd_im(const float* qkv, float* out, const float* v_rowmax, int vt0, int vt1, void* image, float* scales, int B, int L,
+                           int H, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream);
 int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* dqkv, int B, int L, int H, float p_drop,
                         unsigned seed, const unsigned* seed_dev, void* stream);
 

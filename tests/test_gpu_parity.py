@@ -1937,6 +1937,48 @@ def test_layernorm_operand_images_feed_the_lds_dma_gemm(monkeypatch):
     assert rel_err(res_d["image"][2], res_d["split"][2]) <= 2e-6
 
 
+def test_bert_attention_writes_the_next_gemms_operand_image(monkeypatch):
+    """hopmi_bert_attn_fwd_im: the attention kernel also writes its output's fp16 hi / lo operand image, scaled per clip from the
+    bound |dropout(P) V| <= max |V[clip]| / (1 - p) (max |V| from the QKV product's partial row maxima) -- the fp32 output is
+    bit-identical to the plain entry's, the image reproduces it to 2^-22 of the clip's bound, every |out| respects the bound, and the
+    attention-output product fed by the image is fp32-class (error vs float64 <= 2 x the split form's + 1.2e-7), with dropout."""
+    from hopmi import ops, _lib
+    dev = _dev()
+    monkeypatch.setattr(ops, "GEMM_PARTS", 16)
+    monkeypatch.setattr(ops, "IMG_MIN_ROWS", 1024)
+    g = torch.Generator().manual_seed(21)
+    B, L, H, D = 40, 34, 12, 768
+    M = B * L
+    x = (torch.randn(M, D, generator=g) * torch.logspace(-1, 1, M).unsqueeze(1)).to(dev)
+    wqkv = (torch.randn(3 * D, D, generator=g) / D ** 0.5).to(dev)
+    bqkv = torch.randn(3 * D, generator=g).to(dev)
+    wo = (torch.randn(D, D, generator=g) / D ** 0.5).to(dev)
+    iq, iqt = ops.split_weight_image(wqkv, 16), ops.split_weight_image(wqkv.t().contiguous(), 16)
+    io, iot = ops.split_weight_image(wo, 16), ops.split_weight_image(wo.t().contiguous(), 16)
+    rm = []
+    qkv = ops.split_linear(x, iq, iqt, bqkv, 3 * D, D, 16, rowmax=rm).view(B, L, 3, H, 64)
+    assert len(rm) == 1 and tuple(rm[0][0].shape) == (18, M)
+    vmax_clip = qkv[:, :, 2].abs().amax(dim=(1, 2, 3))
+    assert torch.equal(rm[0][0][12:].view(6, B, L).amax(dim=(0, 2)), vmax_clip)
+    for p_drop in (0.0, 0.1):
+        a_img = ops.bert_attention(qkv, p_drop, 77, v_rowmax=rm[0])
+        a_ref = ops.bert_attention(qkv, p_drop, 77)
+        assert torch.equal(a_img, a_ref)
+        got = ops._take_img(a_img, M, D)
+        assert got is not None and ops._take_img(a_ref, M, D) is None
+        img, sc = got
+        bound = (vmax_clip / (1.0 - p_drop)).repeat_interleave(L)
+        assert (a_ref.view(M, D).abs().amax(1) <= bound * 1.001).all()
+        assert (sc[0] * bound < 32768.0 * 1.002).all() and (sc[0] * bound >= 16384.0 * 0.999).all()
+        o_img = ops.split_linear(a_img, io, iot, None, D, D, 16)
+        o_split = ops.split_linear(a_ref, io, iot, None, D, D, 16)
+        want = a_ref.view(M, D).double() @ wo.double().t()
+        den = want.abs().amax(1, keepdim=True)
+        e_img = ((o_img.view(M, D).double() - want).abs() / den).max().item()
+        e_split = ((o_split.view(M, D).double() - want).abs() / den).max().item()
+        assert e_img <= 2.0 * e_split + 1.2e-7, (p_drop, e_img, e_split)
+
+
 @pytest.mark.parametrize("M,K,N", [(1500, 30522, 768), (188, 30522, 768), (130, 4610, 36), (64, 66, 4)])
 def test_mapping_forward_split_k_vs_float64(M, K, N):
     """hopmi_gemm_f16x2_ab_splitk: S = W E + b[:, None] (the mapping layer's forward, HOP.py:200: 1500 x 768 outputs, K = vocab =
