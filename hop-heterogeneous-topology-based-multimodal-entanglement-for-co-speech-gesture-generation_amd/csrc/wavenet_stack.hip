@@ -258,6 +258,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
                                                                    // finalisation sits on the critical path of every exchange)
   float* WINV = GB + STK_MAX_LAYERS * 2 * C;                       // [n_layers][192] inverse weight scales: filter | gate | Wm (x 1 / s_h)
   float* RSI = WINV + STK_MAX_LAYERS * 3 * C;                      // [rows_lds] inverse of the tap panels' row scales
+  float* RSL = RSI + rows_lds;                                     // [1] the layer's uniform operand scale (layers behind a BatchNorm)
   // exchange scratch, aliased onto the (dead between layers) operand images Hh | Hl: 2 x rows_lds x 416 B >= 16.6 KB at MT = 1
   float* RED = reinterpret_cast<float*>(Hh);                       // [2][128] floats
   double* COMB = reinterpret_cast<double*>(RED + 4 * C);           // [4][128] doubles
@@ -395,8 +396,19 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 
       // ---- phase 0: both tap panels (in flight since before the statistics arrived for the first tile) -> normalise -> split -> LDS
       if (tile != bid) issue_tile(L, tile);          // (its producers' flags were checked with the first tile's, see the exchange)
-      const float4 sc4 = reinterpret_cast<const float4*>(SCSH)[c4];
-      const float4 sh4 = reinterpret_cast<const float4*>(SCSH + C)[c4];
+      float4 sc4 = reinterpret_cast<const float4*>(SCSH)[c4];
+      float4 sh4 = reinterpret_cast<const float4*>(SCSH + C)[c4];
+      // Layers behind a BatchNorm take ONE power-of-two operand scale for the whole layer from an a-priori bound (computed with the
+      // scale / shift rows at the end of the exchange): |gamma_c| sqrt(n - 1) + |beta_c| bounds every normalised value, values at one
+      // sigma sit 2^-7 ... 2^-9 below it -- far inside the 2^17 window in which an fp16 hi / lo pair keeps 22 bits (f16_dev.h) -- and the
+      // scale folds into the scale / shift the tile is multiplied with anyway (a power of two: exact).  Layer 0 reads the start
+      // conv's output, which has no such bound: per-row scales from the row maxima (a DPP row reduction per row).
+      const bool uni = layer > 0;
+      const float rsl = uni ? RSL[0] : 1.f, irsl = inv_pow2(rsl);
+      if (uni) {
+        sc4 = make_float4(sc4.x * rsl, sc4.y * rsl, sc4.z * rsl, sc4.w * rsl);
+        sh4 = make_float4(sh4.x * rsl, sh4.y * rsl, sh4.z * rsl, sh4.w * rsl);
+      }
       __syncthreads();                               // previous tile's LDS fully consumed
       STK_STAMP(layer, 12);
 #pragma unroll
@@ -407,15 +419,19 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           a = make_float4(a.x * sc4.x + sh4.x, a.y * sc4.y + sh4.y, a.z * sc4.z + sh4.z, a.w * sc4.w + sh4.w);
           b2 = make_float4(b2.x * sc4.x + sh4.x, b2.y * sc4.y + sh4.y, b2.z * sc4.z + sh4.z, b2.w * sc4.w + sh4.w);
           if (!ok[it]) { a = make_float4(0.f, 0.f, 0.f, 0.f); b2 = a; }
-          // one power-of-two scale per output row over BOTH taps (the row's 128 values sit in the 16 lanes of a DPP row)
-          const float rs = scale_for_absmax(row16_max(absmax4(absmax4(0.f, a), b2)));
+          float rs = 1.f, irs = irsl;
+          if (!uni) {
+            // one power-of-two scale per output row over BOTH taps (the row's 128 values sit in the 16 lanes of a DPP row)
+            rs = scale_for_absmax(row16_max(absmax4(absmax4(0.f, a), b2)));
+            irs = inv_pow2(rs);
+          }
           const Split4 sa = split4h(a.x * rs, a.y * rs, a.z * rs, a.w * rs), sb = split4h(b2.x * rs, b2.y * rs, b2.z * rs, b2.w * rs);
           const int off = row * RS + 4 * c4;
           *reinterpret_cast<u32x2*>(R0h + off) = sa.hi;
           *reinterpret_cast<u32x2*>(R0l + off) = sa.lo;
           *reinterpret_cast<u32x2*>(R1h + off) = sb.hi;
           *reinterpret_cast<u32x2*>(R1l + off) = sb.lo;
-          if (c4 == 0) RSI[row] = inv_pow2(rs);
+          if (c4 == 0) RSI[row] = irs;
         }
       }
       // the TCN weight fragments (L2-resident image, 128 KiB per workgroup through the CU's 64 B/clk vector-memory path: ~2 000
@@ -461,7 +477,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
           const int mt = 2 * i + h;
           if (mt < MT && mt < nt) {
             const int row = 16 * mt + j;
-            const float ir = RSI[row];
+            const float ir = uni ? irsl : RSI[row];          // (uniform layers: a scalar, no LDS read)
             const float4 isf4 = *reinterpret_cast<const float4*>(WINV + layer * 3 * C + 16 * w + 4 * q);
             const float4 isg4 = *reinterpret_cast<const float4*>(WINV + layer * 3 * C + C + 16 * w + 4 * q);
             // pre-activations in real units: accumulator x (1 / row scale) x (1 / output channel's weight scale) + bias
@@ -523,7 +539,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         const int row = 16 * mt + j;
         if (mt < MT && row < R) {
           const float4 res = join4h(*reinterpret_cast<const u32x2*>(R1h + row * RS + 16 * w + 4 * q),
-                                    *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q), RSI[row]);
+                                    *reinterpret_cast<const u32x2*>(R1l + row * RS + 16 * w + 4 * q), uni ? irsl : RSI[row]);
           const float4 ism4 = *reinterpret_cast<const float4*>(WINV + layer * 3 * C + 2 * C + 16 * w + 4 * q);   // (1 / s_o)(1 / s_h)
           const f32x4 yv = {acc[i][0] * ism4.x + bias4.x + res.x, acc[i][1] * ism4.y + bias4.y + res.y, acc[i][2] * ism4.z + bias4.z + res.z,
                             acc[i][3] * ism4.w + bias4.w + res.w};
@@ -694,6 +710,14 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         const float unbiased = varf * L.unbias;
         SCSH[tid] = sc;
         SCSH[C + tid] = sh;
+        {
+          // the next layer's uniform operand scale: |BN(y)_c| <= |gamma_c| sqrt(n - 1) + |beta_c| (a deviation from the mean is at most
+          // sqrt(n - 1) biased standard deviations; rstd sqrt(var) <= 1); 1/16 on top for the storage rounding of y (bf16 mode) and the
+          // fp32 evaluation.  This block runs in wave 0 only (tid < C = 64): one wave reduction.
+          const float bnd = (fabsf(GB[layer * 2 * C + tid]) * sqrtf((float)(1.0 / L.inv_n)) + fabsf(GB[layer * 2 * C + C + tid])) * 1.0625f;
+          const float mx = wave_max_nonneg(bnd);
+          if (tid == 0) RSL[0] = scale_for_absmax(mx);
+        }
         if (bid == 0) {                              // one writer of the layer's outputs
           float* so = A.scsh_out + layer * 2 * C;
           float* mr = A.mean_rstd + layer * 3 * C;
@@ -719,7 +743,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 
 static size_t stk_lds_bytes(int mt, int KP, int ldA) {
   const size_t rows_lds = 16 * mt + 4;
-  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * (LDD + 1) + (size_t)KP * ldA + 2 * C) * sizeof(float) + 16 +
+  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * (LDD + 1) + (size_t)KP * ldA + 2 * C) * sizeof(float) + 32 +
          (size_t)STK_MAX_LAYERS * (2 + 3) * C * sizeof(float);
 }
 
