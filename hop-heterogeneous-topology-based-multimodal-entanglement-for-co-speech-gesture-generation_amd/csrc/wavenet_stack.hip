@@ -258,7 +258,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
                                                                    // finalisation sits on the critical path of every exchange)
   float* WINV = GB + STK_MAX_LAYERS * 2 * C;                       // [n_layers][192] inverse weight scales: filter | gate | Wm (x 1 / s_h)
   float* RSI = WINV + STK_MAX_LAYERS * 3 * C;                      // [rows_lds] inverse of the tap panels' row scales
-  float* RSL = RSI + rows_lds;                                     // [1] the layer's uniform operand scale (layers behind a BatchNorm)
+  float* RSL = RSI + rows_lds;                                     // [n_layers] uniform operand scale of layer l's input (l >= 1: behind a BatchNorm)
   // exchange scratch, aliased onto the (dead between layers) operand images Hh | Hl: 2 x rows_lds x 416 B >= 16.6 KB at MT = 1
   float* RED = reinterpret_cast<float*>(Hh);                       // [2][128] floats
   double* COMB = reinterpret_cast<double*>(RED + 4 * C);           // [4][128] doubles
@@ -290,7 +290,16 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
     const float v = reinterpret_cast<const float*>(A.wimg + (size_t)l * WIMGH_UNITS + WIMG_UNITS)[c];
     WINV[idx] = c < 2 * C ? v : v * ish;
   }
-  if (tid == 0) { FLAG[0] = FLAG[1] = FLAG[2] = 0; FLAG[3] = *reinterpret_cast<volatile int*>(A.sync); }   // [3]: launch sequence number
+  // The uniform operand scales of the layers behind a BatchNorm depend on the PARAMETERS only: |BN_l(y)_c| <= |gamma_c| sqrt(n - 1) +
+  // |beta_c| (a deviation from the mean is at most sqrt(n - 1) biased standard deviations; rstd sqrt(var) <= 1), 1/16 on top for the
+  // storage rounding of y (bf16 mode) and the fp32 evaluation.  Wave l computes layer l + 1's scale here, off every critical path.
+  if (wv + 1 < A.n_layers) {
+    const float g0 = A.L[wv].gamma[lane], b0 = A.L[wv].beta[lane];
+    const float bnd = (fabsf(g0) * sqrtf((float)(1.0 / A.L[wv].inv_n)) + fabsf(b0)) * 1.0625f;
+    const float mx = wave_max_nonneg(bnd);
+    if (lane == 0) RSL[wv + 1] = scale_for_absmax(mx);
+  }
+  if (tid == 0) { RSL[0] = 1.f; FLAG[0] = FLAG[1] = FLAG[2] = 0; FLAG[3] = *reinterpret_cast<volatile int*>(A.sync); }   // [3]: launch sequence number
   // u rows this workgroup never writes (tiles smaller than MT, the 4 padding rows) are read by the node mix's K padding times
   // zero: they must be finite
   for (int idx = tid; idx < rows_lds * LDD; idx += STK_THREADS) U[idx] = 0.f;
@@ -398,13 +407,13 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       if (tile != bid) issue_tile(L, tile);          // (its producers' flags were checked with the first tile's, see the exchange)
       float4 sc4 = reinterpret_cast<const float4*>(SCSH)[c4];
       float4 sh4 = reinterpret_cast<const float4*>(SCSH + C)[c4];
-      // Layers behind a BatchNorm take ONE power-of-two operand scale for the whole layer from an a-priori bound (computed with the
-      // scale / shift rows at the end of the exchange): |gamma_c| sqrt(n - 1) + |beta_c| bounds every normalised value, values at one
+      // Layers behind a BatchNorm take ONE power-of-two operand scale for the whole layer from an a-priori bound (computed in the
+      // kernel's prologue from gamma / beta): |gamma_c| sqrt(n - 1) + |beta_c| bounds every normalised value, values at one
       // sigma sit 2^-7 ... 2^-9 below it -- far inside the 2^17 window in which an fp16 hi / lo pair keeps 22 bits (f16_dev.h) -- and the
       // scale folds into the scale / shift the tile is multiplied with anyway (a power of two: exact).  Layer 0 reads the start
       // conv's output, which has no such bound: per-row scales from the row maxima (a DPP row reduction per row).
       const bool uni = layer > 0;
-      const float rsl = uni ? RSL[0] : 1.f, irsl = inv_pow2(rsl);
+      const float rsl = uni ? RSL[layer] : 1.f, irsl = inv_pow2(rsl);
       if (uni) {
         sc4 = make_float4(sc4.x * rsl, sc4.y * rsl, sc4.z * rsl, sc4.w * rsl);
         sh4 = make_float4(sh4.x * rsl, sh4.y * rsl, sh4.z * rsl, sh4.w * rsl);
@@ -710,14 +719,6 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         const float unbiased = varf * L.unbias;
         SCSH[tid] = sc;
         SCSH[C + tid] = sh;
-        {
-          // the next layer's uniform operand scale: |BN(y)_c| <= |gamma_c| sqrt(n - 1) + |beta_c| (a deviation from the mean is at most
-          // sqrt(n - 1) biased standard deviations; rstd sqrt(var) <= 1); 1/16 on top for the storage rounding of y (bf16 mode) and the
-          // fp32 evaluation.  This block runs in wave 0 only (tid < C = 64): one wave reduction.
-          const float bnd = (fabsf(GB[layer * 2 * C + tid]) * sqrtf((float)(1.0 / L.inv_n)) + fabsf(GB[layer * 2 * C + C + tid])) * 1.0625f;
-          const float mx = wave_max_nonneg(bnd);
-          if (tid == 0) RSL[0] = scale_for_absmax(mx);
-        }
         if (bid == 0) {                              // one writer of the layer's outputs
           float* so = A.scsh_out + layer * 2 * C;
           float* mr = A.mean_rstd + layer * 3 * C;
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 
 static size_t stk_lds_bytes(int mt, int KP, int ldA) {
   const size_t rows_lds = 16 * mt + 4;
-  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * (LDD + 1) + (size_t)KP * ldA + 2 * C) * sizeof(float) + 32 +
+  return rows_lds * (4 * RS + 2 * HS) * sizeof(__bf16) + (rows_lds * (LDD + 1) + (size_t)KP * ldA + 2 * C) * sizeof(float) + 16 + STK_MAX_LAYERS * sizeof(float) +
          (size_t)STK_MAX_LAYERS * (2 + 3) * C * sizeof(float);
 }
 
