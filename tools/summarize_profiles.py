@@ -78,8 +78,9 @@ with open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.csv"), "w") as f:
                 line = [l for l in open(_os.path.join(root, "prof_stats.log")) if l.startswith("{")][-1]
                 d = _json.loads(line)
                 span = [int(tr[b]["Start_Timestamp"]) - int(tr[a]["Start_Timestamp"]) for a, b in zip(marks[-n_rep - 1:-1], marks[-n_rep:])]
+                span.sort()
                 own = (f"; the SAME run's bench line: ms_per_step {d['ms_per_step']:.3f} (median {d.get('median_ms_per_step', 0):.3f}); wall time of those windows "
-                       f"{sum(span) / len(span) / 1e6:.3f} ms")
+                       f"median {span[len(span) // 2] / 1e6:.3f} ms, shortest {span[0] / 1e6:.3f}, longest {span[-1] / 1e6:.3f}")
             except Exception:          # noqa: BLE001
                 pass
             f.write(f"# replayed steps: {n_rep} windows between consecutive hop_losses_fwd_kernel launches at the end of the run; kernel time per replayed step "
