@@ -330,6 +330,14 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 #pragma unroll
         for (int part = 0; part < 2; ++part) wt[gate][ks][part] = tp[((gate * 4 + ks) * 2 + part) * 64];
   };
+  // (one k-step's fragments of both gates: issued between the commit loop's iterations, see phase 0)
+  auto load_wt_ks = [&](int layer, int ks) {
+    const u32x4* tp = A.wimg + (size_t)layer * WIMGH_UNITS + (size_t)(w * 2) * 4 * 2 * 64 + lane;
+#pragma unroll
+    for (int gate = 0; gate < 2; ++gate)
+#pragma unroll
+      for (int part = 0; part < 2; ++part) wt[gate][ks][part] = tp[((gate * 4 + ks) * 2 + part) * 64];
+  };
   auto load_wm = [&](int layer) {
     const u32x4* mp = A.wimg + (size_t)layer * WIMGH_UNITS + WIMG_TCN_UNITS + (size_t)(w * 6) * 2 * 64 + lane;
 #pragma unroll
@@ -422,6 +430,13 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       STK_STAMP(layer, 12);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
+#ifndef STK_EXP_NO_WT
+        // the TCN weight fragments (L2-resident image, 128 KiB per workgroup through the CU's 64 B/clk vector-memory path: ~2 000
+        // cycles of ISSUE) ride between the commit's iterations, one k-step's four loads at a time: the conversions of iteration
+        // `it` run while they are in the memory pipe.  (All 16 in front of the commit made the waves sit in their issue; all 16
+        // behind it -- rounds 3-4 -- put the 2 000 cycles on the critical path of every layer.)
+        if (it < 4) { load_wt_ks(layer, it); __builtin_amdgcn_sched_barrier(0); }
+#endif
         const int row = (tid >> 4) + (STK_THREADS / 16) * it;
         if (row < rows_lds) {
           float4 a = IO::cvt(x0r[it]), b2 = IO::cvt(x1r[it]);
@@ -451,7 +466,10 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 #ifdef STK_EXP_NO_WT
       if (layer == 0) load_wt(layer);                // (timing experiment: results wrong)
 #else
-      load_wt(layer);
+      // (the k-steps the commit loop had no iteration for; spreading all four over the iterations measured no better: 93.8-95.8 us
+      // against 94.3-95.0, V = 42 219.6 against 216.7)
+#pragma unroll
+      for (int ks = NIT < 4 ? NIT : 4; ks < 4; ++ks) load_wt_ks(layer, ks);
 #endif
       __syncthreads();
       STK_STAMP(layer, 1);
