@@ -338,6 +338,11 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 #pragma unroll
       for (int part = 0; part < 2; ++part) wt[gate][ks][part] = tp[((gate * 4 + ks) * 2 + part) * 64];
   };
+  auto load_wm_ks = [&](int layer, int ks) {
+    const u32x4* mp = A.wimg + (size_t)layer * WIMGH_UNITS + WIMG_TCN_UNITS + (size_t)(w * 6) * 2 * 64 + lane;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) wm[ks][part] = mp[(ks * 2 + part) * 64];
+  };
   auto load_wm = [&](int layer) {
     const u32x4* mp = A.wimg + (size_t)layer * WIMGH_UNITS + WIMG_TCN_UNITS + (size_t)(w * 6) * 2 * 64 + lane;
 #pragma unroll
@@ -501,6 +506,13 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
         STK_STAMP(layer, 2);
 #pragma unroll
         for (int i = 0; i < MTH; ++i) {
+#ifndef STK_EXP_NO_WT
+          // (the graph-conv weight fragments -- 96 KiB per workgroup, ~1 500 cycles of issue -- ride between the gate loop's
+          // iterations like the TCN fragments between the commit's: two k-steps per iteration, the rest behind the loop)
+#pragma unroll
+          for (int ks = 2 * i; ks < 2 * i + 2 && ks < 6; ++ks) load_wm_ks(layer, ks);
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           const int mt = 2 * i + h;
           if (mt < MT && mt < nt) {
             const int row = 16 * mt + j;
@@ -522,7 +534,8 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
 #ifdef STK_EXP_NO_WT
         if (layer == 0) load_wm(layer);
 #else
-        load_wm(layer);                              // (behind the gate for the same reason) lands behind the node-mix phase
+#pragma unroll
+        for (int ks = 2 * MTH < 6 ? 2 * MTH : 6; ks < 6; ++ks) load_wm_ks(layer, ks);     // (what the loop had no iteration for)
 #endif
       }
       __syncthreads();
