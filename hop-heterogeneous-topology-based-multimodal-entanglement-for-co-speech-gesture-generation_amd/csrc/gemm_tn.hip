@@ -5,14 +5,16 @@
 //
 // What is different from the NT form: the MFMA wants 8 CONSECUTIVE contraction indices per lane, and here those are 8 consecutive
 // ROWS of a row-major matrix.  The transposition happens on the way into LDS: a thread owns one column of the tile and eight
-// consecutive rows (of each 32-row half of the step) -- eight 4-byte loads, each wave instruction one contiguous 256-byte piece of a
-// row -- scales, splits and writes them as ONE 16-byte ds_write per part into the transposed images At[n][m], Bt[k][m] (rows of 64 m =
-// 128 bytes, row stride 144 bytes: both the column-major stores and the fragment reads hit 16 distinct 16-byte slots per service group).
+// consecutive rows -- eight 4-byte loads, each wave instruction one contiguous 256-byte piece of a row -- scales, splits and
+// writes them as ONE 16-byte ds_write per part into the transposed images At[n][m], Bt[k][m] (rows of 32 m = 64 bytes, row stride
+// 80 bytes: both the column-major stores and the fragment reads hit 16 distinct 16-byte slots per service group).
 // Scales: the contraction index is the row, so rows cannot carry scales of their own; each operand gets ONE power of two, the
 // smallest of its per-row scales (hopmi_row_scales / the producers' fused scales: the consumers of the same tensors as A operands of
 // the NT form have them already), found by every workgroup in its prologue (M floats per operand from L2).
-// Tiles 128 (n) x 128 (k), 8 waves of 64 x 32, m-steps of 64 rows = two MFMA k-blocks between two barriers (32-row steps: 3-9 % slower
-// on the weight-gradient shapes, 14.49 vs 14.42 ms per step); the m range is SPLIT over workgroups when the output has too few
+// Tiles 128 (n) x 128 (k), 8 waves of 64 x 32, m-steps of 32 (64-row steps -- two MFMA k-blocks per barrier pair, 74 KB of LDS -- are 3-9 %
+// faster back to back and were dropped: the GAN-phase step went from 20.5 to 21.4 ms with them, reproducibly, with multi-millisecond
+// gaps inside graph replays -- every kernel of the step a few per cent slower; the larger LDS footprint next to the persistent
+// kernels of that phase is the suspect); the m range is SPLIT over workgroups when the output has too few
 // tiles for the chip (a GRU's 1050 x 350 recurrent gradient: 27 tiles): split s writes slab s of a workspace, a second launch adds
 // the slabs in index order -- bitwise reproducible, no atomics.
 #include "f16_dev.h"
@@ -20,8 +22,8 @@
 namespace hopmi {
 
 constexpr int TN_T = 128;          // output tile (both ways)
-constexpr int TN_MS = 64;          // rows (contraction) per step: two 32-row MFMA k-blocks between two barriers
-constexpr int TN_LD = 72;          // LDS row stride in halves (144 bytes = 9 x 16: the 16 lanes of a service group hit 16 distinct slots)
+constexpr int TN_MS = 32;          // rows (contraction) per step
+constexpr int TN_LD = 40;          // LDS row stride in halves (80 bytes)
 constexpr int TN_THREADS = 512;
 
 struct TnArgs {
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_f16_tn_kernel(TnArgs P) {
   const auto br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (unsigned)(((size_t)(P.M - 1) * P.ldb + P.K) * 4), 0x00020000);
   const int step0 = split * P.steps_per_split;
   const int nsteps = max(0, min(P.steps_per_split, (P.M + TN_MS - 1) / TN_MS - step0));
-  const unsigned a_voff = (unsigned)(((step0 * TN_MS + 8 * o) * P.lda + n0 + c) * 4);      // (second half of the step: + 32 rows)
+  const unsigned a_voff = (unsigned)(((step0 * TN_MS + 8 * o) * P.lda + n0 + c) * 4);
   const unsigned b_voff = (unsigned)(((step0 * TN_MS + 8 * o) * P.ldb + k0 + c) * 4);
   _Float16* At = lds;
   _Float16* Bt = lds + 2 * TN_T * TN_LD;
@@ -87,33 +89,26 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_f16_tn_kernel(TnArgs P) {
   // vmcnt waits -- a lone workgroup stays at 1.3 us per step either way: like the NT form the step is the MFMA phase (~1 900 cycles
   // for 192 MFMAs) plus the split / commit phase (~1 300) between two barriers, not the loads' latency; what overlaps the two is the
   // CU's second workgroup.)
-  float av[16], bv[16];
+  float av[8], bv[8];
   auto issue = [&](int step) {
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        av[8 * hf + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, a_voff, (step * TN_MS + 32 * hf + e) * P.lda * 4, 0));
-        bv[8 * hf + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, b_voff, (step * TN_MS + 32 * hf + e) * P.ldb * 4, 0));
-      }
+    for (int e = 0; e < 8; ++e) {
+      av[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, a_voff, (step * TN_MS + e) * P.lda * 4, 0));
+      bv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, b_voff, (step * TN_MS + e) * P.ldb * 4, 0));
+    }
   };
   // (the bias gradient of the same linear is the column sum of A = dY: the workgroups of the first k-tile column add up what they
   // stage anyway -- thread (c, o) owns column c, rows 8 o .. 8 o + 7 of every step)
   const bool want_cs = P.colsum != nullptr && tk == 0;
   float asum = 0.f;
   auto commit = [&]() {
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const float* a8 = av + 8 * hf;
-      const float* b8 = bv + 8 * hf;
-      if (want_cs) asum += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-      const Split8 sa = split8h(make_float4(a8[0], a8[1], a8[2], a8[3]), make_float4(a8[4], a8[5], a8[6], a8[7]), sA);
-      const Split8 sb = split8h(make_float4(b8[0], b8[1], b8[2], b8[3]), make_float4(b8[4], b8[5], b8[6], b8[7]), sB);
-      *reinterpret_cast<u32x4*>(At + st_off + 32 * hf) = sa.hi;
-      *reinterpret_cast<u32x4*>(At + TN_T * TN_LD + st_off + 32 * hf) = sa.lo;
-      *reinterpret_cast<u32x4*>(Bt + st_off + 32 * hf) = sb.hi;
-      *reinterpret_cast<u32x4*>(Bt + TN_T * TN_LD + st_off + 32 * hf) = sb.lo;
-    }
+    if (want_cs) asum += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+    const Split8 sa = split8h(make_float4(av[0], av[1], av[2], av[3]), make_float4(av[4], av[5], av[6], av[7]), sA);
+    const Split8 sb = split8h(make_float4(bv[0], bv[1], bv[2], bv[3]), make_float4(bv[4], bv[5], bv[6], bv[7]), sB);
+    *reinterpret_cast<u32x4*>(At + st_off) = sa.hi;
+    *reinterpret_cast<u32x4*>(At + TN_T * TN_LD + st_off) = sa.lo;
+    *reinterpret_cast<u32x4*>(Bt + st_off) = sb.hi;
+    *reinterpret_cast<u32x4*>(Bt + TN_T * TN_LD + st_off) = sb.lo;
   };
 
   f32x4 acc[4][2];
@@ -132,23 +127,20 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_f16_tn_kernel(TnArgs P) {
     const int ln = tid & 63, qq = ln >> 4, nn = ln & 15;
     const bool more = s + 1 < nsteps;
     if (more) issue(s + 1);
+    const _Float16* la = At + (64 * wr + nn) * TN_LD + 8 * qq;
+    const _Float16* lb = Bt + (32 * wc + nn) * TN_LD + 8 * qq;
+    u32x4 bh[2], bl[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {                   // the step's two 32-row k-blocks
-      const _Float16* la = At + (64 * wr + nn) * TN_LD + 32 * kb + 8 * qq;
-      const _Float16* lb = Bt + (32 * wc + nn) * TN_LD + 32 * kb + 8 * qq;
-      u32x4 bh[2], bl[2];
+    for (int ni = 0; ni < 2; ++ni) {
+      bh[ni] = *reinterpret_cast<const u32x4*>(lb + 16 * ni * TN_LD);
+      bl[ni] = *reinterpret_cast<const u32x4*>(lb + TN_T * TN_LD + 16 * ni * TN_LD);
+    }
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        bh[ni] = *reinterpret_cast<const u32x4*>(lb + 16 * ni * TN_LD);
-        bl[ni] = *reinterpret_cast<const u32x4*>(lb + TN_T * TN_LD + 16 * ni * TN_LD);
-      }
+    for (int mi = 0; mi < 4; ++mi) {
+      const u32x4 ah = *reinterpret_cast<const u32x4*>(la + 16 * mi * TN_LD);
+      const u32x4 al = *reinterpret_cast<const u32x4*>(la + TN_T * TN_LD + 16 * mi * TN_LD);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const u32x4 ah = *reinterpret_cast<const u32x4*>(la + 16 * mi * TN_LD);
-        const u32x4 al = *reinterpret_cast<const u32x4*>(la + TN_T * TN_LD + 16 * mi * TN_LD);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_h3(ah, al, bh[ni], bl[ni], acc[mi][ni]);
-      }
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_h3(ah, al, bh[ni], bl[ni], acc[mi][ni]);
     }
     __syncthreads();                                   // every wave has read this step's fragments
     if (more) commit();
@@ -219,9 +211,9 @@ static int tn_splits(int M, int N, int K, int batch) {
   int cus = 256;
   const int forced = env_int("HOPMI_GEMM_TN_SPLITS", 0);
   if (forced > 0) return forced < steps ? forced : steps;
-  // fill the chip about twice (two workgroups per CU), but keep at least 4 steps (256 rows) per split
+  // fill the chip about twice (two workgroups per CU), but keep at least 8 steps per split
   int s = (2 * cus + tiles - 1) / tiles;
-  if (s > steps / 4) s = steps / 4;
+  if (s > steps / 8) s = steps / 8;
   if (s < 1) s = 1;
   if (s > 32) s = 32;
   return s;
