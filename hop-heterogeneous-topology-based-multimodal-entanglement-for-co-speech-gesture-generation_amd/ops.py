@@ -1456,12 +1456,15 @@ class _BertAttnFn(torch.autograd.Function):
         ctx.p_drop, ctx.seed, ctx.sp = float(p_drop), int(seed), sp
         if img is not None:
             ctx.mark_non_differentiable(img, sc)
+            ctx.set_materialize_grads(False)         # (no 13 MB zero-fill for the image's "gradient" in front of every backward)
         return out, img, sc
 
     @staticmethod
     @_bwd32
     def backward(ctx, dout, *_unused):
         (qkv,) = ctx.saved_tensors
+        if dout is None:
+            return None, None, None, None
         dout = _dev_f32(dout, "dout")
         B, L, _, H, dh = qkv.shape
         dqkv = torch.empty_like(qkv)
