@@ -1014,7 +1014,7 @@ class _LinearFn(torch.autograd.Function):
 F16_LINEAR = __import__("os").environ.get("HOPMI_F16_LINEAR", "1") != "0"
 # From M N K = 5e9 on (tools/bench_linear.py, against the TUNED library kernels: GRU input projections 120 -> 80 us + 9 us of row
 # scales, align layer 96 -> 60, beat MLP 214 -> 134; below, the row-scales pass and the weight images eat the gain)
-F16_LINEAR_MIN_MNK = float(__import__("os").environ.get("HOPMI_F16_LINEAR_MIN_MNK", "5.0e9"))
+F16_LINEAR_MIN_MNK = float(__import__("os").environ.get("HOPMI_F16_LINEAR_MIN_MNK", "3.0e9"))
 _F16_IMG = {}                       # (ids of the owner parameters, N, K, transpose) -> (weak references, versions, image, made under capture)
 _F16_IMG_FROZEN = {}                # the same for owners that take no gradient (never reset by a recording)
 
@@ -1120,11 +1120,11 @@ def f16_affine_splitk(W, E, b):
                                                            ws.data_ptr(), _stream())), "hopmi_gemm_f16x2_ab_splitk")
     return out
 
-# dW = dY^T X on hopmi_gemm_f16x2_tn (csrc/gemm_tn.hip) instead of the library's fp32 GEMM: from M N K = 2e9 on (below, the row-scale
-# passes and the slab sum eat the gain)
+# dW = dY^T X on hopmi_gemm_f16x2_tn (csrc/gemm_tn.hip) instead of the library's fp32 GEMM: from M N K = 1e9 on (below, the row-scale
+# passes and the slab sum eat the gain; A/B at configs[1]: 2e9 14.38, 1e9 14.34, 5e8 14.35 ms per step)
 F16_TN = __import__("os").environ.get("HOPMI_F16_TN", "1") != "0"
 TN_COLSUM = __import__("os").environ.get("HOPMI_TN_COLSUM", "1") != "0"      # bias gradients as a by-product of the TN weight gradient
-F16_TN_MIN_MNK = float(__import__("os").environ.get("HOPMI_F16_TN_MIN_MNK", "2.0e9"))
+F16_TN_MIN_MNK = float(__import__("os").environ.get("HOPMI_F16_TN_MIN_MNK", "1.0e9"))
 _UNIT_RS = {}                       # (device, M) -> [2][M] row-scale pairs {2^14, 2^-14}: operands bounded by 1 (GRU states)
 
 
@@ -1147,7 +1147,8 @@ def f16_mm_tn_ok(a, b) -> bool:
     """Does the weight gradient a^T b (a: (.., M, N), b: (.., M, K), rows strided or not) go to hopmi_gemm_f16x2_tn?"""
     return bool(F16_TN and GEMM_PARTS == F16_PARTS and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
                 and not torch.is_autocast_enabled("cuda") and a.stride(-1) == 1 and b.stride(-1) == 1
-                and float(a.shape[-2]) * a.shape[-1] * b.shape[-1] * (a.shape[0] if a.dim() == 3 else 1) >= F16_TN_MIN_MNK)
+                and float(a.shape[-2]) * a.shape[-1] * b.shape[-1] * (a.shape[0] if a.dim() == 3 else 1)
+                >= F16_TN_MIN_MNK * (1.0 if a.shape[-2] >= IMG_MIN_ROWS else 2.0))       # (short contractions, e.g. M = 2176: from 2e9 on)
 
 
 def f16_mm_tn(a, b, a_rs, b_rs, out=None, accumulate=False, colsum=False):
