@@ -478,6 +478,9 @@ GEMM_AB_MAX_N = int(__import__("os").environ.get("HOPMI_GEMM_AB_MAX_N", "2304"))
 # AND its row scales (which the weight-gradient GEMM needs anyway), the LDS-DMA form multiplies -- also where K is not a multiple of
 # 32 (GRU: K = 700, 2100): A/B HOPMI_F16_LINEAR_IMG=0 (row scales + split form)
 F16_LINEAR_IMG = __import__("os").environ.get("HOPMI_F16_LINEAR_IMG", "1") != "0"
+# (the generator's linears have larger N K per row than the BERT products the 3072-row threshold was measured on: from 2048 rows on,
+# 14.34 -> 14.30 ms at configs[1] -- the beat MLP -- and 12.73 -> 12.70 at configs[3] -- the GRU input projections at M = 2176)
+LINEAR_IMG_MIN_ROWS = int(__import__("os").environ.get("HOPMI_LINEAR_IMG_MIN_ROWS", "2048"))
 
 
 def rows_image(a2d):
@@ -499,7 +502,7 @@ def _linear_operand(t, t2):
     im = _take_img(t, M, K) if K % 32 == 0 else None
     if im is not None:
         return im[1], im
-    if rs is None and F16_LINEAR_IMG and M >= IMG_MIN_ROWS and K % 2 == 0 and K >= 128 and t2.is_contiguous() and t2.data_ptr() % 8 == 0:
+    if rs is None and F16_LINEAR_IMG and M >= LINEAR_IMG_MIN_ROWS and K % 2 == 0 and K >= 128 and t2.is_contiguous() and t2.data_ptr() % 8 == 0:
         im = rows_image(t2)
         return im[1], im
     return (rs if rs is not None else row_scales(t2)), None
