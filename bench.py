@@ -361,7 +361,7 @@ def main():
                        + {"f16x2": "", "split3": "the frozen BERT's linears as SIX split-bf16 terms (--bert-gemm split3); ",
                           "split2": "the frozen BERT's linears as THREE split-bf16 terms, 2^-16-class products (--bert-gemm split2); ",
                           "library": "the frozen BERT's linears on the library's f32 GEMM (--bert-gemm library); "}[args.bert_gemm]
-                       + "the remaining (small) library GEMMs f32") if args.dtype == "fp32" else
+                       + "the remaining library GEMMs (mapping layer forward, small projections) f32") if args.dtype == "fp32" else
                       "bf16 library GEMMs (autocast), bf16 activations between them (dtype argument of the BERT / GRU / attention HIP "
                       "kernels) + bf16 gradient exchange; inside the HIP kernels f32 accumulation and elementwise arithmetic with "
                       "three-term fp16 hi/lo MFMA products (f32-equivalent); f32 WaveNet stack, master weights and optimizer"),
