@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3   # exact-f32 MFMA == vector peak
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
+EXIT_NON_FINITE = 3            # the model left the timed region with a non-finite loss / parameter: no `value` is reported
 
 
 def parse():
@@ -337,6 +338,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # ---- the run only counts if the model it trained is alive: every loss of the last step and every trainable parameter finite
+    # (round 5's headline was timed on a model that had gone to NaN inside the recorded step, and nothing said so) -------------------
+    import math
+    bad_losses = sorted(k for k, v in last.items() if not math.isfinite(v))
+    with torch.no_grad():
+        pmax = torch.stack(torch._foreach_norm([p for p in model.parameters() if p.requires_grad], float("inf")))
+        n_bad_params = int((~torch.isfinite(pmax)).sum().item())
+    alive = not bad_losses and n_bad_params == 0
+    if world > 1:
+        t = torch.tensor([0.0 if alive else 1.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        alive_all = t.item() == 0.0
+    else:
+        alive_all = alive
+    losses_json = {k: (v if math.isfinite(v) else repr(v)) for k, v in last.items()}      # (strict JSON: no bare NaN)
+
+    if rank == 0 and not alive_all:
+        print(json.dumps({"metric": "training clips/sec", "value": None, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "error": "non-finite model state after the timed region"
+                                                          + ("" if alive else f" (rank 0: losses {bad_losses}, {n_bad_params} parameter tensors)")
+                                                          + ": the throughput of a dead model is not a measurement",
+                          "losses": losses_json}), flush=True)
+    if not alive_all:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(EXIT_NON_FINITE)
+
     if rank == 0:
         per_step = sorted(b - a for a, b in zip(stamps, stamps[1:]))
         median_ms = 1e3 * per_step[len(per_step) // 2]
@@ -366,6 +395,7 @@ def main():
                       "kernels) + bf16 gradient exchange; inside the HIP kernels f32 accumulation and elementwise arithmetic with "
                       "three-term fp16 hi/lo MFMA products (f32-equivalent); f32 WaveNet stack, master weights and optimizer"),
             "data": "synthetic",
+            "losses": losses_json,                     # of the LAST timed step (finite, or the run exits with EXIT_NON_FINITE above)
             "config": {"workload": f"BASELINE.json configs[{1 if V == 9 else 3}] per GPU: {args.dataset} {V + 1}-joint ({V} graph nodes), "
                                    f"34-frame clips, batch {B}/GPU, {args.dtype}, one full train_llm step = "
                                    + ("GAN phase (epoch > 10): discriminator step (1 no-grad generator forward, 2 discriminator forwards, "
@@ -421,14 +451,13 @@ def main():
                                       "split3": "hopmi_gemm_split, 3 bf16 parts per operand, 6 MFMA terms: fp32-equivalent (error vs float64 "
                                                 "equal to the library's fp32 GEMM, tools/bench_gemm.py)",
                                       "split2": "hopmi_gemm_split, 2 bf16 parts per operand, 3 MFMA terms (2^-16-class products)"}[args.bert_gemm]),
-                       "library_gemm_selection": "shipped TunableOp table (replay only)" if tuned else "library default",
-                       "losses": last},
+                       "library_gemm_selection": "shipped TunableOp table (replay only)" if tuned else "library default"},
         }
         if ks is not None:
             out["roofline"] = roofline(ks, V, B, args.kernel_steps, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, allow_nan=False), flush=True)
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

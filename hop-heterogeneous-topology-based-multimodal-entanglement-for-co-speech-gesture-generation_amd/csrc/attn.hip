@@ -24,6 +24,7 @@
 // bf16 GEMMs around the operator under autocast (no cast launches; loads widened, stores rounded, arithmetic unchanged).
 // A bf16 operand has no lo part (its 8 significand bits fit fp16's 11), so the terms that would multiply it are not issued
 // (mfma_h<A_LO, B_LO>): the scaled Q, P and dS keep theirs.
+#define HOPMI_FILE_ID 4          // (diagnostic build: common.h, split_check)
 #include "attn_dev.h"
 #include "f16_dev.h"
 #include "io_dev.h"
@@ -859,3 +860,5 @@ extern "C" int hopmi_reprog_attn_bwd(const float* q, const float* k, const float
                                      float scale, float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   return hopmi_reprog_attn_bwd_dt(q, k, v, d_o, HOPMI_F32, lse, delta, dq, dk, dv, ws, N, S, H, E, scale, p_drop, seed, seed_dev, stream);
 }
+
+HOPMI_SPLIT_STATUS_SETTER(attn)

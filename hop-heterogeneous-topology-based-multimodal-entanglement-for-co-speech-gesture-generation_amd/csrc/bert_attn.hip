@@ -12,6 +12,7 @@
 // probabilities, no cross-workgroup reductions (bitwise reproducible).  All contractions on exact-fp32 MFMA
 // (16x16x4, outputs transposed so that every global store is 16 bytes per lane); dropout is the stateless
 // (seed,row,head,key) hash of attn.hip.
+#define HOPMI_FILE_ID 5          // (diagnostic build: common.h, split_check)
 #include "attn_dev.h"
 #include "io_dev.h"
 #include "f16_dev.h"
@@ -416,3 +417,5 @@ extern "C" int hopmi_bert_attn_bwd(const float* qkv, const float* d_out, float* 
                                    unsigned seed, const unsigned* seed_dev, void* stream) {
   return hopmi_bert_attn_bwd_dt(qkv, d_out, dqkv, B, L, H, p_drop, seed, seed_dev, HOPMI_F32, stream);
 }
+
+HOPMI_SPLIT_STATUS_SETTER(bert_attn)

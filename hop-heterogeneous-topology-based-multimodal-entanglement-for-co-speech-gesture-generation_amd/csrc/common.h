@@ -50,6 +50,38 @@ __device__ __forceinline__ void store_row_scale(float* __restrict__ scales, int 
   scales[row] = __uint_as_float(sb);
   scales[M + row] = inv_scale(sb);
 }
+// ---- diagnostic build only (-DHOPMI_CHECK_SPLIT: `make dbg` -> libhopmi_dbg.so, loaded through HOPMI_LIB): every conversion of a
+// scaled fp32 value to its fp16 hi part reports into a device status buffer when the hi part is infinity / NaN --
+//   words [0..3]: the INPUT was finite, i.e. the operand's scale let a value past fp16's range (the scale scheme of that site is
+//                 wrong for this data): [0] = (file id << 16 | source line) of the first such conversion in stream order,
+//                 [1] = how many, [2] = bits of the first offending (scaled) fp32 value;
+//   words [4..7]: the input was already infinity / NaN (where a non-finite value first ENTERED a split), same layout.
+// File ids: 1 gemm.hip, 2 gemm_tn.hip, 3 elementwise.hip, 4 attn.hip, 5 bert_attn.hip, 6 gru.hip, 7 wavenet.hip,
+// 8 wavenet_stack.hip.  The buffer is registered per translation unit (hopmi_debug_set_split_status_<file>); ops.split_status()
+// reads it.  The production build compiles the check away (and carries no such symbol).
+#ifdef HOPMI_CHECK_SPLIT
+#ifndef HOPMI_FILE_ID
+#define HOPMI_FILE_ID 0                      // (a translation unit without fp16 splits)
+#endif
+static __device__ unsigned* g_split_status = nullptr;
+__device__ __forceinline__ void split_check(float x, _Float16 hi, int line) {
+  const unsigned short hb = __builtin_bit_cast(unsigned short, hi);
+  if ((hb & 0x7c00u) != 0x7c00u) return;
+  unsigned* w = g_split_status;
+  if (w == nullptr) return;
+  w += (fabsf(x) <= 3.4028235e38f) ? 0 : 4;
+  if (atomicCAS(&w[0], 0u, ((unsigned)HOPMI_FILE_ID << 16) | (unsigned)line) == 0u) w[2] = __float_as_uint(x);
+  atomicAdd(&w[1], 1u);
+}
+#define HOPMI_SPLIT_STATUS_SETTER(name)                                                                             \
+  extern "C" int hopmi_debug_set_split_status_##name(unsigned* p) {                                                 \
+    return hipMemcpyToSymbol(HIP_SYMBOL(hopmi::g_split_status), &p, sizeof(p)) == hipSuccess ? 0 : -1;               \
+  }
+#else
+__device__ __forceinline__ void split_check(float, _Float16, int) {}
+#define HOPMI_SPLIT_STATUS_SETTER(name)
+#endif
+
 __device__ __forceinline__ unsigned wave_max_u32(unsigned m) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));

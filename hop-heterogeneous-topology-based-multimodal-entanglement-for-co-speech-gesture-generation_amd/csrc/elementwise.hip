@@ -9,6 +9,7 @@
 // LayerNorm rows (D <= 1024, D % 4 == 0; 768 for BERT-base) are one wave each: the row lives in registers,
 // mean/variance by DPP + cross-row shuffles, so x is read once and out written once.  Dropout uses the same
 // stateless hash as the attention kernel (seed, row, column) so the backward regenerates the mask.
+#define HOPMI_FILE_ID 3          // (diagnostic build: common.h, split_check)
 #include "f16_dev.h"
 #include "io_dev.h"
 
@@ -58,6 +59,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int LN_MAX4 = 4;            // float4 per lane: D <= 64 * 4 * 4 = 1024
 
+// 2-norm of the row a wave holds in registers, rounded UP (it feeds the a-priori bound of the image-emitting GEMM epilogue behind
+// this operator, gemm.hip: |out| <= ||row|| ||w|| + |b|), given the row's largest magnitude `amax` (bits, reduced over the wave).
+// The squares are taken of the row times the power of two that puts `amax` near 2^14: a plain sum of squares underflows to ZERO for
+// a row whose elements are below ~1e-19 -- gradient rows behind a saturated GRU are 1e-30 and smaller -- and a zero bound tells the
+// epilogue "nothing to protect": it scaled such a row's (tiny, non-zero) products by 2^123, past fp16's range, and wrote infinity
+// hi parts / NaN lo parts into the operand image (round 5's NaN in the bench regime: found with the diagnostic build's status word,
+// row_norm = 0.0 against a product of 9.6e-33).  Scaled, the sum is exact in range: (2^15)^2 x 1024 elements = 2^40.
+__device__ __forceinline__ float ln_row_norm(const float4 (&v)[LN_MAX4], int D4, int lane, unsigned amax) {
+  const unsigned sb = scale_bits_for_max(amax);
+  const float sc = __uint_as_float(sb);
+  float nrm = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX4; ++k) {
+    if (lane + 64 * k < D4) {
+      const float a = v[k].x * sc, b = v[k].y * sc, c = v[k].z * sc, d = v[k].w * sc;
+      nrm += a * a + b * b + c * c + d * d;
+    }
+  }
+  return sqrtf(wave_sum(nrm)) * 1.0000005f * inv_scale(sb);
+}
+
 // The row a wave holds in registers, times its power-of-two scale, as the fp16 hi / lo images [2][M][D] that hopmi_gemm_f16x2_ab
 // reads by LDS-DMA (hopmi_rows_image_f16's layout): the GEMM behind this operator then needs neither the split in its k-loop nor a
 // pass of its own over the activations (round 5).
@@ -98,8 +120,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
-  unsigned amax = 0;                            // max |out| of the row (row_scales: the next GEMM's fp16-form operand scale)
-  float nrm = 0.f;                              // sum out^2 (row_norms: the a-priori bound of the next GEMM's image-emitting epilogue)
+  unsigned amax = 0;                            // max |out| of the row (row_scales: the next GEMM's fp16-form operand scale; row_norms)
   float4 z[LN_MAX4];
   float s = 0.f;
 #pragma unroll
@@ -143,19 +164,18 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_fwd_kernel(const T* __re
       if (out_t != nullptr) st4(out_t + ((size_t)row * D4 + c4) * 4, o);
       if (xhat != nullptr) reinterpret_cast<float4*>(xhat)[(size_t)row * D4 + c4] = h;
       amax = abs_bits_max4(amax, o);
-      nrm += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
-      z[k] = o;                                 // (kept for the image below)
+      z[k] = o;                                 // (kept for the image and the norm below)
     }
   }
   if (rstd_out != nullptr && lane == 0) rstd_out[row] = rstd;
+  if (row_scales != nullptr || row_norms != nullptr) amax = wave_max_u32(amax);
   if (row_scales != nullptr) {
-    amax = wave_max_u32(amax);
     if (lane == 0) store_row_scale(row_scales, M, row, amax);
     if (image != nullptr) ln_store_image(image, z, M, D4, row, lane, __uint_as_float(scale_bits_for_max(amax)));
   }
   if (row_norms != nullptr) {
-    nrm = wave_sum(nrm);
-    if (lane == 0) row_norms[row] = sqrtf(nrm) * 1.0000005f;        // (rounded up: it feeds a bound)
+    const float nrm = ln_row_norm(z, D4, lane, amax);
+    if (lane == 0) row_norms[row] = nrm;
   }
 }
 
@@ -173,8 +193,7 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int D4 = D >> 2;
-  float nrm = 0.f;                              // sum dx^2 (row_norms)
-  unsigned amax = 0;                            // max |dx| of the row (row_scales: the next GEMM's fp16-form operand scale)
+  unsigned amax = 0;                            // max |dx| of the row (row_scales: the next GEMM's fp16-form operand scale; row_norms)
   float4 dh[LN_MAX4], xh[LN_MAX4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -212,18 +231,17 @@ __global__ __launch_bounds__(256) void bias_drop_res_ln_bwd_kernel(const float* 
       }
       st4(dx + ((size_t)row * D4 + c4) * 4, dz);
       amax = abs_bits_max4(amax, dz);
-      nrm += dz.x * dz.x + dz.y * dz.y + dz.z * dz.z + dz.w * dz.w;
-      dh[k] = dz;                               // (kept for the image below)
+      dh[k] = dz;                               // (kept for the image and the norm below)
     }
   }
+  if (row_scales != nullptr || row_norms != nullptr) amax = wave_max_u32(amax);
   if (row_scales != nullptr) {
-    amax = wave_max_u32(amax);
     if (lane == 0) store_row_scale(row_scales, M, row, amax);
     if (image != nullptr) ln_store_image(image, dh, M, D4, row, lane, __uint_as_float(scale_bits_for_max(amax)));
   }
   if (row_norms != nullptr) {
-    nrm = wave_sum(nrm);
-    if (lane == 0) row_norms[row] = sqrtf(nrm) * 1.0000005f;
+    const float nrm = ln_row_norm(dh, D4, lane, amax);
+    if (lane == 0) row_norms[row] = nrm;
   }
 }
 
@@ -607,3 +625,5 @@ extern "C" int hopmi_bn_cl_bwd(const float* x, const float* dy, const float* gam
                      dbeta, M, C);
   return check_launch("hopmi_bn_cl_bwd");
 }
+
+HOPMI_SPLIT_STATUS_SETTER(elementwise)

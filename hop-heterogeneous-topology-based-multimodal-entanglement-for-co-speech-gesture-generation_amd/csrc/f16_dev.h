@@ -50,25 +50,28 @@ __device__ __forceinline__ f32x4 mfma_h(u32x4 a_hi, u32x4 a_lo, u32x4 b_hi, u32x
 }
 
 // two (already scaled) floats -> {packed fp16 hi pair, packed fp16 lo pair}; element 0 in the low half (memory order)
-__device__ __forceinline__ u32x2 split2h(float a, float b) {
+// (`line`: the caller's source line, for the diagnostic build's status word -- common.h, split_check)
+__device__ __forceinline__ u32x2 split2h(float a, float b, int line = __builtin_LINE()) {
   // (the values as fp32 registers: whatever produced them is rounded to fp32 first -- see RULE above; costs no instruction)
   asm("" : "+v"(a), "+v"(b));
   const f16x2 hi = {(_Float16)a, (_Float16)b};
+  split_check(a, hi[0], line);
+  split_check(b, hi[1], line);
   const f16x2 lo = {(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1])};
   return u32x2{__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo)};
 }
 
-__device__ __forceinline__ Split4 split4h(float a, float b, float c, float d) {
-  const u32x2 p = split2h(a, b), r = split2h(c, d);
+__device__ __forceinline__ Split4 split4h(float a, float b, float c, float d, int line = __builtin_LINE()) {
+  const u32x2 p = split2h(a, b, line), r = split2h(c, d, line);
   return Split4{u32x2{p[0], r[0]}, u32x2{p[1], r[1]}};
 }
 
-__device__ __forceinline__ Split8 split8h(float4 a, float4 b) {
-  const u32x2 p0 = split2h(a.x, a.y), p1 = split2h(a.z, a.w), p2 = split2h(b.x, b.y), p3 = split2h(b.z, b.w);
+__device__ __forceinline__ Split8 split8h(float4 a, float4 b, int line = __builtin_LINE()) {
+  const u32x2 p0 = split2h(a.x, a.y, line), p1 = split2h(a.z, a.w, line), p2 = split2h(b.x, b.y, line), p3 = split2h(b.z, b.w, line);
   return Split8{u32x4{p0[0], p1[0], p2[0], p3[0]}, u32x4{p0[1], p1[1], p2[1], p3[1]}};
 }
-__device__ __forceinline__ Split8 split8h(float4 a, float4 b, float s) {
-  return split8h(make_float4(a.x * s, a.y * s, a.z * s, a.w * s), make_float4(b.x * s, b.y * s, b.z * s, b.w * s));
+__device__ __forceinline__ Split8 split8h(float4 a, float4 b, float s, int line = __builtin_LINE()) {
+  return split8h(make_float4(a.x * s, a.y * s, a.z * s, a.w * s), make_float4(b.x * s, b.y * s, b.z * s, b.w * s), line);
 }
 
 // packed fp16 pair -> the two floats

@@ -18,6 +18,7 @@
 // commit phases and halve the tile-count quantisation) for the larger grids.  LDS rows are 96 bytes (64 data + 32 pad): the 16 lanes
 // of every ds_read_b128 service group then hit 16 distinct 16-byte bank slots.  Tiles are enumerated XCD-aware: the tiles
 // of one XCD walk one panel of A against consecutive panels of B, so both stay in that XCD's L2.
+#define HOPMI_FILE_ID 1          // (diagnostic build: common.h, split_check)
 #include "bf16_dev.h"
 
 #include <cstdint>
@@ -73,9 +74,11 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // two (already scaled) floats -> packed fp16 hi pair, packed fp16 lo pair (round to nearest even; x - hi is exact in fp32)
-__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned (&out)[2]) {
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned (&out)[2], int line = __builtin_LINE()) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   const h2 hi = {(_Float16)a, (_Float16)b};
+  split_check(a, hi[0], line);
+  split_check(b, hi[1], line);
   const h2 lo = {(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1])};
   out[0] = __builtin_bit_cast(unsigned, hi);
   out[1] = __builtin_bit_cast(unsigned, lo);
@@ -708,9 +711,21 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
             const unsigned sbits = scale_bits_for_max(__float_as_uint(io.row_norm[row] * io.mul + io.add) & 0x7fffffffu);
             const float xs = out * __uint_as_float(sbits);
             const _Float16 hi = (_Float16)xs;
-            const size_t ia = f16_blk(row, col, f16_np(N) >> 5);
+            split_check(xs, hi, __LINE__);
+#ifdef HOPMI_CHECK_SPLIT
+            // (diagnostic build: the first violation of the a-priori bound leaves its coordinates in words [8..15])
+            if ((__builtin_bit_cast(unsigned short, hi) & 0x7c00u) == 0x7c00u && fabsf(xs) <= 3.4028235e38f && g_split_status != nullptr &&
+                atomicCAS(&g_split_status[8], 0u, 1u) == 0u) {
+              unsigned* w = g_split_status;
+              w[9] = (unsigned)row; w[10] = (unsigned)col; w[11] = __float_as_uint(io.row_norm[row]); w[12] = __float_as_uint(io.mul);
+              w[13] = __float_as_uint(io.add); w[14] = __float_as_uint(out); w[15] = (unsigned)ep;
+            }
+#endif
+            // (the image this writes is a ROWS image of an [M][N] operand: hopmi_rows_image_f16_bytes, f16_kp(N) = N columns -- the
+            // layout its consumer, this kernel's A-operand staging, reads; not the weight images' 128-padded width)
+            const size_t ia = f16_blk(row, col, f16_kp(N) >> 5);
             io.image[ia] = hi;
-            io.image[(size_t)((M + 127) / 128) * 128 * f16_np(N) + ia] = (_Float16)(xs - (float)hi);
+            io.image[(size_t)((M + 127) / 128) * 128 * f16_kp(N) + ia] = (_Float16)(xs - (float)hi);
             if (tn == 0 && ni == 0 && n == 0) { io.scales[row] = __uint_as_float(sbits); io.scales[M + row] = inv_scale(sbits); }
           }
         }
@@ -1024,3 +1039,5 @@ extern "C" int hopmi_gemm_split_ep(const float* A, const void* Bimage, const flo
   return parts == 2 ? launch_gemm_split<2>(A, Bimage, bias, C, M, N, K, st, epilogue, C2, aux)
                     : launch_gemm_split<3>(A, Bimage, bias, C, M, N, K, st, epilogue, C2, aux);
 }
+
+HOPMI_SPLIT_STATUS_SETTER(gemm)

@@ -17,6 +17,7 @@
 // kernels of that phase is the suspect); the m range is SPLIT over workgroups when the output has too few
 // tiles for the chip (a GRU's 1050 x 350 recurrent gradient: 27 tiles): split s writes slab s of a workspace, a second launch adds
 // the slabs in index order -- bitwise reproducible, no atomics.
+#define HOPMI_FILE_ID 2          // (diagnostic build: common.h, split_check)
 #include "f16_dev.h"
 
 namespace hopmi {
@@ -279,3 +280,5 @@ extern "C" int hopmi_gemm_f16x2_tn_cs(const float* A, int lda, long long batch_s
   }
   return HOPMI_OK;
 }
+
+HOPMI_SPLIT_STATUS_SETTER(gemm_tn)

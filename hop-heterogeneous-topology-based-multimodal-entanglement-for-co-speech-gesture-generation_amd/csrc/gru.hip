@@ -24,6 +24,7 @@
 #include <utility>
 #include <vector>
 
+#define HOPMI_FILE_ID 6          // (diagnostic build: common.h, split_check)
 #include "attn_dev.h"
 #include "f16_dev.h"
 
@@ -1257,3 +1258,5 @@ extern "C" int hopmi_gru_bwd(const float* dy, const float* y, const float* gates
                              float* dgi, float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream) {
   return gru_bwd_impl(dy, y, gates, whhT, dgi, dgh, ws, ws2, B, T, H, stream);
 }
+
+HOPMI_SPLIT_STATUS_SETTER(gru)

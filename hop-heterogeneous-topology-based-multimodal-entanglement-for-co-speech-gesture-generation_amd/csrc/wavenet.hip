@@ -25,6 +25,7 @@
 // scale+shift in a fixed order (reproducible).  Nothing is saved for the backward: it recomputes the gates from xin.
 #include <hip/hip_ext.h>
 
+#define HOPMI_FILE_ID 7          // (diagnostic build: common.h, split_check)
 #include "attn_dev.h"
 #include "f16_dev.h"
 #include "io_dev.h"
@@ -754,3 +755,5 @@ extern "C" int hopmi_wn_bn_replay(const float* mean_rstd, float* running_mean, f
                      running_var, momentum);
   return check_launch("hopmi_wn_bn_replay");
 }
+
+HOPMI_SPLIT_STATUS_SETTER(wavenet)

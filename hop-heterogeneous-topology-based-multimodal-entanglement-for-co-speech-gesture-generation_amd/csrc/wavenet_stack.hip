@@ -33,6 +33,7 @@
 #include <utility>
 #include <vector>
 
+#define HOPMI_FILE_ID 8          // (diagnostic build: common.h, split_check)
 #include "attn_dev.h"
 #include "f16_dev.h"
 #include "io_dev.h"
@@ -968,3 +969,5 @@ extern "C" int hopmi_wn_stack_fwd(const float* x0, const void* wimg, const float
                                reinterpret_cast<void* const*>(y), utail, utail_ld, scsh_out, mean_rstd_out, ws, B, T_in, V, dilations,
                                n_layers, HOPMI_F32, stream);
 }
+
+HOPMI_SPLIT_STATUS_SETTER(wavenet_stack)

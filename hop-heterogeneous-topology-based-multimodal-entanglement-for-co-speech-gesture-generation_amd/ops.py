@@ -99,6 +99,50 @@ def time_noop_launch():
     _lib.check(_timed("noop", 0, 0, lambda: L.hopmi_noop_launch(st), exact=True), "hopmi_noop_launch")
 
 
+# ------------------------------------------------------- diagnostic build: the fp16-split status word (csrc/common.h, split_check)
+_SPLIT_FILES = {1: "gemm.hip", 2: "gemm_tn.hip", 3: "elementwise.hip", 4: "attn.hip", 5: "bert_attn.hip", 6: "gru.hip", 7: "wavenet.hip",
+                8: "wavenet_stack.hip"}
+_SPLIT_STATUS = None
+
+
+def split_status(reset=False):
+    """Diagnostic library only (`make dbg`, HOPMI_LIB=.../libhopmi_dbg.so): what the fp16 hi/lo splits of every kernel reported since
+    the last reset -- {"overflow": (site, count, value) or None, "nonfinite_in": (site, count, value) or None}, `site` = "file:line" of
+    the FIRST conversion in stream order whose hi part was infinity / NaN ("overflow": on a finite input, i.e. an operand scale that
+    does not hold for the data; "nonfinite_in": the input already was).  The first call registers the buffer with every translation
+    unit.  Returns None with the production library (which compiles the check away).  Synchronises the device."""
+    global _SPLIT_STATUS
+    import ctypes
+    import struct
+    L = _lib.lib()
+    if not hasattr(L, "hopmi_debug_set_split_status_gemm"):
+        return None
+    if _SPLIT_STATUS is None:
+        buf = torch.zeros(16, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for name in ("gemm", "gemm_tn", "elementwise", "attn", "bert_attn", "gru", "wavenet", "wavenet_stack"):
+            fn = getattr(L, "hopmi_debug_set_split_status_" + name)
+            fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+            if fn(buf.data_ptr()) != 0:
+                raise _lib.HopmiError(f"hopmi: hopmi_debug_set_split_status_{name} failed")
+        _SPLIT_STATUS = buf
+    torch.cuda.synchronize()
+    w = [x & 0xFFFFFFFF for x in _SPLIT_STATUS.tolist()]
+
+    def dec(o):
+        if w[o + 1] == 0:
+            return None
+        return (f"{_SPLIT_FILES.get(w[o] >> 16, w[o] >> 16)}:{w[o] & 0xFFFF}", w[o + 1], struct.unpack("f", struct.pack("I", w[o + 2]))[0])
+
+    out = {"overflow": dec(0), "nonfinite_in": dec(4)}
+    if w[8]:      # the image-emitting GEMM epilogue's first bound violation: where, and what the bound was made of
+        f = lambda u: struct.unpack("f", struct.pack("I", u))[0]
+        out["ab_img"] = dict(row=w[9], col=w[10], row_norm=f(w[11]), mul=f(w[12]), add=f(w[13]), out=f(w[14]), epilogue=w[15])
+    if reset:
+        _SPLIT_STATUS.zero_()
+    return out
+
+
 def gcn_algorithmic_bytes(n_slabs: int, V: int) -> int:
     """read x' + write h = 2*64*V*4 B per slab, plus the per-launch constants
     (A: V*V*4 B twice, Wm+bm: 49 408 B)."""
