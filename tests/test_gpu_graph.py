@@ -554,6 +554,48 @@ def test_graphed_step_baseline_size_vs_reference(V, B, epoch, monkeypatch):
             assert float(g_opt.state[p]["step"]) == n_steps
 
 
+def _bench_regime(extra_args=(), env=None, timeout=400):
+    """tools/nan_hunt.py as a child process: bench.py's exact set-up with a finiteness census after every step -> its RESULT dict."""
+    import json
+    from conftest import ROOT, run_isolated
+    r = run_isolated([os.path.join(ROOT, "tools", "nan_hunt.py")] + list(extra_args), timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, f"rc {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    return json.loads(lines[-1][len("RESULT "):]), r.stdout
+
+
+def test_graphed_step_bench_regime_stays_finite():
+    """The regime bench.py times and no other test ran: default initialisation under seed 0, the reference's
+    learning rate 1e-2 (run_ted.py:103), dropout ON (HOP.py:256,296; the BERT in train mode), fused Adam, the shipped GEMM table,
+    7 eager steps (6 of them instrumented, as bench.py's kernel region), the recorder's eager call and then 35 replays of the recorded step at configs[1] size.
+    After EVERY step: all losses, all trainable parameters, all gradients and all buffers finite.  The trajectory is chaotic at
+    this learning rate (variants of the arithmetic end anywhere between 20 and 200 after 40 steps), so the comparison with the
+    twin run on the library's fp32 GEMMs (--bert-gemm library) is a band, not an equality: the mean of the last 10 losses within
+    a factor 10 of the twin's.  Red on the round-5 tree (NaN at the 2nd recorded step), green with the underflow-safe row norms."""
+    got, log = _bench_regime(["--steps", "36", "--tag", "regime"])
+    assert got["first_bad"] is None, log[-3000:]
+    assert got["replays"] == 35 and got["steps_run"] == 43, got          # (1 + 6 eager, 1 eager call of the recorder, recording + 35 replays)
+    twin, tlog = _bench_regime(["--steps", "36", "--tag", "twin", "--bert-gemm", "library"])
+    assert twin["first_bad"] is None, tlog[-3000:]
+    a, b = sum(got["losses"][-10:]) / 10, sum(twin["losses"][-10:]) / 10
+    assert b / 10 <= a <= b * 10, (a, b)
+
+
+def test_bench_regime_under_the_diagnostic_library_reports_no_split_overflow():
+    """The same run against libhopmi_dbg.so (`make dbg`: -DHOPMI_CHECK_SPLIT, csrc/common.h): every conversion of a scaled value to
+    its fp16 hi part, in every kernel, reports into a status buffer when it produces infinity / NaN.  No site may report in the
+    bench regime -- neither an overflow on a finite input (an operand scale that does not hold for the data: what round 5's
+    a-priori FFN bound did) nor a non-finite value entering a split.  The diagnostic build computes the same bits (asserted:
+    identical losses to the production library's run is checked by the hunt's logs, here only that it ran the diagnostic code)."""
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "hop-heterogeneous-topology-based-multimodal-entanglement-for-co-speech-gesture-generation_amd", "libhopmi_dbg.so")
+    assert os.path.exists(lib), f"{lib} is missing: `make -C .../csrc all` builds it next to libhopmi.so"
+    got, log = _bench_regime(["--steps", "36", "--tag", "regime_dbg"], env={"HOPMI_LIB": lib})
+    assert got["diagnostic_library"], "the child did not load the diagnostic library"
+    assert got["first_bad"] is None, log[-3000:]
+    assert got["split_reports"] == [], got["split_reports"]
+
+
 @pytest.mark.parametrize("eager_calls", [1, 0])
 def test_graphed_step_epoch_10_to_11_transition(eager_calls, monkeypatch):
     """A training run crosses from epoch 10 to epoch 11 with the generator's recording already in use, and epoch 11 is the

@@ -1937,6 +1937,66 @@ def test_layernorm_operand_images_feed_the_lds_dma_gemm(monkeypatch):
     assert rel_err(res_d["image"][2], res_d["split"][2]) <= 2e-6
 
 
+def test_ffn_image_path_on_vanishing_gradient_rows(monkeypatch):
+    """Round 5's NaN (headline): the row 2-norms that bound the image-emitting FFN epilogue were sqrt(sum x^2); for a
+    gradient row below ~1e-19 (behind a saturated GRU they are 1e-30) the squares underflow to ZERO, the zero bound scaled the tiny
+    non-zero products by 2^123 and the operand image received infinity / NaN.  Here: dO rows spanning 1 ... 1e-36 (and an exact
+    zero row) through LayerNorm backward -> FFN backward on the image path.  The norms must bound the true row norms from above
+    (never 0 for a non-zero row) within 1e-5, every gradient must be finite, and the result must match the split form's (no a-priori
+    bound) row by row at the fp32 class."""
+    from hopmi import ops
+    dev = _dev()
+    monkeypatch.setattr(ops, "GEMM_PARTS", 16)
+    monkeypatch.setattr(ops, "IMG_MIN_ROWS", 1024)
+    monkeypatch.setattr(ops, "IMG_FUSED", True)
+    g = torch.Generator().manual_seed(31)
+    M, D, N1 = 1152, 768, 3072
+    x = torch.randn(M, D, generator=g).to(dev)
+    res = torch.randn(M, D, generator=g).to(dev)
+    bias, gamma, beta = (torch.randn(D, generator=g).to(dev) for _ in range(3))
+    w1 = (torch.randn(N1, D, generator=g) / D ** 0.5).to(dev)
+    w2 = (torch.randn(D, N1, generator=g) / N1 ** 0.5).to(dev)
+    b1 = torch.randn(N1, generator=g).to(dev)
+    i1, i1t = ops.split_weight_image(w1, 16), ops.split_weight_image(w1.t().contiguous(), 16)
+    i2, i2t = ops.split_weight_image(w2, 16), ops.split_weight_image(w2.t().contiguous(), 16)
+    bounds = (float(w1.norm(dim=1).max()) * 1.000001, float(b1.abs().max()), float(w2.norm(dim=0).max()) * 1.000001)
+    # row magnitudes: 36 decades, one exactly-zero row, one row of a single tiny element
+    mag = torch.logspace(0, -36, M, dtype=torch.float64)
+    go = (torch.randn(M, D, generator=g).double() * mag.unsqueeze(1)).float()
+    go[7] = 0.0
+    go[11] = 0.0
+    go[11, 5] = 1e-33
+    go = go.to(dev)
+    out = {}
+    for tag, bnd in (("image", bounds), ("split", None)):
+        xx = x.detach().clone().requires_grad_()
+        hh, _ = ops.bias_dropout_residual_layernorm2(xx, bias, res, gamma, beta, 1e-12, 0.0, 5)
+        seen = []
+        f = ops.split_ffn(hh, i1, i1t, b1, i2, i2t, N1, D, 16, bounds=bnd)
+        f.register_hook(lambda gr: seen.append(gr))
+        f2, _ = ops.bias_dropout_residual_layernorm2(f, bias, hh, gamma, beta, 1e-12, 0.0, 6)
+        (f2 * go).sum().backward()
+        out[tag] = (xx.grad.clone(), seen[0])
+    dO = out["image"][1]
+    nr = ops._take_norms(dO, M)
+    assert nr is not None, "the LayerNorm backward did not leave its row norms"
+    true = dO.double().norm(dim=1)
+    nz = true > 0
+    big = true > 1e-37                                  # (a subnormal norm is rounded to a multiple of 1.4e-45, either way)
+    assert bool((nr.double()[big] >= true[big]).all()), "a row norm below the true norm: the bound of the image epilogue does not hold"
+    assert bool((nr[nz] > 0).all()), "a zero norm for a non-zero row"
+    assert bool((nr.double()[nz] <= true[nz] * (1 + 1e-5) + 1e-45).all())
+    assert bool((nr[~nz] == 0).all())
+    assert float(true[nz].min()) < 1e-30, "the test lost its vanishing rows"
+    gi, gs = out["image"][0], out["split"][0]
+    assert bool(torch.isfinite(gi).all()), "non-finite gradient through the FFN image path"
+    # row by row against the split form (which takes its scales from the data): the rows differ by 36 decades
+    num = (gi.double() - gs.double()).norm(dim=1)
+    den = gs.double().norm(dim=1)
+    ok = den > 1e-40                                   # (below that the fp32 results themselves are subnormal)
+    assert float((num[ok] / den[ok]).max()) <= 4e-6, float((num[ok] / den[ok]).max())
+
+
 def test_bert_attention_writes_the_next_gemms_operand_image(monkeypatch):
     """hopmi_bert_attn_fwd_im: the attention kernel also writes its output's fp16 hi / lo operand image, scaled per clip from the
     bound |dropout(P) V| <= max |V[clip]| / (1 - p) (max |V| from the QKV product's partial row maxima) -- the fp32 output is

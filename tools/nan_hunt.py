@@ -54,7 +54,8 @@ def main():
     inputs = (batch["in_audio"], batch["log_melspec"], batch["text"], batch["target_dir_vec"], batch["vid_indices"])
     graphed = hopmi.GraphedTrainStep(sargs, model, disc, g_opt, d_opt, eager_calls=1, enabled=not args.eager)
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-    ops.split_status(reset=True)                   # diagnostic library (HOPMI_LIB=.../libhopmi_dbg.so): registers the status buffer
+    diag = ops.split_status(reset=True) is not None   # diagnostic library (HOPMI_LIB=.../libhopmi_dbg.so): registers the status buffer
+    split_reports = []
 
     def census(step, losses):
         """-> (bad: bool, text)"""
@@ -75,6 +76,8 @@ def main():
         st = ops.split_status(reset=True)          # (None with the production library)
         if st is not None:
             line += f" splits {st}"
+            if any(v is not None for v in st.values()):
+                split_reports.append((step, st))
         bad = bool(bad_l or bad_p or bad_g or bad_b)
         if bad:
             line += f"\n   NON-FINITE: losses {bad_l}; {len(bad_p)} params; {len(bad_g)} of {len(gs)} grads; buffers {bad_b}"
@@ -120,6 +123,9 @@ def main():
         if stop:
             break
         stop = run(lambda: graphed(args.epoch, *inputs), "eager" if args.eager else f"graph(r{graphed.n_replay})")
+    import json
+    print("RESULT " + json.dumps({"tag": args.tag, "first_bad": first_bad, "steps_run": step_no, "replays": graphed.n_replay,
+                                  "losses": hist, "split_reports": split_reports, "diagnostic_library": diag}), flush=True)
     print(f"HUNT {args.tag} first_bad={first_bad} steps_run={step_no} replays={graphed.n_replay} last_loss={hist[-1] if hist else None} "
           f"env={ {k: v for k, v in os.environ.items() if k.startswith('HOPMI_')} }", flush=True)
 
