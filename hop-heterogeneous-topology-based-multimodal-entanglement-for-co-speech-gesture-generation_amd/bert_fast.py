@@ -54,16 +54,25 @@ class FrozenBertEncoder:
         self._img = {}
         self._bounds = {}                        # layer -> (weight versions, norm bounds of the FFN weights)
         self._w16 = {}
+        # (the caches below carry ops.CACHE_EPOCH in their keys: ops.reset_all_caches("all") / invalidate_weight_images() retires them)
 
     def _fused_qkv(self, i, att):
-        ver = (att.query.weight._version, att.key.weight._version, att.value.weight._version, att.query.weight.data_ptr())
+        ver = (att.query.weight._version, att.key.weight._version, att.value.weight._version, att.query.weight.data_ptr(),
+               att.query.bias._version, att.key.bias._version, att.value.bias._version, ops.CACHE_EPOCH)
         hit = self._qkv.get(i)
-        if hit is None or hit[0] != ver:
+
+        def build():
             with torch.no_grad():
-                w = torch.cat([att.query.weight, att.key.weight, att.value.weight], 0).contiguous()
-                b = torch.cat([att.query.bias, att.key.bias, att.value.bias], 0).contiguous()
-            hit = (ver, w, b)
+                return (torch.cat([att.query.weight, att.key.weight, att.value.weight], 0).contiguous(),
+                        torch.cat([att.query.bias, att.key.bias, att.value.bias], 0).contiguous())
+
+        if hit is None or hit[0] != ver:
+            hit = (ver,) + build()
             self._qkv[i] = hit
+        elif ops._checking():
+            w, b = build()
+            ops._check_equal("FrozenBertEncoder fused QKV weight", hit[1], w)
+            ops._check_equal("FrozenBertEncoder fused QKV bias", hit[2], b)
         return hit[1], hit[2]
 
     def _linear(self, key, x, weight, bias, rowmax=None):
@@ -86,12 +95,16 @@ class FrozenBertEncoder:
         if (parts == 0 or torch.is_autocast_enabled() or x.numel() // x.shape[-1] < SPLIT_MIN_ROWS
                 or not ops.split_gemm_supported(N, K) or not ops.split_gemm_supported(K, N)):
             return None
-        ver = (weight._version, weight.data_ptr(), parts)
+        ver = (weight._version, weight.data_ptr(), parts, ops.CACHE_EPOCH)
         hit = self._img.get(key)
         if hit is None or hit[0] != ver:
             with torch.no_grad():
                 hit = (ver, ops.split_weight_image(weight, parts), ops.split_weight_image(weight.t().contiguous(), parts))
             self._img[key] = hit
+        elif ops._checking():
+            with torch.no_grad():
+                ops._check_equal(f"FrozenBertEncoder weight image {key}", hit[1], ops.split_weight_image(weight, parts))
+                ops._check_equal(f"FrozenBertEncoder transposed weight image {key}", hit[2], ops.split_weight_image(weight.t().contiguous(), parts))
         return hit[1], hit[2]
 
     def _ffn_bounds(self, i, lay):
@@ -99,15 +112,25 @@ class FrozenBertEncoder:
         host read per weight version, in the first -- eager -- call): what the image-emitting GEMM epilogues bound their outputs
         with (ops._SplitFfnFn)."""
         w1, b1, w2 = lay.intermediate.dense.weight, lay.intermediate.dense.bias, lay.output.dense.weight
-        ver = (w1._version, w1.data_ptr(), b1._version, w2._version, w2.data_ptr())
+        ver = (w1._version, w1.data_ptr(), b1._version, w2._version, w2.data_ptr(), ops.CACHE_EPOCH)
         hit = self._bounds.get(i)
-        if hit is None or hit[0] != ver:
-            if w1.is_cuda and torch.cuda.is_current_stream_capturing():
-                return None if hit is None else hit[1]       # (never read back under capture; the eager calls came first)
+
+        def measure():
             with torch.no_grad():
                 t = torch.stack([w1.float().norm(dim=1).max(), b1.float().abs().max(), w2.float().norm(dim=0).max()]).tolist()
-            hit = (ver, (t[0] * 1.000001, t[1], t[2] * 1.000001))
+            return (t[0] * 1.000001, t[1], t[2] * 1.000001)
+
+        if hit is None or hit[0] != ver:
+            if w1.is_cuda and torch.cuda.is_current_stream_capturing():
+                # never read back under capture.  A bound of ANOTHER weight version is not a bound: without a current one the FFN
+                # takes the split form (row scales from the data) for this recording
+                return None
+            hit = (ver, measure())
             self._bounds[i] = hit
+        elif ops._checking():
+            ops._check_count()
+            if measure() != hit[1]:
+                ops._check_fail(f"FrozenBertEncoder FFN norm bounds of layer {i}", f"cached {hit[1]} against {measure()}")
         return hit[1]
 
     def _ffn(self, i, lay, h):
@@ -123,7 +146,7 @@ class FrozenBertEncoder:
     def _bf16(self, key, weight, bias=None):
         """bf16 copies of a frozen weight (and bias), made once per weight version: under autocast the library would
         otherwise re-cast every weight in every step."""
-        ver = (weight._version, weight.data_ptr(), None if bias is None else bias._version)
+        ver = (weight._version, weight.data_ptr(), None if bias is None else bias._version, ops.CACHE_EPOCH)
         hit = self._w16.get(key)
         if hit is None or hit[0] != ver:
             with torch.no_grad():

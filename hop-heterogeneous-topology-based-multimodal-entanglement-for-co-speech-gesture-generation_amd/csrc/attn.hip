@@ -732,6 +732,13 @@ static int attn_args_ok(const char* what, int N, int S, int H, int E, float p_dr
     return HOPMI_EINVAL;
   }
   if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("%s: p_drop=%f outside [0,1)", what, p_drop); return HOPMI_EINVAL; }
+  // the dropped-out probabilities (P o M) <= 1 / (1 - p_drop) are split at the FIXED scale 2^14 (forward P V, backward dV): from
+  // p_drop = 0.75 on, 4 x 2^14 leaves fp16's range and the row-maximum element (P == 1) would become infinity.  The reference trains
+  // with 0.1 (HOP.py:256); refuse what this kernel cannot represent instead of returning NaN.
+  if (p_drop >= 0.75f) {
+    set_error("%s: p_drop=%f: the fp16 hi/lo form of the dropped-out probabilities holds p_drop < 0.75 (use ops.strict_fp32 for more)", what, p_drop);
+    return HOPMI_EINVAL;
+  }
   if (dtype != HOPMI_F32 && dtype != HOPMI_BF16) { set_error("%s: dtype %d (0 = fp32, 1 = bf16)", what, dtype); return HOPMI_EINVAL; }
   return HOPMI_OK;
 }

@@ -501,6 +501,7 @@ class GraphedTrainStep:
         traceback.print_exception(type(exc), exc, exc.__traceback__, file=sys.stderr)
         self.enabled = False
         self.records.clear()
+        _ops.reset_all_caches("recording")          # (whatever the interrupted recording cached lives in a pool that is being given up)
         self.broken = f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}"
         L = _lib.lib()
         st = ctypes.c_int(-1)

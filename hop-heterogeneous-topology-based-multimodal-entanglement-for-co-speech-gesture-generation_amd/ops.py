@@ -455,11 +455,129 @@ def row_scales(a2d):
     return sc
 
 
+# ------------------------------------------------------- derived-operand caches: one invalidation point, one paranoid mode
+# Everything this package derives from a tensor and keeps beside it -- the row scales / fp16 operand images producers attach to
+# their outputs (`_hopmi_rs`, `_hopmi_img`), bf16 casts of parameters (_CAST_CACHE), fp16 hi/lo images of trainable and frozen
+# weights (_F16_IMG, _F16_IMG_FROZEN), constant scale tables (_UNIT_RS), and the frozen BERT's fused QKV weight, images, FFN bounds
+# and bf16 copies (bert_fast.FrozenBertEncoder) -- is valid for ONE (owner identity, version counter, CACHE_EPOCH) triple.
+# `reset_all_caches()` is the single invalidation point: scope "recording" forgets what must not cross a recording's boundary
+# (graph.GraphedTrainStep, both ends and after a failed recording); scope "all" (invalidate_weight_images: a write through `.data`
+# that no version counter saw) additionally moves CACHE_EPOCH, which every table and the encoder's private caches carry in their key.
+# HOPMI_CACHE_CHECK=1 (`cache_check(True)`): every HIT of those caches outside a stream capture is verified against a fresh
+# computation -- bitwise for scales, weight images and casts; for operand images by decoding them (a producer may have chosen
+# another power-of-two scale than the row maximum's: hi + lo must reproduce the tensor to 2^-21 of the row's scaled maximum and be
+# finite) -- and raises HopmiError naming the cache.  The GPU suite runs the recorded-step and soak tests once under it.
+CACHE_EPOCH = 0
+CACHE_CHECK = __import__("os").environ.get("HOPMI_CACHE_CHECK", "0") == "1"
+_CACHE_CHECKS_DONE = 0          # hits verified so far (tests assert the mode did something)
+_EXTRA_RESETTERS = []           # callables(scope) of caches that live outside this module
+
+
+def cache_check(on=None):
+    """Switch the paranoid mode of the derived-operand caches; returns the previous setting (`None` only reads it)."""
+    global CACHE_CHECK
+    prev = CACHE_CHECK
+    if on is not None:
+        CACHE_CHECK = bool(on)
+    return prev
+
+
+def cache_checks_done():
+    return _CACHE_CHECKS_DONE
+
+
+def register_cache_resetter(fn):
+    """`fn(scope)` is called by reset_all_caches (scope "recording" or "all")."""
+    _EXTRA_RESETTERS.append(fn)
+
+
+def reset_all_caches(scope="all"):
+    """THE invalidation point of every derived-operand cache (see above).  scope "recording": what an eager call made must not be
+    served to a recording and vice versa (casts and trainable-weight images: dropped; frozen-weight images first BUILT under capture:
+    dropped -- their prepare launch was only recorded and their memory is the graph pool's).  scope "all": everything, and
+    CACHE_EPOCH moves so that caches held elsewhere (the frozen BERT encoder's, tensor-attached scales / images) stop matching."""
+    global CACHE_EPOCH
+    if scope not in ("recording", "all"):
+        raise ValueError(f"hopmi reset_all_caches: scope {scope!r}")
+    _CAST_CACHE.clear()
+    _F16_IMG.clear()
+    if scope == "all":
+        CACHE_EPOCH += 1
+        _F16_IMG_FROZEN.clear()
+        _UNIT_RS.clear()
+    else:
+        for key in [k for k, v in _F16_IMG_FROZEN.items() if v[3]]:
+            del _F16_IMG_FROZEN[key]
+    for fn in list(_EXTRA_RESETTERS):
+        fn(scope)
+
+
+def _checking():
+    return CACHE_CHECK and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+
+
+def _check_fail(what, detail):
+    raise _lib.HopmiError(f"hopmi HOPMI_CACHE_CHECK: stale or wrong cached operand -- {what}: {detail}")
+
+
+def _check_count():
+    global _CACHE_CHECKS_DONE
+    _CACHE_CHECKS_DONE += 1
+
+
+def _check_equal(what, cached, fresh):
+    _check_count()
+    if cached.shape != fresh.shape or cached.dtype != fresh.dtype or not torch.equal(cached, fresh):
+        _check_fail(what, f"cached {tuple(cached.shape)} {cached.dtype} differs from a fresh computation")
+
+
+def _check_scales(what, t2d, sc):
+    """Scales a producer attached to `t2d` still describe it: (power of two, inverse) pairs, equal to the row-maximum scale of a fresh
+    pass or -- a producer that scaled from an a-priori bound -- up to 2^12 below it (never above: that row would overflow fp16)."""
+    _check_count()
+    fresh = row_scales(t2d)
+    if not bool(((sc[0].double() * sc[1].double()) == 1.0).all()):
+        _check_fail(what, "not (scale, inverse) pairs")
+    ratio = fresh[0].double() / sc[0].double()
+    if not bool(((ratio >= 1.0) & (ratio <= 4096.0)).all()):
+        r = int(torch.nonzero(~((ratio >= 1.0) & (ratio <= 4096.0)))[0])
+        _check_fail(what, f"row {r}: attached scale {float(sc[0][r]):g} against {float(fresh[0][r]):g} from the values")
+
+
+def _decode_rows_image(img, M, K):
+    """(hi + lo) of a tile-blocked fp16 rows image (csrc/gemm.hip f16_blk) as an fp32 (M, Kp) matrix + the hi part (for finiteness)."""
+    Kp = (K + 31) // 32 * 32
+    Mp = (M + 127) // 128 * 128
+    h = img.view(torch.float16).view(2, Mp // 128, Kp // 32, 128, 32).permute(0, 1, 3, 2, 4).reshape(2, Mp, Kp)
+    return (h[0, :M].float() + h[1, :M].float()), h[0, :M]
+
+
+def _check_image(what, t2d, img, sc):
+    """The image + scales a producer attached to `t2d` (M, K) describe it: hi finite, (hi + lo) / s == t to 2^-21 of the row's
+    scaled maximum (+ the fp16 subnormal floor), s a power of two with its inverse beside it."""
+    _check_count()
+    M, K = t2d.shape
+    val, hi = _decode_rows_image(img, M, K)
+    s, inv = sc[0].double(), sc[1].double()
+    if not bool(torch.isfinite(hi).all()):
+        _check_fail(what, "non-finite hi part in the operand image")
+    if not bool(((s * inv) == 1.0).all()) or not bool((torch.frexp(sc[0])[0] == 0.5).all()):
+        _check_fail(what, "row scales are not (power of two, inverse) pairs")
+    want = t2d.double() * s.unsqueeze(1)
+    tol = want.abs().amax(dim=1, keepdim=True) * 2.0 ** -21 + 2.0 ** -23
+    bad = (val[:, :K].double() - want).abs() > tol
+    if K < val.shape[1] and bool((val[:, K:] != 0).any()):
+        _check_fail(what, "non-zero pad columns in the operand image")
+    if bool(bad.any()):
+        r = int(torch.nonzero(bad.any(dim=1))[0])
+        _check_fail(what, f"image row {r} does not reproduce the tensor ({int(bad.sum())} elements off)")
+
+
 def _attach_rs(t, sc):
     """Remember the fp16-form row scales `sc` ([2][M]) of tensor `t` ON the tensor object, with what identifies the values they
     were taken from (storage address, version counter): the kernel that produced `t` had its rows in registers, and the GEMM that
     consumes `t` (possibly on the other side of an autograd edge: the Python object travels) asks `_take_rs`."""
-    t._hopmi_rs = (sc, t.data_ptr(), t._version)
+    t._hopmi_rs = (sc, t.data_ptr(), t._version, CACHE_EPOCH)
 
 
 def _take_rs(t, M):
@@ -467,9 +585,11 @@ def _take_rs(t, M):
     hit = getattr(t, "_hopmi_rs", None)
     if hit is None:
         return None
-    sc, ptr, ver = hit
-    if ptr != t.data_ptr() or ver != t._version or tuple(sc.shape) != (2, M) or sc.device != t.device:
+    sc, ptr, ver, epoch = hit
+    if ptr != t.data_ptr() or ver != t._version or epoch != CACHE_EPOCH or tuple(sc.shape) != (2, M) or sc.device != t.device:
         return None
+    if _checking() and t.dtype == torch.float32 and t.numel() % M == 0 and (t.numel() // M) % 4 == 0 and t.is_contiguous() and t.data_ptr() % 16 == 0:
+        _check_scales("row scales attached to a tensor (_take_rs)", t.detach().reshape(M, -1), sc)
     return sc
 
 
@@ -477,14 +597,22 @@ def _attach_img(t, img, sc, norms=None):
     """Remember the fp16 hi / lo operand image `img` (tile-blocked, hopmi_rows_image_f16_bytes) and its row scales `sc` of tensor `t` ON
     the tensor object (as _attach_rs does for the scales alone): the LayerNorm kernels write it beside `t`, the GEMM that consumes `t`
     asks `_take_img` and runs the LDS-DMA form (hopmi_gemm_f16x2_ab_ep).  `norms`: the rows' 2-norms ([M], `_take_norms`)."""
-    t._hopmi_img = (img, sc, t.data_ptr(), t._version, norms)
+    t._hopmi_img = (img, sc, t.data_ptr(), t._version, norms, CACHE_EPOCH)
     _attach_rs(t, sc)
 
 
 def _take_norms(t, M):
     hit = getattr(t, "_hopmi_img", None)
-    if hit is None or hit[4] is None or hit[2] != t.data_ptr() or hit[3] != t._version or tuple(hit[4].shape) != (M,):
+    if hit is None or hit[4] is None or hit[2] != t.data_ptr() or hit[3] != t._version or hit[5] != CACHE_EPOCH or tuple(hit[4].shape) != (M,):
         return None
+    if _checking() and t.dtype == torch.float32 and t.is_contiguous():
+        # the norms feed an a-priori BOUND (gemm.hip, image epilogue): never below the true norm, never far above it
+        _check_count()
+        true = t.detach().reshape(M, -1).double().norm(dim=1)
+        got = hit[4].double()
+        big = true > 1e-37
+        if not bool((got[big] >= true[big]).all()) or not bool((got <= true * (1 + 1e-5) + 1e-44).all()):
+            _check_fail("row norms attached to a tensor (_take_norms)", "they do not bound the rows' 2-norms")
     return hit[4]
 
 
@@ -492,10 +620,12 @@ def _take_img(t, M, K):
     hit = getattr(t, "_hopmi_img", None)
     if hit is None or not IMG_FUSED:
         return None
-    img, sc, ptr, ver, _ = hit
-    if (ptr != t.data_ptr() or ver != t._version or img.numel() != _lib.lib().hopmi_rows_image_f16_bytes(M, K) or tuple(sc.shape) != (2, M)
-            or img.device != t.device):
+    img, sc, ptr, ver, _, epoch = hit
+    if (ptr != t.data_ptr() or ver != t._version or epoch != CACHE_EPOCH or img.numel() != _lib.lib().hopmi_rows_image_f16_bytes(M, K)
+            or tuple(sc.shape) != (2, M) or img.device != t.device):
         return None
+    if _checking() and t.dtype == torch.float32 and t.is_contiguous():
+        _check_image("operand image attached to a tensor (_take_img)", t.detach().reshape(M, K), img, sc)
     return img, sc
 
 
@@ -646,7 +776,9 @@ def _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=False, aux=None, 
                 and M >= max(F16_LINEAR_MIN_ROWS, IMG_MIN_ROWS)):
             # no scales at hand: the pass that would take the row scales writes the operand's fp16 images as well, and the LDS-DMA form
             # multiplies (bit-identical to row scales + the split form)
-            return _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=keep, aux=aux, out=out, rowmax=rowmax, a_img=rows_image(a2d))
+            im = rows_image(a2d)
+            _attach_rs(a2d, im[1])                     # (a later consumer of the same tensor object -- the weight-gradient GEMM -- takes the scales)
+            return _split_gemm_ep(a2d, img, bias, N, K, parts, epilogue, keep=keep, aux=aux, out=out, rowmax=rowmax, a_img=im)
         if a_part is None:
             a_part = row_scales(a2d)
             _attach_rs(a2d, a_part)                    # (a later consumer of the same tensor object -- the weight-gradient GEMM -- takes them)
@@ -961,26 +1093,22 @@ _CAST_CACHE = {}    # id(parameter) -> (weak reference, version, dtype, cast cop
 
 
 def cast_cache_reset():
-    """Forget every cached cast.  graph.GraphedTrainStep calls this right before it starts recording a step and right after: a copy
-    made by an eager call lives in the eager allocator pool, and a recording that was served that copy would bake its address in
-    without recording the cast (stale or freed memory on every replay); a copy made while recording lives in the graph's pool."""
-    _CAST_CACHE.clear()
-    _F16_IMG.clear()
-    # frozen-owner images survive a recording (it may hold their address) -- except one that was first BUILT under capture: its
-    # prepare launch was only recorded and its memory belongs to the graph's pool, so an eager step must not be served it
-    for key in [k for k, v in _F16_IMG_FROZEN.items() if v[3]]:
-        del _F16_IMG_FROZEN[key]
+    """What graph.GraphedTrainStep calls right before it starts recording a step and right after (and after a failed recording): a
+    copy made by an eager call lives in the eager allocator pool, and a recording that was served that copy would bake its address
+    in without recording the cast (stale or freed memory on every replay); a copy made while recording lives in the graph's pool.
+    = reset_all_caches("recording")."""
+    reset_all_caches("recording")
 
 
 def invalidate_weight_images():
-    """Forget every cached operand derived from a weight (bf16 casts, fp16 hi/lo images of trainable AND frozen owners).  The caches
-    are keyed on the owner parameters' identity + version counter, so an update that bypasses the counter (`p.data.copy_`,
-    `p.data.mul_`, an EMA written through `.data`) leaves a stale image behind that every later forward / dX product would use
-    until the next optimizer step: call this after any such write.  (`load_state_dict`, optimizer steps and in-place ops on the
-    parameter itself move the counter and need nothing.)"""
-    _CAST_CACHE.clear()
-    _F16_IMG.clear()
-    _F16_IMG_FROZEN.clear()
+    """Forget every cached operand derived from a weight or attached to a tensor: bf16 casts, fp16 hi/lo images of trainable AND
+    frozen owners, the frozen BERT encoder's fused QKV weight / images / FFN norm bounds / bf16 copies, row scales and images
+    producers attached to their outputs.  The caches are keyed on identity + version counter (+ CACHE_EPOCH), so an update that
+    bypasses the counter (`p.data.copy_`, `p.data.mul_`, an EMA written through `.data`) leaves stale operands behind -- for the
+    FFN bounds a too-small bound, i.e. overflowing fp16 images -- until the next optimizer step: call this after any such write.
+    (`load_state_dict`, optimizer steps and in-place ops on the parameter itself move the counter and need nothing.)
+    = reset_all_caches("all")."""
+    reset_all_caches("all")
 
 
 def _cast_param(w, dt):
@@ -994,6 +1122,8 @@ def _cast_param(w, dt):
     hit = _CAST_CACHE.get(id(w))
     # (a hit must come from the same side of a recording as the lookup: entry[4] says whether the copy was made under capture)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == dt and hit[4] == cap:
+        if _checking():
+            _check_equal("cast of a parameter (_cast_param)", hit[3], w.detach().to(dt))
         return hit[3]
     c = w.detach().to(dt)
     _CAST_CACHE[id(w)] = (weakref.ref(w), w._version, dt, c, cap)
@@ -1084,7 +1214,7 @@ def f16_weight_image(w, transpose=False, owners=None):
     if not owners:
         return build()
     key = tuple(id(o) for o in owners) + (N, K, bool(transpose))
-    vers = tuple(o._version for o in owners) + (w.data_ptr(),)
+    vers = tuple(o._version for o in owners) + (w.data_ptr(), CACHE_EPOCH)
     # FROZEN owners (no gradient): the image is static -- one table that no recording resets (a recording may hold the address of an
     # image made by an eager call: the table keeps it alive until the weight itself changes, and GraphedTrainStep drops its
     # recordings when a frozen parameter's version moves)
@@ -1094,6 +1224,8 @@ def f16_weight_image(w, transpose=False, owners=None):
     hit = table.get(key)
     # (a frozen image made by an EAGER call serves both sides of a recording; one made under capture only the recording)
     if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == vers and (hit[3] == cap or (frozen and not hit[3])):
+        if _checking():
+            _check_equal("fp16 image of a weight (f16_weight_image)", hit[2], build())
         return hit[2]
     img = build()
     if not frozen and len(table) > 256:
@@ -1253,11 +1385,15 @@ class _F16LinearFn(torch.autograd.Function):
         dx = dw = db = None
         tn = ctx.needs_input_grad[1] and f16_mm_tn_ok(dy2, x2)
         ds, di = _take_rs(dy, dy2.shape[0]), None
-        if (tn or (ctx.needs_input_grad[0] and N % 4 == 0 and K >= 128)) and N % 4 == 0:
-            if ds is None or ctx.needs_input_grad[0]:
-                ds, di = _linear_operand(dy, dy2)      # one pass serves both gradient products
+        dx_f16 = ctx.needs_input_grad[0] and N % 4 == 0 and K >= 128       # (dX contracts over N: the kernel's K % 4 == 0 rule applies to it here)
+        if dx_f16:
+            ds, di = _linear_operand(dy, dy2)          # one pass (scales + image) serves both gradient products
+        elif tn and ds is None and N % 4 == 0:
+            # only the weight gradient wants dY (a first layer, or dX with K < 128 on the library): its row scales, no image
+            ds = row_scales(dy2)
+            _attach_rs(dy2, ds)
         if ctx.needs_input_grad[0]:
-            if N % 4 == 0 and K >= 128:                  # (dX contracts over N: the kernel's K % 4 == 0 rule applies to it here)
+            if dx_f16:
                 dx = _split_gemm(dy2, f16_weight_image(w, transpose=True, owners=ctx.owners), None, K, N, F16_PARTS, a_part=ds, a_img=di)
             else:
                 dx = dy2 @ w

@@ -754,6 +754,25 @@ def test_graphed_step_soak_interleaved_with_eager_work(epoch, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------- input stage (feeder)
+@pytest.mark.parametrize("which", ["recorded_step_baseline_size", "soak", "bf16"])
+def test_operand_caches_hold_under_the_paranoid_mode(which, monkeypatch):
+    """HOPMI_CACHE_CHECK (ops.cache_check): every hit of a derived-operand cache outside a stream capture -- row scales / operand
+    images / row norms attached to tensors, parameter casts, fp16 weight images, the frozen BERT encoder's fused QKV weight, images
+    and FFN bounds -- is verified against a fresh computation and raises on a mismatch.  Run once over the recorded step at
+    configs[1] size (the image paths need >= 3072 rows), the 52-replay soak with its interleaved eager work, and the bf16 step: the
+    tests' own assertions hold, nothing raises, and the mode did verify hits."""
+    from hopmi import ops
+    monkeypatch.setattr(ops, "CACHE_CHECK", True)
+    n0 = ops.cache_checks_done()
+    if which == "recorded_step_baseline_size":
+        test_graphed_step_baseline_size_vs_reference(9, 128, 0, monkeypatch)
+    elif which == "soak":
+        test_graphed_step_soak_interleaved_with_eager_work(0, monkeypatch)
+    else:
+        test_graphed_step_bf16_follows_eager(monkeypatch)
+    assert ops.cache_checks_done() >= n0 + 10, ops.cache_checks_done() - n0
+
+
 def test_logmel_vs_float64_restatement():
     """hopmi_logmel (GPU: reflect-padded framing, periodic Hann, radix-2 FFT in LDS, Slaney mel filters, power_to_db with
     ref = max and an 80 dB floor) against oracle/mel_ref.py, the float64 restatement of librosa 0.8.1's published

@@ -1997,6 +1997,63 @@ def test_ffn_image_path_on_vanishing_gradient_rows(monkeypatch):
     assert float((num[ok] / den[ok]).max()) <= 4e-6, float((num[ok] / den[ok]).max())
 
 
+def test_cache_check_catches_a_stale_weight_operand_and_one_call_invalidates_everything(monkeypatch):
+    """A write through `.data` moves no version counter: the cached fp16 image of a trainable weight, and the frozen BERT encoder's
+    fused QKV weight / images / FFN norm bounds (too SMALL after a rescale: overflowing fp16 images), go stale.  Under
+    HOPMI_CACHE_CHECK the next hit raises and names the cache; ops.invalidate_weight_images() (= reset_all_caches("all"), the
+    single invalidation point: it also moves CACHE_EPOCH, which the encoder's private caches and the tensor-attached scales carry)
+    makes every consumer rebuild."""
+    from hopmi import _lib, bert_fast, ops, synth
+    dev = _dev()
+    monkeypatch.setattr(ops, "GEMM_PARTS", 16)
+    w = torch.nn.Parameter(torch.randn(256, 512, device=dev))
+    img0 = ops.f16_weight_image(w, owners=(w,))
+    assert ops.f16_weight_image(w, owners=(w,)) is img0                       # a hit
+    w.data.mul_(3.0)                                                          # behind the counter's back
+    assert ops.f16_weight_image(w, owners=(w,)) is img0                       # ... still served: the documented hazard
+    monkeypatch.setattr(ops, "CACHE_CHECK", True)
+    with pytest.raises(_lib.HopmiError, match="f16_weight_image"):
+        ops.f16_weight_image(w, owners=(w,))
+    epoch = ops.CACHE_EPOCH
+    ops.invalidate_weight_images()
+    assert ops.CACHE_EPOCH == epoch + 1
+    img1 = ops.f16_weight_image(w, owners=(w,))
+    assert img1 is not img0 and not torch.equal(img1, img0)
+    assert ops.f16_weight_image(w, owners=(w,)) is img1                       # verified hit, no raise
+    # the encoder's private caches
+    llm = synth.build_bert(1).to(dev)
+    for p in llm.parameters():
+        p.requires_grad_(False)
+    enc = bert_fast.FrozenBertEncoder(llm)
+    lay = llm.encoder.layer[0]
+    monkeypatch.setattr(ops, "CACHE_CHECK", False)
+    b0 = enc._ffn_bounds(0, lay)
+    q0 = enc._fused_qkv(0, lay.attention.self)[0]
+    x = torch.randn(1152, 768, device=dev)
+    i0 = enc._images((0, "f1"), x, lay.intermediate.dense.weight)
+    lay.intermediate.dense.weight.data.mul_(4.0)
+    lay.attention.self.query.weight.data.mul_(2.0)
+    assert enc._ffn_bounds(0, lay) == b0                                      # stale: a quarter of the true bound
+    monkeypatch.setattr(ops, "CACHE_CHECK", True)
+    with pytest.raises(_lib.HopmiError, match="FFN norm bounds"):
+        enc._ffn_bounds(0, lay)
+    with pytest.raises(_lib.HopmiError, match="fused QKV"):
+        enc._fused_qkv(0, lay.attention.self)
+    with pytest.raises(_lib.HopmiError, match="weight image"):
+        enc._images((0, "f1"), x, lay.intermediate.dense.weight)
+    ops.invalidate_weight_images()
+    b1 = enc._ffn_bounds(0, lay)
+    assert abs(b1[0] / b0[0] - 4.0) < 1e-5
+    assert not torch.equal(enc._fused_qkv(0, lay.attention.self)[0], q0)
+    assert not torch.equal(enc._images((0, "f1"), x, lay.intermediate.dense.weight)[0], i0[0])
+    # tensor-attached scales stop matching when the epoch moves
+    t = torch.randn(1152, 768, device=dev)
+    ops._attach_rs(t, ops.row_scales(t))
+    assert ops._take_rs(t, 1152) is not None
+    ops.reset_all_caches("all")
+    assert ops._take_rs(t, 1152) is None
+
+
 def test_bert_attention_writes_the_next_gemms_operand_image(monkeypatch):
     """hopmi_bert_attn_fwd_im: the attention kernel also writes its output's fp16 hi / lo operand image, scaled per clip from the
     bound |dropout(P) V| <= max |V[clip]| / (1 - p) (max |V| from the QKV product's partial row maxima) -- the fp32 output is
@@ -2111,6 +2168,35 @@ def test_gemm_f16x2_tn_vs_float64(M, N, K):
     acc = out.clone()
     ops.f16_mm_tn(dyd, xd, a_rs, b_rs, out=acc, accumulate=True)
     assert rel_err(acc.cpu().double(), 2 * ref) <= 3.0 * e_lib + 2.4e-7
+
+
+def test_gemm_f16x2_tn_per_output_channel_precision_limit():
+    """What the TN form's ONE scale per operand costs, pinned per output row of dW (advisor, round 5).  The rows of dY are the
+    contraction index, so dY carries a single power-of-two scale (the minimum of its row scales): an output channel n whose dY
+    column sits a factor r below the tensor's maximum keeps an absolute error of ~2^-39 of that maximum (f16_dev.h), i.e. a RELATIVE
+    error of ~2^-39 / r -- fp32-class down to r = 2^-17, 11 bits at r = 2^-28, gone below ~2^-39, where the library's fp32 GEMM keeps
+    full precision.  (Adam divides by sqrt(v) + 1e-8: a gradient 2^-39 below the layer's largest changes its update by less than
+    that epsilon does; DESIGN.md 4.10b states the limit next to the "fp32-equivalent" claim.)  Columns of dY spanning 1 ... 1e-9."""
+    from hopmi import ops
+    dev = _dev()
+    M, N, K = 4352, 768, 1536
+    g = torch.Generator().manual_seed(5)
+    r = torch.logspace(0, -9, N, dtype=torch.float64)
+    dy = (torch.randn(M, N, generator=g).double() * r.unsqueeze(0)).float()
+    x = torch.randn(M, K, generator=g)
+    ref = dy.double().t() @ x.double()
+    dyd, xd = dy.to(dev), x.to(dev)
+    out = ops.f16_mm_tn(dyd, xd, ops.row_scales(dyd), ops.row_scales(xd)).cpu().double()
+    lib = (dyd.t() @ xd).cpu().double()
+    err = (out - ref).norm(dim=1) / ref.norm(dim=1)
+    err_lib = (lib - ref).norm(dim=1) / ref.norm(dim=1)
+    # the measured ratio column maximum / tensor maximum of every output channel
+    ratio = dy.abs().amax(dim=0).double() / float(dy.abs().max())
+    allowed = 4.0 * err_lib.max() + 2.0 ** -37 / ratio
+    assert bool((err <= allowed).all()), (float((err / allowed).max()), int((err / allowed).argmax()))
+    # fp32 class where the columns are within 2^-17 of the largest
+    near = ratio >= 2.0 ** -17
+    assert float(err[near].max()) <= 4.0 * float(err_lib.max()) + 2e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(4352, 2100, 700), (4352, 768, 1536), (1000, 132, 72)])
