@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
 // a knob inside one process call it after changing the variable).
 namespace {
 struct EnvSlot { const char* name; int value; };
-constexpr int kEnvSlots = 16;
+constexpr int kEnvSlots = 32;
 EnvSlot g_env[kEnvSlots];
 std::atomic<int> g_env_n{0};
 std::mutex g_env_mu;

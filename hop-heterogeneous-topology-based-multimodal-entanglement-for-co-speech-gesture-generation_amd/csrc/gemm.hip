@@ -550,13 +550,22 @@ struct AbImageOut { _Float16* image; float* scales; const float* row_norm; float
 
 // BM = 64 (fp16 form): 64-row tiles (8 waves of 32 x 32) for shapes whose 128-row tiling leaves most CUs idle (N = 768 at M = 2176:
 // 102 tiles -> 204).
-template <int NP, int NBUF, bool F16 = false, int BM = 128>
-__global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Bimg,
+// WV = waves per workgroup (round 6).  The k-loop is LDS-BANDWIDTH bound, not matrix-pipe bound: per k-step a 64 x 128 tile's 8 waves
+// of 32 x 32 read 8 x 8 KB of fragments and the DMA writes 24 KB -- 88 KB through the CU's 128 B/clk LDS = 704 clocks against 386 clocks
+// of MFMA (3 terms x 64 x 128 x 32 x 2 flops at 4 069 flops/clk/CU): the matrix pipe cannot be busy more than 0.55 of the time, measured
+// 0.26.  Four waves of 32 x 64 read 4 x 12 KB for the same tile (an A fragment serves four column tiles instead of two): 72 KB, 576
+// clocks, with three workgroups per CU (48 KB of LDS each) instead of two.  Same terms in the same order per output element: bit-identical.
+template <int NP, int NBUF, bool F16 = false, int BM = 128, int WV = 8>
+__global__ __launch_bounds__(64 * WV, 1) void gemm_split_ab_kernel(const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Bimg,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N,
                                                              int K, int tiles_m, int tiles_n, const float* __restrict__ a_rows, int ep,
                                                              float* __restrict__ C2, const float* __restrict__ aux,
                                                              float* __restrict__ c_rowmax, AbImageOut io) {
   static_assert(BM == 128 || (BM == 64 && F16), "64-row tiles: fp16 form only");
+  static_assert(WV == 8 || (WV == 4 && BM == 64 && F16), "4-wave workgroups: 64-row tiles of the fp16 form");
+  constexpr int WC = WV / 2;                       // wave columns (wave rows: always 2)
+  constexpr int NI = GN / (16 * WC);               // 16-column MFMA tiles per wave: 2 (8 waves) or 4 (4 waves)
+  constexpr int BCH = 8 / WV;                      // 16-row chunks of the B tile every wave stages per part
   __shared__ unsigned s_cmax[F16 ? BM : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int IMG = 128 * 64;                    // bytes of one part image of the B operand tile
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   constexpr int MI = BM / 32;                      // 16-row MFMA tiles per wave (wave rows = BM / 2)
   constexpr int BUFB = NP * (IMGA + IMG);          // [A parts | B parts]
   int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wv >> 2, wc = wv & 3;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wv / WC, wc = wv % WC;
   const int lane = tid & 63, q = lane >> 4, n = lane & 15;
   const int ntiles = tiles_m * tiles_n;
   const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
@@ -595,19 +604,22 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
       if (BM == 128 || wv < 4)                         // (64-row tiles: waves 0-3 move the A rows; wave-uniform)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + p * a_part + k0),
                                          (__attribute__((address_space(3))) void*)(dst + p * IMGA), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + p * b_part + k0),
-                                       (__attribute__((address_space(3))) void*)(dst + NP * IMGA + p * IMG), 16, 0, 0);
+#pragma unroll
+      for (int c = 0; c < BCH; ++c)                    // (chunk wv + WV c: 16 rows = 512 halves of the blocked image, 1 KiB of LDS further on)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + p * b_part + k0 + (size_t)c * WV * 512),
+                                         (__attribute__((address_space(3))) void*)(dst + NP * IMGA + p * IMG + c * WV * 1024), 16, 0, 0);
     }
   };
 
-  f32x4 acc[MI][2];
+  f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
   // (64-row tiles: waves 4-7 issue half the DMA instructions of waves 0-3; the counted waits below assume 2 NP per tile, which
   // over-waits for those waves -- harmless)
   constexpr int PER_TILE = 2 * NP;
+  static_assert(WV == 8 || NBUF == 2, "4-wave workgroups: the counted waits below are written for two tile buffers (vmcnt(0))");
 
   // split-K (gridDim.y > 1; hopmi_gemm_f16x2_ab_splitk): slab y multiplies k-steps [nk_all y / S, nk_all (y + 1) / S) into C + y M N
   const int nk_all = K / GK, ksp = gridDim.y, ky = blockIdx.y;
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const int fa_off = ((BM / 2) * wr + n) * 64 + ((q ^ gswz(n)) << 4);          // (the swizzle only depends on n: row = 16 k + n)
-  const int fb_off = NP * IMGA + (32 * wc + n) * 64 + ((q ^ gswz(n)) << 4);
+  const int fb_off = NP * IMGA + (16 * NI * wc + n) * 64 + ((q ^ gswz(n)) << 4);
   for (int kt = 0; kt < nk; ++kt) {
     const bool ahead = kt + NBUF - 1 < nk;
 #if HOPMI_AB_EXP == 1                                  // (timing experiment: no DMA in the k-loop)
@@ -643,7 +655,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 #endif
       }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       u32x4 bf[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -685,8 +697,8 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) rmx[mi][r] = 0u;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + 32 * wc + 16 * ni + n;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n0 + 16 * NI * wc + 16 * ni + n;
     if (F16 && col >= N) continue;                   // (pad columns of the last column tile)
     const float bv = bias != nullptr ? bias[col] : 0.f;
     const float sb = F16 ? inv_b[col] : 1.f;
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(GT, 1) void gemm_split_ab_kernel(const __bf16* __re
   }
 }
 
-template <int NP, int NBUF, bool F16 = false, int BM = 128>
+template <int NP, int NBUF, bool F16 = false, int BM = 128, int WV = 8>
 static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias, float* C, int M, int N, int K, hipStream_t st,
                            const float* a_rows = nullptr, int ep = EP_BIAS, float* C2 = nullptr, const float* aux = nullptr,
                            float* c_rowmax = nullptr, AbImageOut io = AbImageOut{nullptr, nullptr, nullptr, 0.f, 0.f}) {
@@ -754,14 +766,14 @@ static void launch_gemm_ab(const void* Aimg, const void* Bimg, const float* bias
   const size_t lds = (size_t)NBUF * NP * (BM + 128) * 64;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<NP, NBUF, F16, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_ab_kernel<NP, NBUF, F16, BM, WV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       (void)hipGetLastError();
     attr_done = true;
   }
   const int ntiles = tiles_m * tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF, F16, BM>), dim3(grid), dim3(GT), lds, st, static_cast<const __bf16*>(Aimg),
+  hipLaunchKernelGGL((gemm_split_ab_kernel<NP, NBUF, F16, BM, WV>), dim3(grid), dim3(64 * WV), lds, st, static_cast<const __bf16*>(Aimg),
                      static_cast<const __bf16*>(Bimg), bias, C, M, N, K, tiles_m, tiles_n, a_rows, ep, C2, aux, c_rowmax, io);
 }
 
@@ -912,6 +924,9 @@ static bool ab_half_tiles(int M, int N) {
   return true;       // (in the training step 64-row tiles win at every shape: 15.01 -> 14.81 ms per step against 128-row tiles, A/B on one box)
 }
 
+// 4-wave workgroups of 32 x 64 per wave (gemm_split_ab_kernel, WV): HOPMI_GEMM_AB_WAVES = 4 / 8 forces a form
+static bool ab_four_waves() { return env_int("HOPMI_GEMM_AB_WAVES", 8) == 4; }
+
 extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales, const void* Bimage, const float* bias, float* C, float* C2,
                                       const float* aux, float* c_rowmax, int M, int N, int K, int epilogue, void* stream) {
   if (!Aimage || !a_scales || !Bimage || !C) { set_error("hopmi_gemm_f16x2_ab: null pointer argument"); return HOPMI_EINVAL; }
@@ -932,6 +947,7 @@ extern "C" int hopmi_gemm_f16x2_ab_ep(const void* Aimage, const float* a_scales,
   // 64-row tiles when 128-row tiles would leave most of the chip idle (as the split form's mode 3)
   const bool half = ab_half_tiles(M, N);
   if (half && nbuf == 3) launch_gemm_ab<2, 3, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
+  else if (half && ab_four_waves()) launch_gemm_ab<2, 2, true, 64, 4>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else if (nbuf == 2) launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
   else launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, c_rowmax);
@@ -954,6 +970,7 @@ extern "C" int hopmi_gemm_f16x2_ab_img(const void* Aimage, const float* a_scales
   const AbImageOut io{static_cast<_Float16*>(out_image), out_scales, row_norm, bound_mul, bound_add};
   const bool half = ab_half_tiles(M, N);
   if (half && env_int("HOPMI_GEMM_NBUF", 0) == 3) launch_gemm_ab<2, 3, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
+  else if (half && ab_four_waves()) launch_gemm_ab<2, 2, true, 64, 4>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   else if (half) launch_gemm_ab<2, 2, true, 64>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   else if (env_int("HOPMI_GEMM_NBUF", 0) == 3) launch_gemm_ab<2, 3, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);
   else launch_gemm_ab<2, 2, true>(Aimage, Bimage, bias, C, M, N, K, st, a_scales, epilogue, C2, aux, nullptr, io);

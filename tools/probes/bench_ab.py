@@ -6,7 +6,7 @@ import hopmi
 from hopmi import ops, _lib
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-M = 4352
+M = int(sys.argv[sys.argv.index('--m') + 1]) if '--m' in sys.argv else 4352
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 
@@ -32,9 +32,13 @@ for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 2304)):
     t_img = timed(lambda: L.hopmi_rows_image_f16(x.data_ptr(), M, K, img_a.data_ptr(), sc2.data_ptr(), st))
     out = torch.empty(M, N, device=dev)
     res = {}
-    for nbuf in ("2", "3"):
-        os.environ["HOPMI_GEMM_NBUF"] = nbuf
-        L.hopmi_reload_env()
-        res[nbuf] = timed(lambda: L.hopmi_gemm_f16x2_ab(img_a.data_ptr(), sc2.data_ptr(), img.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
     ref = ops._split_gemm(x, img, b, N, K, 16, a_part=sc)
-    print(f"M={M} N={N} K={K}: split form {t_split:6.1f} us | ab nbuf2 {res['2']:6.1f} nbuf3 {res['3']:6.1f} us (image pass {t_img:5.1f}) equal {torch.equal(out, ref)}", flush=True)
+    eq = {}
+    for waves in ("8", "4"):                          # (round 6: 4-wave workgroups of 32 x 64 per wave)
+        os.environ["HOPMI_GEMM_AB_WAVES"] = waves
+        L.hopmi_reload_env()
+        out.zero_()
+        res[waves] = timed(lambda: L.hopmi_gemm_f16x2_ab(img_a.data_ptr(), sc2.data_ptr(), img.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+        eq[waves] = torch.equal(out, ref)
+    print(f"M={M} N={N} K={K}: split form {t_split:6.1f} us | ab 8 waves {res['8']:6.1f} 4 waves {res['4']:6.1f} us (image pass {t_img:5.1f}) "
+          f"bit-identical to the split form: {eq}  TF-equiv(4w) {2 * M * N * K / res['4'] / 1e6:6.1f}", flush=True)
