@@ -731,12 +731,20 @@ __global__ __launch_bounds__(STK_THREADS) void wn_stack_fwd_kernel(StackArgs A) 
       __syncthreads();
       STK_STAMP(layer, 15);
       if (tid < C) {
+        // (all STK_GROUPS slots, unrolled: a dead group's slot holds zeros -- written above by its wave -- and x + 0.0 == x, so the
+        // sum is the same bits as over the live groups only; with the run-time bound the loop ran as 8 dependent LDS round trips,
+        // ~1 400 cycles on the critical path of every layer: now the 16 reads are in flight together)
+        float2 fa[STK_GROUPS], fb[STK_GROUPS];
+#pragma unroll
+        for (int k = 0; k < STK_GROUPS; ++k) {
+          fa[k] = *reinterpret_cast<const float2*>(FINF + k * 4 * C + 2 * tid);
+          fb[k] = *reinterpret_cast<const float2*>(FINF + k * 4 * C + 2 * (C + tid));
+        }
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < n_groups; ++k) {
-          const float2 a = *reinterpret_cast<const float2*>(FINF + k * 4 * C + 2 * tid);
-          const float2 b = *reinterpret_cast<const float2*>(FINF + k * 4 * C + 2 * (C + tid));
-          s1 += (double)a.x + (double)a.y;
-          s2 += (double)b.x + (double)b.y;
+#pragma unroll
+        for (int k = 0; k < STK_GROUPS; ++k) {
+          s1 += (double)fa[k].x + (double)fa[k].y;
+          s2 += (double)fb[k].x + (double)fb[k].y;
         }
         // mean and variance in double (E[y^2] - mean^2 cancels); everything behind them in float: 1 / sqrt by the hardware
         // rsq with one Newton step (1e-7 relative)

@@ -31,7 +31,18 @@ def main():
     steps._randperm = lambda n, device: torch.arange(n - 1, -1, -1, device=device)
     if os.environ.get("HOPMI_WORKER_DUMMY_MB"):        # diagnostic: shift every later allocation
         _dummy = torch.empty(int(float(os.environ["HOPMI_WORKER_DUMMY_MB"]) * (1 << 20)), dtype=torch.uint8, device=dev)
-    m1, d1, inp = _pair(9, dev)
+    fullsize = len(sys.argv) > 4 and sys.argv[4] == "fullsize"
+    if fullsize:
+        # BERT-base geometry at 96 clips = 3 264 rows: past ops.IMG_MIN_ROWS / LINEAR_IMG_MIN_ROWS, so the operand-image paths (LayerNorm /
+        # GEMM-epilogue / attention producers, the LDS-DMA GEMM form, the TN weight gradients) and their caches run BESIDE the exchange
+        # -- the caches are keyed on version counters that graph._adam_own_rows and _mark_written move outside the optimizer
+        from test_gpu_parity import _full_size_setup
+        m1, d1, _, inp = _full_size_setup(9, 96)
+        m1._randn_like = lambda t: torch.full_like(t, 0.25)
+        m1, d1 = m1.to(dev).train(), d1.to(dev).train()
+        inp = {k: v.to(dev) for k, v in inp.items()}
+    else:
+        m1, d1, inp = _pair(9, dev)
     # a different batch per rank (same replicas)
     names = ("in_audio", "log_melspec", "text", "target_dir_vec", "vid_indices")
     batch = tuple((inp[k] * (1.0 + 0.25 * rank)) if inp[k].is_floating_point() else inp[k].roll(rank, 0) for k in names)
@@ -160,7 +171,8 @@ def main():
     fake_status.zero_()
     graphed._bwd_status.zero_()
     graphed._peer_status.zero_()
-    print("RANKJSON " + json.dumps(dict(rank=rank, losses_eager=losses1, losses_graph=losses2, sharded=sharded_before, own=own,
+    from hopmi import ops as _hops
+    print("RANKJSON " + json.dumps(dict(rank=rank, fullsize=fullsize, img_min_rows=_hops.IMG_MIN_ROWS, losses_eager=losses1, losses_graph=losses2, sharded=sharded_before, own=own,
                                         stale_before_unshard=stale, n_plan=[k for k, _ in next(iter(graphed.records.values()))["cap"].plan],
                                         worst_max=max(v[0] for v in worst.values()), worst_mean=max(v[1] for k, v in worst.items() if not noise(k)),
                                         worst_mean_name=max((k for k in worst if not noise(k)), key=lambda k: worst[k][1]),

@@ -348,6 +348,38 @@ def test_graphed_step_dropout_advances(monkeypatch):
     assert len(set(losses[1:])) >= 4, losses
 
 
+def test_graphed_exchange_two_ranks_one_gpu_image_paths():
+    """The same two-rank comparison at BERT-base geometry and 96 clips per rank (3 264 rows >= ops.IMG_MIN_ROWS): the operand-image
+    producers, the LDS-DMA GEMM form, the TN weight gradients and every version-keyed operand cache run beside the row-sharded
+    exchange (whose Adam hook and _mark_written move version counters outside the optimizer).  Held to: the same loss dict as the
+    GradSync path every step, replicas identical across the ranks after unshard(), the shard bookkeeping of the small case."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29777", os.path.join(root, "tests", "graph_rank_worker.py"), "0", "sequential", "overlap", "fullsize"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    dec = json.JSONDecoder()
+    rows = [dec.raw_decode(chunk)[0] for chunk in r.stdout.split("RANKJSON ")[1:]]
+    assert len(rows) == 2, r.stdout[-2000:]
+    for row in rows:
+        assert row["fullsize"] and row["img_min_rows"] <= 3264, row["img_min_rows"]
+        assert row["sharded"] and row["own"] in ([0, 750], [750, 1500]), row
+        assert row["stale_before_unshard"] > 1e-4
+        for a, b in zip(row["losses_eager"], row["losses_graph"]):
+            assert sorted(a) == sorted(b)
+            for k in a:
+                assert abs(a[k] - b[k]) <= 5e-4 * max(abs(a[k]), 1e-6), (k, a[k], b[k])
+        assert row["replica_spread"] <= 1e-6 and row["replica_spread2"] <= 1e-6, (row["replica_spread"], row["replica_spread2"])
+        assert row["resharded"] and row["short_was_eager"], row
+        # (a skipped or doubled update of a tensor would show as ~lr = 1e-3 on its mean)
+        assert row["worst_mean"] <= 5e-4 and row["worst2_mean"] <= 8e-4, {k: row[k] for k in ("worst_mean", "worst_mean_name", "worst2_mean", "top2_mean")}
+        assert row["stopped_at"] == 1, row["stopped_at"]
+
+
 @pytest.mark.parametrize("epoch,order,exchange", [(0, "sequential", "overlap"), (11, "sequential", "overlap"), (0, "interleaved", "overlap"),
                                                   (11, "interleaved", "overlap"), (0, "sequential", "flat")])
 def test_graphed_exchange_two_ranks_one_gpu(epoch, order, exchange):
