@@ -187,6 +187,154 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_f16_tn_kernel(TnArgs P) {
   }
 }
 
+// Round 6: the same kernel with TWO tile buffers and the commit of step s + 1 (scale, split, transposing LDS stores: ~100 vector
+// instructions per thread) issued BETWEEN the MFMA groups of step s instead of behind a barrier of its own -- one barrier per step,
+// and the matrix pipe runs while the SIMD's vector issue slots (an MFMA holds them for 8 of its 16 cycles) take the split.  The LDS
+// rows shrink to their 64 data bytes (no pad; the 16-byte slot XOR-swizzled with the row, gemm.hip's gswz: column-major stores and
+// fragment reads both conflict-free), so two buffers are 64 KB and two workgroups per CU still fit.  Same terms, same order per
+// output element: bit-identical to the single-buffer form (tools/bench_linear.py --tn checks it).
+__device__ __forceinline__ int tn_swz(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_f16_tn_db_kernel(TnArgs P) {
+  constexpr int LDR = 32;                                                           // halves per LDS row (64 bytes, swizzled)
+  constexpr int BUF = 2 * 2 * TN_T * LDR;                                            // halves per tile buffer: [operand][part][128 rows][32]
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BUF];
+  __shared__ float red[TN_THREADS / 64];
+  int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wv >> 2, wc = wv & 3;
+  const int lane = tid & 63, q = lane >> 4, i16 = lane & 15;
+  const int b = blockIdx.x;
+  const int tk = b % P.tiles_k, tn = (b / P.tiles_k) % P.tiles_n, split = b / (P.tiles_k * P.tiles_n);
+  const int n0 = tn * TN_T, k0 = tk * TN_T;
+  const float* A = P.A + (size_t)blockIdx.y * P.batchA;
+  const float* B = P.B + (size_t)blockIdx.y * P.batchB;
+
+  const float sA = tn_tensor_scale(P.a_rows, P.M, red);
+  const float sB = tn_tensor_scale(P.b_rows, P.M, red);
+
+  // staging map: column c of the tile, rows 8 o .. 8 o + 7 of the step.  Buffer loads: a row past M is past the resource's extent and
+  // reads as zero (it enters the contraction: it must), a column past N / K reads whatever lies there -- it only feeds output rows /
+  // columns that are not stored -- and nothing is guarded (hipcc turns a guarded load into a branch with a full wait behind it).
+  // The per-thread byte offset is loop-invariant; the row of the step rides on the scalar offset.
+  const int c = tid & 127, o = tid >> 7;
+  const auto ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (unsigned)(((size_t)(P.M - 1) * P.lda + P.N) * 4), 0x00020000);
+  const auto br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (unsigned)(((size_t)(P.M - 1) * P.ldb + P.K) * 4), 0x00020000);
+  const int step0 = split * P.steps_per_split;
+  const int nsteps = max(0, min(P.steps_per_split, (P.M + TN_MS - 1) / TN_MS - step0));
+  const unsigned a_voff = (unsigned)(((step0 * TN_MS + 8 * o) * P.lda + n0 + c) * 4);
+  const unsigned b_voff = (unsigned)(((step0 * TN_MS + 8 * o) * P.ldb + k0 + c) * 4);
+  const int st_off = c * LDR + ((o ^ tn_swz(c)) << 3);
+
+  // One staging register set, issued one step ahead.  (Measured and dropped: a second set issued two steps ahead with counted
+  // vmcnt waits -- a lone workgroup stays at 1.3 us per step either way: like the NT form the step is the MFMA phase (~1 900 cycles
+  // for 192 MFMAs) plus the split / commit phase (~1 300) between two barriers, not the loads' latency; what overlaps the two is the
+  // CU's second workgroup.)
+  float av[8], bv[8];
+  auto issue = [&](int step) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      av[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, a_voff, (step * TN_MS + e) * P.lda * 4, 0));
+      bv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, b_voff, (step * TN_MS + e) * P.ldb * 4, 0));
+    }
+  };
+  // (the bias gradient of the same linear is the column sum of A = dY: the workgroups of the first k-tile column add up what they
+  // stage anyway -- thread (c, o) owns column c, rows 8 o .. 8 o + 7 of every step)
+  const bool want_cs = P.colsum != nullptr && tk == 0;
+  float asum = 0.f;
+  auto commit_a = [&](_Float16* buf) {
+    if (want_cs) asum += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+    const Split8 sa = split8h(make_float4(av[0], av[1], av[2], av[3]), make_float4(av[4], av[5], av[6], av[7]), sA);
+    *reinterpret_cast<u32x4*>(buf + st_off) = sa.hi;
+    *reinterpret_cast<u32x4*>(buf + TN_T * LDR + st_off) = sa.lo;
+  };
+  auto commit_b = [&](_Float16* buf) {
+    const Split8 sb = split8h(make_float4(bv[0], bv[1], bv[2], bv[3]), make_float4(bv[4], bv[5], bv[6], bv[7]), sB);
+    *reinterpret_cast<u32x4*>(buf + 2 * TN_T * LDR + st_off) = sb.hi;
+    *reinterpret_cast<u32x4*>(buf + 3 * TN_T * LDR + st_off) = sb.lo;
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
+
+  if (nsteps > 0) {
+    issue(0);
+    commit_a(lds);
+    commit_b(lds);
+    if (nsteps > 1) issue(1);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("" : "+v"(tid));                      // (keeps the loop-invariant LDS addresses from being hoisted into registers)
+    const int ln = tid & 63, qq = ln >> 4, nn = ln & 15;
+    const bool more = s + 1 < nsteps;
+    const _Float16* cur = lds + (s & 1) * BUF;
+    _Float16* nxt = lds + ((s + 1) & 1) * BUF;
+    const int fsl = (qq ^ tn_swz(nn)) << 3;            // (tile rows are 16 mi + nn: the swizzle only depends on nn)
+    const _Float16* la = cur + (64 * wr + nn) * LDR + fsl;
+    const _Float16* lb = cur + 2 * TN_T * LDR + (32 * wc + nn) * LDR + fsl;
+    u32x4 bh[2], bl[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      bh[ni] = *reinterpret_cast<const u32x4*>(lb + 16 * ni * LDR);
+      bl[ni] = *reinterpret_cast<const u32x4*>(lb + TN_T * LDR + 16 * ni * LDR);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const u32x4 ah = *reinterpret_cast<const u32x4*>(la + 16 * mi * LDR);
+      const u32x4 al = *reinterpret_cast<const u32x4*>(la + TN_T * LDR + 16 * mi * LDR);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_h3(ah, al, bh[ni], bl[ni], acc[mi][ni]);
+      // the next step's tile (its raw values arrived during the previous step) is split and stored into the OTHER buffer while
+      // this step's MFMAs run: A behind the first MFMA group, B behind the third
+      if (more && mi == 0) { __builtin_amdgcn_sched_barrier(0); commit_a(nxt); __builtin_amdgcn_sched_barrier(0); }
+      if (more && mi == 2) { __builtin_amdgcn_sched_barrier(0); commit_b(nxt); __builtin_amdgcn_sched_barrier(0); }
+    }
+    if (s + 2 < nsteps) issue(s + 2);
+    __syncthreads();                                   // the other buffer is complete; every wave is done reading this one
+  }
+
+  // epilogue: lane (q, i16) holds rows 4 q + r (n), column i16 (k) of every 16 x 16 tile
+  const float inv = inv_pow2(sA) * inv_pow2(sB);
+  float* out;
+  int ldo;
+  if (P.splits > 1) {
+    out = P.slabs + (size_t)blockIdx.y * P.batchS + (size_t)split * P.N * P.K;
+    ldo = P.K;
+  } else {
+    out = P.C + (size_t)blockIdx.y * P.batchC;
+    ldo = P.ldc;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = k0 + 32 * wc + 16 * ni + i16;
+      if (col >= P.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 64 * wr + 16 * mi + 4 * q + r;
+        if (row < P.N) {
+          float* p = out + (size_t)row * ldo + col;
+          const float v = acc[mi][ni][r] * inv;
+          *p = (P.splits == 1 && P.accumulate) ? *p + v : v;
+        }
+      }
+    }
+  if (want_cs) {                                       // (wave-uniform; the loop's last barrier is behind every LDS read)
+    float* r = reinterpret_cast<float*>(lds);
+    r[o * TN_T + c] = asum;
+    __syncthreads();
+    if (tid < TN_T && n0 + tid < P.N) {
+      const float v = (r[tid] + r[TN_T + tid]) + (r[2 * TN_T + tid] + r[3 * TN_T + tid]);
+      if (P.splits > 1) P.cs_slabs[(size_t)split * P.N + n0 + tid] = v;
+      else P.colsum[n0 + tid] = v;
+    }
+  }
+}
+
 // C[n][k] (+)= slab 0 + slab 1 + ... (index order)
 __global__ __launch_bounds__(256) void gemm_tn_sum_kernel(const float* __restrict__ slabs, int splits, long long batchS, float* __restrict__ C,
                                                           int ldc, long long batchC, int N, int K, int accumulate,
@@ -271,7 +419,11 @@ extern "C" int hopmi_gemm_f16x2_tn_cs(const float* A, int lda, long long batch_s
   }
   P.colsum = a_colsum;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gemm_f16_tn_kernel, dim3(P.tiles_n * P.tiles_k * P.splits, batch), dim3(TN_THREADS), 0, st, P);
+  // HOPMI_GEMM_TN_DB: 1 = the double-buffered form (round 6), 0 = the single-buffer form
+  if (env_int("HOPMI_GEMM_TN_DB", 1) == 1)
+    hipLaunchKernelGGL(gemm_f16_tn_db_kernel, dim3(P.tiles_n * P.tiles_k * P.splits, batch), dim3(TN_THREADS), 0, st, P);
+  else
+    hipLaunchKernelGGL(gemm_f16_tn_kernel, dim3(P.tiles_n * P.tiles_k * P.splits, batch), dim3(TN_THREADS), 0, st, P);
   if (int e = check_launch("hopmi_gemm_f16x2_tn")) return e;
   if (P.splits > 1) {
     hipLaunchKernelGGL(gemm_tn_sum_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256), batch), dim3(256), 0, st, P.slabs, P.splits, P.batchS,
