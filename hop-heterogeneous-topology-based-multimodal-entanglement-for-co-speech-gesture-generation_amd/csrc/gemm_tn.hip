@@ -420,7 +420,11 @@ extern "C" int hopmi_gemm_f16x2_tn_cs(const float* A, int lda, long long batch_s
   P.colsum = a_colsum;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // HOPMI_GEMM_TN_DB: 1 = the double-buffered form (round 6), 0 = the single-buffer form
-  if (env_int("HOPMI_GEMM_TN_DB", 1) == 1)
+  // (also built and measured in round 6, then removed: the same form with 16-byte loads -- threads 0-255 staging A, 256-511 B, four
+  // float4 loads and eight 8-byte LDS stores per thread and step instead of sixteen 4-byte loads and four 16-byte stores --
+  // bit-identical products, 128.0 against 127.1 us at the GRU shape, nothing in the step: the vector-memory instruction count is
+  // not what bounds this kernel; profiles/r06_bench_tn.txt)
+  if (env_int("HOPMI_GEMM_TN_DB", 1) >= 1)
     hipLaunchKernelGGL(gemm_f16_tn_db_kernel, dim3(P.tiles_n * P.tiles_k * P.splits, batch), dim3(TN_THREADS), 0, st, P);
   else
     hipLaunchKernelGGL(gemm_f16_tn_kernel, dim3(P.tiles_n * P.tiles_k * P.splits, batch), dim3(TN_THREADS), 0, st, P);
