@@ -148,7 +148,12 @@ def roofline(ks, V, B, n_kernel_steps, dtype="fp32"):
                     "wn_layer_fwd_kernel (fused WaveNet layer incl. the gwnet graph conv: BN-on-load, gated TCN, skip tail, "
                     "node mix, graph conv, residual, BN statistics); the 8 layer launches of every training forward"),
          "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-         "traffic": traffic, "launches": gf["launches"], "avg_us": 1e3 * gf["kernel_ms"] / gf["launches"],
+         "traffic": traffic,
+         "traffic_source": (None if traffic is None else
+                            f"profiles/{PROFILE_ROUND}_traffic.json: HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this tree "
+                            "on an MI355X (tools/profile_round.sh; corrected as MI355X_MICROARCH.md prescribes) -- a COMMITTED measurement, not one "
+                            "taken inside this run: bench.py cannot run the profiler on itself"),
+         "launches": gf["launches"], "avg_us": 1e3 * gf["kernel_ms"] / gf["launches"],
          "algorithmic_bytes_per_launch": gf["bytes"] / gf["launches"],
          "bytes_definition": ("SURVEY.md 8(d), fused layers, summed over the 8 layers of the launch: 4 B x 64 ch x V x (B*T_in read + "
                               "B*T_out written (not the dead last layer's) + 4*B skip-tail frames)" if stack else

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--tag", default="default")
     ap.add_argument("--every", type=int, default=1, help="census every n-th step")
     ap.add_argument("--lr", type=float, default=None)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     args = ap.parse_args()
     import torch
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
@@ -37,6 +38,7 @@ def main():
     torch.cuda.set_device(dev)
     V = 9 if args.dataset == "TED" else 42
     B = args.batch
+    hopmi.mixed_precision(None if args.dtype == "fp32" else args.dtype)
     hopmi.gemm_parts({"library": 0, "f16x2": 16, "split3": 3, "split2": 2}[args.bert_gemm])
     hopmi.use_tuned_gemms(None)
     torch.manual_seed(0)
@@ -52,7 +54,8 @@ def main():
     sargs = synth.step_args(args.dataset)
     batch = synth.synthetic_batch(B, V, 1234, dev)
     inputs = (batch["in_audio"], batch["log_melspec"], batch["text"], batch["target_dir_vec"], batch["vid_indices"])
-    graphed = hopmi.GraphedTrainStep(sargs, model, disc, g_opt, d_opt, eager_calls=1, enabled=not args.eager)
+    graphed = hopmi.GraphedTrainStep(sargs, model, disc, g_opt, d_opt, eager_calls=1, enabled=not args.eager,
+                                     grad_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     diag = ops.split_status(reset=True) is not None   # diagnostic library (HOPMI_LIB=.../libhopmi_dbg.so): registers the status buffer
     split_reports = []

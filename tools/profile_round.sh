@@ -7,7 +7,7 @@
 #   5./6./7. kernel-trace + stats of the bf16 (configs[2] per GPU), TED-Expressive (configs[3]) and GAN-phase workloads
 # Raw output goes to gpurun_out/prof_*; tools/summarize_profiles.py turns it into profiles/<tag>_*.{csv,json}.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 REPO=$(pwd)
 mkdir -p gpurun_out
