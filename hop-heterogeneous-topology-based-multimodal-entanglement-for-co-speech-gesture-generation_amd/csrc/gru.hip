@@ -525,26 +525,31 @@ __device__ __forceinline__ void load_resident_w(u32x4 (&wh)[3][MAXK2], u32x4 (&w
 }
 
 // KP = 128 MAXK2 >= H: K padded so that each of the 4 K quarters is MAXK2 MFMA steps of 32.
-// 8 waves: wave w owns K quarter (w & 3) of unit half (w >> 2); the gate epilogue is one element per thread.
-template <int MAXK2, typename TG>
+// 8 waves: wave w owns K quarter (w & 3) of unit half (w >> 2); the gate epilogue is one element per thread and row tile.
+// MR = 16-row tiles per workgroup (round 6).  MR = 1 is the kernel of rounds 2-5.  MR = 2 (32 batch rows per workgroup, the same
+// resident weight fragments serve both tiles) is for a batch that would need more workgroups than the chip holds at 16 rows --
+// the decoder of a training step's TWO generator forwards run as one launch of 2 B rows (ops.gru_bidirectional_pair: same
+// weights; a time step is a hand-off round trip of ~2 us around ~0.5 us of arithmetic, so the second tile rides nearly free).
+template <int MAXK2, typename TG, int MR = 1>
 __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __restrict__ gi, const float* __restrict__ whh,
                                                                  const float* __restrict__ bhh, float* y,
                                                                  float* __restrict__ gates, int* status, int B, int T,
                                                                  int H, int nJ, int nbb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KP = 128 * MAXK2, WS2 = (KP + 48) / 2;                 // 32-bit words per LDS row: 16-byte reads conflict-free
-  unsigned* Ahi = reinterpret_cast<unsigned*>(smem);                   // [16][WS2]  h_prev rows, bf16 hi parts
-  unsigned* Alo = Ahi + GP_BM * WS2;                                   //            ... lo parts
-  float* red = reinterpret_cast<float*>(Alo + GP_BM * WS2);            // [4 K quarters][16][GP_RED_F]
+  constexpr int BMR = GP_BM * MR;                                      // batch rows per workgroup
+  unsigned* Ahi = reinterpret_cast<unsigned*>(smem);                   // [16 MR][WS2]  h_prev rows, fp16 hi parts
+  unsigned* Alo = Ahi + BMR * WS2;                                     //               ... lo parts
+  float* red = reinterpret_cast<float*>(Alo + BMR * WS2);              // [4 K quarters][16 MR][GP_RED_F]
   const GpWork wk = gp_decode(nJ, nbb);
   if (!wk.valid) return;
   const int d = wk.d, bb = wk.bb, jb = wk.jb;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, i = lane & 15;
   const int kq = w & 3, ch = w >> 2;
-  const int j0 = jb * GP_NU, b0 = bb * GP_BM;
+  const int j0 = jb * GP_NU, b0 = bb * BMR;
   const size_t ystride = (size_t)2 * H;
   const int jj = tid & 31, j = j0 + jj, jc = min(j, H - 1);
-  const int row = tid >> 5, b = b0 + row, bc = min(b, B - 1);           // the thread's element in the gate epilogue
+  const int row = tid >> 5;                                            // the thread's elements in the gate epilogue: rows row + 16 mr
 
   u32x4 wh[3][MAXK2], wl[3][MAXK2];                                    // resident W_hh fragments of this wave
   float e_inv[3];                                                      // accumulator -> gh of the EPILOGUE element's unit: (1 / s_W[g][unit]) 2^-14
@@ -566,69 +571,84 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __res
   float e_bhh[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) e_bhh[g] = bhh[(d * 3 + g) * H + jc];
-  float h_own = 0.f;                                                   // this thread's h_{t-1}[b][j]
+  float h_own[MR];                                                     // this thread's h_{t-1}[b][j], one per row tile
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) h_own[mr] = 0.f;
   bool dead = false;
 
   for (int s = 0; s < T; ++s) {
     const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
     GRU_STAMP(0);
-    float e_gi[3];
-    {
+    float e_gi[MR][3];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      const int bc = min(b0 + row + GP_BM * mr, B - 1);
       const TG* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
 #pragma unroll
-      for (int g = 0; g < 3; ++g) e_gi[g] = (float)gip[g * H];
+      for (int g = 0; g < 3; ++g) e_gi[mr][g] = (float)gip[g * H];
     }
     if (s > 0) {
-      float2 v[2][MAXK2];                                              // wave w stages rows w and w + 8
-      poll_segments<2, MAXK2>(v, [&](int m) -> const float* {
+      float2 v[2 * MR][MAXK2];                                         // wave w stages rows w + 8 m
+      poll_segments<2 * MR, MAXK2>(v, [&](int m) -> const float* {
         const int br = b0 + w + 8 * m;
         return br < B ? y + ((size_t)br * T + tp) * ystride + d * H : nullptr;
       }, H, lane, dead, status);
       GRU_STAMP(1);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane, H_UNIT_SCALE);   // |h| <= 1
+      for (int m = 0; m < 2 * MR; ++m) commit_split_row<MAXK2>(Ahi, Alo, WS2, w + 8 * m, v[m], lane, H_UNIT_SCALE);   // |h| <= 1
       __syncthreads();
       GRU_STAMP(2);
-      f32x4 acc[3];
+      f32x4 acc[MR][3];
 #pragma unroll
-      for (int g = 0; g < 3; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+      for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[mr][g] = {0.f, 0.f, 0.f, 0.f};
       const unsigned* ahp = Ahi + i * WS2 + 4 * q + kq * MAXK2 * 16;
       const unsigned* alp = Alo + i * WS2 + 4 * q + kq * MAXK2 * 16;
 #pragma unroll
       for (int kk = 0; kk < MAXK2; ++kk) {
-        const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + 16 * kk);
-        const u32x4 al = *reinterpret_cast<const u32x4*>(alp + 16 * kk);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = mfma_h3(ah, al, wh[g][kk], wl[g][kk], acc[g]);
+        for (int mr = 0; mr < MR; ++mr) {
+          const u32x4 ah = *reinterpret_cast<const u32x4*>(ahp + GP_BM * mr * WS2 + 16 * kk);
+          const u32x4 al = *reinterpret_cast<const u32x4*>(alp + GP_BM * mr * WS2 + 16 * kk);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[mr][g] = mfma_h3(ah, al, wh[g][kk], wl[g][kk], acc[mr][g]);
+        }
       }
       GRU_STAMP(3);
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+      for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(kq * GP_BM + 4 * q + r) * GP_RED_F + 32 * g + 16 * ch + i] = acc[g][r];
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(kq * BMR + GP_BM * mr + 4 * q + r) * GP_RED_F + 32 * g + 16 * ch + i] = acc[mr][g][r];
       __syncthreads();
       GRU_STAMP(4);
     }
-    if (b < B && j < H) {
-      float gh[3];
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        float a = e_bhh[g];
-        if (s > 0) {
-          float p = 0.f;
+    for (int mr = 0; mr < MR; ++mr) {
+      const int rw = row + GP_BM * mr, b = b0 + rw;
+      if (b < B && j < H) {
+        float gh[3];
 #pragma unroll
-          for (int ww = 0; ww < 4; ++ww) p += red[(ww * GP_BM + row) * GP_RED_F + 32 * g + jj];
-          a += p * e_inv[g];
+        for (int g = 0; g < 3; ++g) {
+          float a = e_bhh[g];
+          if (s > 0) {
+            float p = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) p += red[(ww * BMR + rw) * GP_RED_F + 32 * g + jj];
+            a += p * e_inv[g];
+          }
+          gh[g] = a;
         }
-        gh[g] = a;
+        const float r = sigmoidf_(e_gi[mr][0] + gh[0]);
+        const float z = sigmoidf_(e_gi[mr][1] + gh[1]);
+        const float n = tanhf_(e_gi[mr][2] + r * gh[2]);
+        h_own[mr] = (1.f - z) * n + z * h_own[mr];
+        st_sc1_f(y + ((size_t)b * T + t) * ystride + d * H + j, h_own[mr]);   // handed off: write-through
+        float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
+        gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = gh[2];
       }
-      const float r = sigmoidf_(e_gi[0] + gh[0]);
-      const float z = sigmoidf_(e_gi[1] + gh[1]);
-      const float n = tanhf_(e_gi[2] + r * gh[2]);
-      h_own = (1.f - z) * n + z * h_own;
-      st_sc1_f(y + ((size_t)b * T + t) * ystride + d * H + j, h_own);   // handed off: write-through
-      float* gp = gates + (((size_t)b * T + t) * 2 + d) * 4 * H + j;
-      gp[0] = r; gp[H] = z; gp[2 * H] = n; gp[3 * H] = gh[2];
     }
     GRU_STAMP(5);
     // no trailing barrier: the next step's panel commit follows this step's second barrier (all MFMA reads done), and its
@@ -1089,12 +1109,15 @@ static int gru_resident_capacity(const void* fn, size_t lds) {
   return cap;
 }
 
-template <bool FWD, typename TG>
+template <bool FWD, typename TG, int MR = 1>
 static int gru_persistent_capacity(int H) {
   const int mk = (H + 127) / 128;
 #define HOPMI_GP_CAP(MK_)                                                                                                    \
   {                                                                                                                          \
     constexpr int WS2 = (128 * MK_ + 48) / 2;                                                                                \
+    if (FWD && MR == 2)                                                                                                      \
+      return gru_resident_capacity(reinterpret_cast<const void*>(&gru_fwd_persistent_kernel<MK_, TG, 2>),                     \
+                                   (size_t)2 * 2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * 2 * GP_BM * GP_RED_F * sizeof(float));  \
     if (FWD)                                                                                                                 \
       return gru_resident_capacity(reinterpret_cast<const void*>(&gru_fwd_persistent_kernel<MK_, TG>),                        \
                                    (size_t)2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_F * sizeof(float));  \
@@ -1115,6 +1138,12 @@ static bool gru_persistent_ok(int B, int H, const void* ws) {
   const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + GP_BM - 1) / GP_BM;
   return ws != nullptr && gp_grid(nJ, nbb) <= gru_persistent_capacity<FWD, TG>(H);
 }
+// the forward's 32-row form (MR = 2): for a batch whose 16-row tiling does not fit the chip
+template <typename TG>
+static bool gru_persistent_ok_mr2(int B, int H, const void* ws) {
+  const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + 2 * GP_BM - 1) / (2 * GP_BM);
+  return ws != nullptr && env_int("HOPMI_GRU_MR2", 1) != 0 && gp_grid(nJ, nbb) <= gru_persistent_capacity<true, TG, 2>(H);
+}
 
 extern "C" size_t hopmi_gru_ws_bytes(int B, int T, int H) {
   if (B <= 0 || T <= 0 || H <= 0) return 0;
@@ -1125,12 +1154,19 @@ static int* gru_status_word(void* ws, int B, int T, int H) {
   return static_cast<int*>(ws) + hopmi_gru_ws_bytes(B, T, H) / sizeof(int) - 16;
 }
 
-template <int MAXK2, typename TG>
+template <int MAXK2, typename TG, int MR = 1>
 static void launch_gru_fwd_persistent(int grid, hipStream_t st, const TG* gi, const float* whh, const float* bhh, float* y,
                                       float* gates, int* status, int B, int T, int H, int nJ, int nbb) {
   constexpr int WS2 = (128 * MAXK2 + 48) / 2;
-  const size_t lds = (size_t)2 * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * GP_BM * GP_RED_F * sizeof(float);
-  hipLaunchKernelGGL((gru_fwd_persistent_kernel<MAXK2, TG>), dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, status, B, T, H,
+  const size_t lds = (size_t)2 * MR * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * MR * GP_BM * GP_RED_F * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent_kernel<MAXK2, TG, MR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gru_fwd_persistent_kernel<MAXK2, TG, MR>), dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, status, B, T, H,
                      nJ, nbb);
 }
 
@@ -1156,6 +1192,18 @@ static int gru_fwd_impl(const TG* gi, const float* whh, const float* bhh, float*
       default: launch_gru_fwd_persistent<3, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
     }
     return check_launch("hopmi_gru_fwd(persistent)");
+  }
+  if (gru_persistent_ok_mr2<TG>(B, H, ws)) {                           // 32 batch rows per workgroup (round 6)
+    const int nJ = (H + GP_NU - 1) / GP_NU, nbb = (B + 2 * GP_BM - 1) / (2 * GP_BM);
+    int* status = gru_status_word(ws, B, T, H);
+    gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), y, (size_t)B * T * 2 * H, st);
+    const int grid = gp_grid(nJ, nbb);
+    switch ((H + 127) / 128) {
+      case 1: launch_gru_fwd_persistent<1, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      case 2: launch_gru_fwd_persistent<2, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      default: launch_gru_fwd_persistent<3, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+    }
+    return check_launch("hopmi_gru_fwd(persistent, 32 rows)");
   }
   if (ws != nullptr) gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), nullptr, 0, st);                        // status = 0
   const int nJ = (H + GRU_NU - 1) / GRU_NU, nbb = (B + GRU_BM - 1) / GRU_BM;
