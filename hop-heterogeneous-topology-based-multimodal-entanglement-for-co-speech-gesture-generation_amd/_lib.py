@@ -104,6 +104,7 @@ SIGNATURES = {
     "hopmi_gru_ws_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "hopmi_gru_fwd": (_I, [_VP] * 6 + [_I, _I, _I, _VP]),
     "hopmi_gru_fwd_dt": (_I, [_VP, _I] + [_VP] * 5 + [_I, _I, _I, _VP]),
+    "hopmi_gru_fwd_pair_dt": (_I, [_VP, _VP, _I, _I] + [_VP] * 5 + [_I, _I, _I, _VP]),
     "hopmi_gru_bwd_dt": (_I, [_VP] * 5 + [_I] + [_VP] * 3 + [_I, _I, _I, _VP]),
     "hopmi_gru_bwd_operands": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "hopmi_gru_bwd_ws_floats": (ctypes.c_size_t, [_I, _I]),

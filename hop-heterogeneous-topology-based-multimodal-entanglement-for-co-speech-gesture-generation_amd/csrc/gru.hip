@@ -534,7 +534,9 @@ template <int MAXK2, typename TG, int MR = 1>
 __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __restrict__ gi, const float* __restrict__ whh,
                                                                  const float* __restrict__ bhh, float* y,
                                                                  float* __restrict__ gates, int* status, int B, int T,
-                                                                 int H, int nJ, int nbb) {
+                                                                 int H, int nJ, int nbb, const TG* __restrict__ gi2, int B1) {
+  // (gi2 / B1: batch rows >= B1 take their input projections from gi2[row - B1] -- hopmi_gru_fwd_pair_dt: two forwards' decoder
+  // inputs that live in two tensors; a plain call passes B1 = B)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KP = 128 * MAXK2, WS2 = (KP + 48) / 2;                 // 32-bit words per LDS row: 16-byte reads conflict-free
   constexpr int BMR = GP_BM * MR;                                      // batch rows per workgroup
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(512) void gru_fwd_persistent_kernel(const TG* __res
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
       const int bc = min(b0 + row + GP_BM * mr, B - 1);
-      const TG* gip = gi + (((size_t)bc * T + t) * 2 + d) * 3 * H + jc;
+      const TG* gip = (bc < B1 ? gi + (size_t)bc * T * 6 * H : gi2 + (size_t)(bc - B1) * T * 6 * H) + ((size_t)t * 2 + d) * 3 * H + jc;
 #pragma unroll
       for (int g = 0; g < 3; ++g) e_gi[mr][g] = (float)gip[g * H];
     }
@@ -1156,7 +1158,7 @@ static int* gru_status_word(void* ws, int B, int T, int H) {
 
 template <int MAXK2, typename TG, int MR = 1>
 static void launch_gru_fwd_persistent(int grid, hipStream_t st, const TG* gi, const float* whh, const float* bhh, float* y,
-                                      float* gates, int* status, int B, int T, int H, int nJ, int nbb) {
+                                      float* gates, int* status, int B, int T, int H, int nJ, int nbb, const TG* gi2, int B1) {
   constexpr int WS2 = (128 * MAXK2 + 48) / 2;
   const size_t lds = (size_t)2 * MR * GP_BM * WS2 * sizeof(unsigned) + (size_t)4 * MR * GP_BM * GP_RED_F * sizeof(float);
   static bool attr_done = false;
@@ -1167,15 +1169,23 @@ static void launch_gru_fwd_persistent(int grid, hipStream_t st, const TG* gi, co
     attr_done = true;
   }
   hipLaunchKernelGGL((gru_fwd_persistent_kernel<MAXK2, TG, MR>), dim3(grid), dim3(512), lds, st, gi, whh, bhh, y, gates, status, B, T, H,
-                     nJ, nbb);
+                     nJ, nbb, gi2, B1);
 }
 
 template <typename TG>
 static int gru_fwd_impl(const TG* gi, const float* whh, const float* bhh, float* y, float* gates, void* ws, int B, int T, int H,
-                        void* stream) {
+                        void* stream, const TG* gi2 = nullptr, int B1 = -1) {
   const void* ptrs[] = {gi, whh, bhh, y, gates};
   if (int e = gru_validate(ptrs, 5, B, T, H)) return e;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool pair = gi2 != nullptr;
+  if (!pair) { gi2 = gi; B1 = B; }
+  if (pair && (B1 < 1 || B1 >= B)) { set_error("hopmi_gru_fwd_pair: B1=%d must lie inside (0, B=%d)", B1, B); return HOPMI_EINVAL; }
+  // a pair that cannot run as ONE persistent launch runs as two plain calls (the forms below read one gi tensor)
+  if (pair && !((H != GS_H || env_int("HOPMI_GRU_SMALL", 1) == 0) && (gru_persistent_ok<true, TG>(B, H, ws) || gru_persistent_ok_mr2<TG>(B, H, ws)))) {
+    if (int e = gru_fwd_impl<TG>(gi, whh, bhh, y, gates, ws, B1, T, H, stream)) return e;
+    return gru_fwd_impl<TG>(gi2, whh, bhh, y + (size_t)B1 * T * 2 * H, gates + (size_t)B1 * T * 2 * 4 * H, ws, B - B1, T, H, stream);
+  }
   if (H == GS_H && env_int("HOPMI_GRU_SMALL", 1) != 0) {               // one workgroup per (16 rows, direction): no hand-off
     if (ws != nullptr) gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), nullptr, 0, st);                      // status = 0
     hipLaunchKernelGGL((gru_fwd_small_kernel<TG>), dim3(2 * ((B + 15) / 16)), dim3(256), 0, st, gi, whh, bhh, y, gates, B, T);
@@ -1187,9 +1197,9 @@ static int gru_fwd_impl(const TG* gi, const float* whh, const float* bhh, float*
     gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), y, (size_t)B * T * 2 * H, st);
     const int grid = gp_grid(nJ, nbb);
     switch ((H + 127) / 128) {
-      case 1: launch_gru_fwd_persistent<1, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
-      case 2: launch_gru_fwd_persistent<2, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
-      default: launch_gru_fwd_persistent<3, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      case 1: launch_gru_fwd_persistent<1, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb, gi2, B1); break;
+      case 2: launch_gru_fwd_persistent<2, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb, gi2, B1); break;
+      default: launch_gru_fwd_persistent<3, TG>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb, gi2, B1); break;
     }
     return check_launch("hopmi_gru_fwd(persistent)");
   }
@@ -1199,9 +1209,9 @@ static int gru_fwd_impl(const TG* gi, const float* whh, const float* bhh, float*
     gru_prepare(ws, hopmi_gru_ws_bytes(B, T, H), y, (size_t)B * T * 2 * H, st);
     const int grid = gp_grid(nJ, nbb);
     switch ((H + 127) / 128) {
-      case 1: launch_gru_fwd_persistent<1, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
-      case 2: launch_gru_fwd_persistent<2, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
-      default: launch_gru_fwd_persistent<3, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb); break;
+      case 1: launch_gru_fwd_persistent<1, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb, gi2, B1); break;
+      case 2: launch_gru_fwd_persistent<2, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb, gi2, B1); break;
+      default: launch_gru_fwd_persistent<3, TG, 2>(grid, st, gi, whh, bhh, y, gates, status, B, T, H, nJ, nbb, gi2, B1); break;
     }
     return check_launch("hopmi_gru_fwd(persistent, 32 rows)");
   }
@@ -1224,6 +1234,16 @@ extern "C" int hopmi_gru_fwd_dt(const void* gi, int gi_dtype, const float* whh, 
   if (gi_dtype == 1) return gru_fwd_impl(static_cast<const __bf16*>(gi), whh, bhh, y, gates, ws, B, T, H, stream);
   if (gi_dtype == 0) return gru_fwd_impl(static_cast<const float*>(gi), whh, bhh, y, gates, ws, B, T, H, stream);
   set_error("hopmi_gru_fwd_dt: gi_dtype %d (0 = fp32, 1 = bf16)", gi_dtype);
+  return HOPMI_EINVAL;
+}
+
+extern "C" int hopmi_gru_fwd_pair_dt(const void* gi1, const void* gi2, int B1, int gi_dtype, const float* whh, const float* bhh, float* y,
+                                     float* gates, void* ws, int B, int T, int H, void* stream) {
+  if (!gi2) { set_error("hopmi_gru_fwd_pair_dt: null gi2"); return HOPMI_EINVAL; }
+  if (gi_dtype == 1)
+    return gru_fwd_impl(static_cast<const __bf16*>(gi1), whh, bhh, y, gates, ws, B, T, H, stream, static_cast<const __bf16*>(gi2), B1);
+  if (gi_dtype == 0) return gru_fwd_impl(static_cast<const float*>(gi1), whh, bhh, y, gates, ws, B, T, H, stream, static_cast<const float*>(gi2), B1);
+  set_error("hopmi_gru_fwd_pair_dt: gi_dtype %d (0 = fp32, 1 = bf16)", gi_dtype);
   return HOPMI_EINVAL;
 }
 

@@ -310,7 +310,8 @@ class Model(nn.Module):
             return self._bert_fast(inputs_embeds)
         return self.llm_model(inputs_embeds=inputs_embeds).last_hidden_state
 
-    def forecast(self, in_audio, x_enc, text, pre_seq, vid_indices):
+    def _decoder_input(self, in_audio, x_enc, text, pre_seq, vid_indices):
+        """HOP.py:184-247: everything in front of the pose decoder -> (dec_in (B,34,in), z_context, z_mu, z_logvar)."""
         B = pre_seq.shape[0]
         V = pre_seq.shape[2] // 3
         z_mu = z_logvar = z_context = None
@@ -348,6 +349,31 @@ class Model(nn.Module):
         # (ops.cut_point: the identity, except under a recording with an overlapped gradient exchange -- the decoder's input and
         # the two VAE outputs the KLD term reads are where the backward is cut in two)
         dec_in = ops.cut_point(torch.cat(parts, dim=2).to(torch.float32).contiguous())
-        dec_out = ops.gru_bidirectional(dec_in, self.gru)                       # HOP.py:248 (h0 = 0)
+        return dec_in, z_context, ops.cut_point(z_mu), ops.cut_point(z_logvar)
+
+    def _head(self, dec_out):
         dec_out = dec_out[:, :, :self.hidden_size] + dec_out[:, :, self.hidden_size:]
-        return self.out(dec_out), z_context, ops.cut_point(z_mu), ops.cut_point(z_logvar)
+        return self.out(dec_out)
+
+    def forecast(self, in_audio, x_enc, text, pre_seq, vid_indices):
+        dec_in, z_context, z_mu, z_logvar = self._decoder_input(in_audio, x_enc, text, pre_seq, vid_indices)
+        dec_out = ops.gru_bidirectional(dec_in, self.gru)                       # HOP.py:248 (h0 = 0)
+        return self._head(dec_out), z_context, z_mu, z_logvar
+
+    def forward_pair(self, in_audio, x_enc, text, pre_seq, vid_indices, second_vids):
+        """The two generator forwards of a train_llm generator step (train_llm.py:42 and :58: the graded one, and -- under no_grad,
+        on other speaker indices -- the diversity regulariser's) with the pose decoder's GRU run ONCE over both batches
+        (ops.gru_bidirectional_pair: same weights, one recurrence launch per layer instead of two).  `second_vids()` is called
+        between the two forwards' front parts, where train_llm draws its speaker permutation (the random streams keep their order:
+        reparameterisation noise of forward 1, the permutation, noise of forward 2; every dropout seed in the same order as two
+        `forward` calls, the decoder draws none).  Returns (outputs, z, z_mu, z_logvar), (out_rand, z_rand): values of two `forward`
+        calls at the fp32 class."""
+        dec_in1, z1, mu1, lv1 = self._decoder_input(in_audio, x_enc, text, pre_seq, vid_indices)
+        vids2 = second_vids()
+        with torch.no_grad():
+            dec_in2, z2, _, _ = self._decoder_input(in_audio, x_enc, text, pre_seq, vids2)
+        y1, y2 = ops.gru_bidirectional_pair(dec_in1, dec_in2, self.gru)
+        out1 = self._head(y1)
+        with torch.no_grad():
+            out2 = self._head(y2)
+        return (out1, z1, mu1, lv1), (out2, z2)

@@ -2130,47 +2130,122 @@ class _GruLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         y, gates, whh = ctx.saved_tensors
-        with torch.autocast("cuda", enabled=False):
-            dy = _dev_f32(dy.float(), "dy")
-            B, T, H2 = y.shape
-            H = H2 // 2
-            L, st = _lib.lib(), _stream()
-            # the recurrence's W_hh^T and the shifted states for dW_hh: one launch (was a transpose copy, a fill, two strided copies)
-            want_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-            whhT = torch.empty(2, H, 3 * H, dtype=torch.float32, device=y.device)
-            hprev = torch.empty(B, T, 2, H, dtype=torch.float32, device=y.device)
-            _lib.check(L.hopmi_gru_bwd_operands(y.data_ptr(), whh.data_ptr(), hprev.data_ptr(), whhT.data_ptr(), B, T, H, st),
-                       "hopmi_gru_bwd_operands")
-            dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.bfloat16 if ctx.typed else torch.float32, device=y.device)
-            dgh = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
-            ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
-            ws2 = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=y.device)
-                   if gru_persistent_allowed() else None)
-            _lib.check(_timed("gru_bwd", 0, 2 * T * B * 2 * 3 * H * H,
-                              lambda: L.hopmi_gru_bwd_dt(dy.data_ptr(), y.data_ptr(), gates.data_ptr(), whhT.data_ptr(),
-                                                         dgi.data_ptr(), 1 if ctx.typed else 0, dgh.data_ptr(), ws.data_ptr(), _ptr(ws2),
-                                                         B, T, H, st)),
-                       "hopmi_gru_bwd")
-            _track_status(ws2)
-            if GRU_CHECK_STATUS and ws2 is not None and not torch.cuda.is_current_stream_capturing() and int(ws2[-16].item()) != 0:
-                raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
-            # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
-            # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
-            if not want_dw:                    # (frozen recurrent weights, e.g. the discriminator inside the generator's step)
-                return dgi, None, None
-            M = B * T
-            dgh2, hp2 = dgh.view(M, 2, 3 * H).transpose(0, 1), hprev.view(M, 2, H).transpose(0, 1)       # (2, M, 3H) / (2, M, H) views
-            if f16_mm_tn_ok(dgh2, hp2) and (6 * H) % 4 == 0:
-                # the states are bounded by 1: a constant scale; dgh: one pass over the (M, 6H) rows, shared by the two directions
-                dwhh = f16_mm_tn(dgh2, hp2, row_scales(dgh.view(M, 6 * H)), unit_row_scales(M, y.device))
-            else:
-                dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
-            dbhh = colsum(dgh.view(B * T, 6 * H)).view(2, 3 * H)
-        return dgi, dwhh, dbhh
+        return _gru_layer_backward(y, gates, whh, dy, ctx.typed, ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+
+
+def _gru_layer_backward(y, gates, whh, dy, typed, want_dw):
+    """(dgi, dwhh, dbhh) of one bidirectional GRU layer's recurrence from its saved output and gates (hopmi_gru_bwd_dt): shared by
+    _GruLayerFn and _GruLayerPairFn (whose y / gates are the graded batch's leading rows of the pair's tensors)."""
+    with torch.autocast("cuda", enabled=False):
+        dy = _dev_f32(dy.float(), "dy")
+        B, T, H2 = y.shape
+        H = H2 // 2
+        L, st = _lib.lib(), _stream()
+        # the recurrence's W_hh^T and the shifted states for dW_hh: one launch (was a transpose copy, a fill, two strided copies)
+        whhT = torch.empty(2, H, 3 * H, dtype=torch.float32, device=y.device)
+        hprev = torch.empty(B, T, 2, H, dtype=torch.float32, device=y.device)
+        _lib.check(L.hopmi_gru_bwd_operands(y.data_ptr(), whh.data_ptr(), hprev.data_ptr(), whhT.data_ptr(), B, T, H, st),
+                   "hopmi_gru_bwd_operands")
+        dgi = torch.empty(B, T, 2, 3 * H, dtype=torch.bfloat16 if typed else torch.float32, device=y.device)
+        dgh = torch.empty(B, T, 2, 3 * H, dtype=torch.float32, device=y.device)
+        ws = torch.empty(L.hopmi_gru_bwd_ws_floats(B, H), dtype=torch.float32, device=y.device)
+        ws2 = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=y.device)
+               if gru_persistent_allowed() else None)
+        _lib.check(_timed("gru_bwd", 0, 2 * T * B * 2 * 3 * H * H,
+                          lambda: L.hopmi_gru_bwd_dt(dy.data_ptr(), y.data_ptr(), gates.data_ptr(), whhT.data_ptr(),
+                                                     dgi.data_ptr(), 1 if typed else 0, dgh.data_ptr(), ws.data_ptr(), _ptr(ws2),
+                                                     B, T, H, st)),
+                   "hopmi_gru_bwd")
+        _track_status(ws2)
+        if GRU_CHECK_STATUS and ws2 is not None and not torch.cuda.is_current_stream_capturing() and int(ws2[-16].item()) != 0:
+            raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out in the backward (status word set)")
+        # dW_hh[d] = sum_{b,t} dgh[b,t,d,:]^T h_prev[b,t,d,:]  with h_prev = y shifted one step along each
+        # direction's processing order (zero at its first step); db_hh = sum dgh.  Plain GEMMs.
+        if not want_dw:                    # (frozen recurrent weights, e.g. the discriminator inside the generator's step)
+            return dgi, None, None
+        M = B * T
+        dgh2, hp2 = dgh.view(M, 2, 3 * H).transpose(0, 1), hprev.view(M, 2, H).transpose(0, 1)       # (2, M, 3H) / (2, M, H) views
+        if f16_mm_tn_ok(dgh2, hp2) and (6 * H) % 4 == 0:
+            # the states are bounded by 1: a constant scale; dgh: one pass over the (M, 6H) rows, shared by the two directions
+            dwhh = f16_mm_tn(dgh2, hp2, row_scales(dgh.view(M, 6 * H)), unit_row_scales(M, y.device))
+        else:
+            dwhh = torch.einsum("btdg,btdh->dgh", dgh, hprev)
+        dbhh = colsum(dgh.view(B * T, 6 * H)).view(2, 3 * H)
+    return dgi, dwhh, dbhh
 
 
 def gru_layer(gi: torch.Tensor, whh: torch.Tensor, bhh: torch.Tensor) -> torch.Tensor:
     return _GruLayerFn.apply(gi, whh, bhh)
+
+
+class _GruLayerPairFn(torch.autograd.Function):
+    """One recurrence launch for TWO batches on the same weights (hopmi_gru_fwd_pair_dt): gi1 (B1,T,2,3H) takes gradients, gi2
+    (B2,T,2,3H) is the no-grad forward's (its output is marked non-differentiable).  The backward is _GruLayerFn's on the first B1
+    rows: y and gates are allocated whole, the graded batch is their leading (contiguous) part."""
+
+    @staticmethod
+    def forward(ctx, gi1, gi2, whh, bhh):
+        typed = gi1.dtype == torch.bfloat16
+        if gi2.dtype != gi1.dtype:
+            gi2 = gi2.to(gi1.dtype)
+        gi1 = _dev_bf16(gi1, "gi1") if typed else _dev_f32(gi1.float(), "gi1")
+        gi2 = _dev_bf16(gi2.detach(), "gi2") if typed else _dev_f32(gi2.detach().float(), "gi2")
+        whh, bhh = _dev_f32(whh.float(), "whh"), _dev_f32(bhh.float(), "bhh")
+        B1, T, two, H3 = gi1.shape
+        B2 = gi2.shape[0]
+        H = H3 // 3
+        if two != 2 or tuple(gi2.shape[1:]) != (T, 2, H3) or whh.shape != (2, 3 * H, H) or bhh.shape != (2, 3 * H):
+            raise _lib.HopmiError(f"hopmi gru pair: bad shapes gi1{tuple(gi1.shape)} gi2{tuple(gi2.shape)} whh{tuple(whh.shape)}")
+        B = B1 + B2
+        y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=gi1.device)
+        gates = torch.empty(B, T, 2, 4 * H, dtype=torch.float32, device=gi1.device)
+        L, st = _lib.lib(), _stream()
+        ws = (torch.empty(L.hopmi_gru_ws_bytes(B, T, H) // 4, dtype=torch.int32, device=gi1.device)
+              if gru_persistent_allowed() else None)
+        _lib.check(_timed("gru_fwd", 0, 2 * T * B * 2 * 3 * H * H,
+                          lambda: L.hopmi_gru_fwd_pair_dt(gi1.data_ptr(), gi2.data_ptr(), B1, 1 if typed else 0, whh.data_ptr(), bhh.data_ptr(),
+                                                          y.data_ptr(), gates.data_ptr(), _ptr(ws), B, T, H, st)), "hopmi_gru_fwd_pair")
+        _track_status(ws)
+        if GRU_CHECK_STATUS and ws is not None and not torch.cuda.is_current_stream_capturing() and int(ws[-16].item()) != 0:
+            raise _lib.HopmiError("hopmi gru: a persistent-kernel hand-off timed out (status word set)")
+        y1, y2 = y[:B1], y[B1:]
+        ctx.save_for_backward(y1, gates[:B1], whh)
+        ctx.typed = typed
+        ctx.mark_non_differentiable(y2)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy, _dy2=None):
+        y1, gates1, whh = ctx.saved_tensors
+        dgi, dwhh, dbhh = _gru_layer_backward(y1, gates1, whh, dy, ctx.typed, ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        return dgi, None, dwhh, dbhh
+
+
+GRU_PAIR = __import__("os").environ.get("HOPMI_GRU_PAIR", "1") != "0"
+
+
+def gru_bidirectional_pair(x1: torch.Tensor, x2: torch.Tensor, gru: torch.nn.GRU):
+    """gru_bidirectional of two batches on the same module with ONE recurrence launch per layer: x1 (B1,T,in) takes part in autograd,
+    x2 (B2,T,in) is a no-grad forward's input -> (y1 (B1,T,2H), y2 (B2,T,2H), y2 without a graph).  The values are those of two
+    gru_bidirectional calls (fp32 class; not bit for bit where the 32-row kernel takes over, see the kernel).  Inter-layer dropout
+    is not supported here (the HOP decoder has none, HOP.py:166-167)."""
+    if not (gru.bidirectional and gru.batch_first and gru.bias) or gru.dropout != 0:
+        raise _lib.HopmiError("hopmi gru pair: batch_first, bidirectional, biased nn.GRU modules without inter-layer dropout")
+    H = gru.hidden_size
+    pack = gru.__dict__.get("_hopmi_pack")
+    if pack is None:
+        pack = gru.__dict__["_hopmi_pack"] = _GruPack()
+    bufs = pack.ensure(gru)
+    a, b = x1, x2.detach()
+    for layer in range(gru.num_layers):
+        al = lambda n: _PackedAlias.apply(bufs[layer][n], getattr(gru, f"{n}_l{layer}"), getattr(gru, f"{n}_l{layer}_reverse"))
+        owners = (getattr(gru, f"weight_ih_l{layer}"), getattr(gru, f"weight_ih_l{layer}_reverse"))
+        w_ih, b_ih = al("weight_ih"), al("bias_ih")
+        gi1 = linear(a, w_ih.flatten(0, 1), b_ih.flatten(), owners=owners).view(a.shape[0], a.shape[1], 2, 3 * H)
+        with torch.no_grad():
+            gi2 = linear(b, w_ih.detach().flatten(0, 1), b_ih.detach().flatten(), owners=owners).view(b.shape[0], b.shape[1], 2, 3 * H)
+        a, b = _GruLayerPairFn.apply(gi1, gi2, al("weight_hh"), al("bias_hh"))
+    return a, b
 
 
 class _PackedAlias(torch.autograd.Function):

@@ -178,6 +178,9 @@ FUSED_LOSSES = True
 ELIDE_UNUSED_D_GRADS = os.environ.get("HOPMI_ELIDE_D_GRADS", "1") != "0"
 # discriminator step: the per-sample part of the discriminator (GRU, linears) once on the real and the generated batch side by side
 PAIRED_DISCRIMINATOR = os.environ.get("HOPMI_PAIRED_D", "1") != "0"
+# generator step: the graded forward and the regulariser's no-grad forward through Model.forward_pair (one decoder recurrence launch
+# per layer for both); A/B: HOPMI_PAIRED_FWD=0
+PAIRED_FORWARDS = os.environ.get("HOPMI_PAIRED_FWD", "1") != "0"
 
 
 class _params_take_no_grad:
@@ -224,7 +227,19 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
 
         model_optim.zero_grad()
         with _amp(args, target_dir_vec):
-            outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
+            # The graded forward and the diversity regulariser's no-grad forward (train_llm.py:42,58) as one call when the module
+            # offers it (model.Model.forward_pair: the pose decoder's recurrences run once over both batches); the speaker permutation
+            # is drawn where the reference draws it in the random streams (between the two forwards' noise draws).
+            pair_fn = getattr(_unwrap(model), "forward_pair", None) if (
+                PAIRED_FORWARDS and _ops.GRU_PAIR and args.z_type == "speaker" and args.loss_reg_weight > 0.0 and _unwrap(model) is model
+                and in_audio.is_cuda and not getattr(_unwrap(model), "_no_pair", False)) else None
+            out_rand = z_rand = None
+            if pair_fn is not None:
+                (outputs, z_context, z_mu, z_logvar), (out_rand, z_rand) = pair_fn(
+                    in_audio, log_melspec, text_token_padded, pre_seq, vid_indices,
+                    lambda: vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)])
+            else:
+                outputs, z_context, z_mu, z_logvar = model(in_audio, log_melspec, text_token_padded, pre_seq, vid_indices)
             if epoch > 10 or not ELIDE_UNUSED_SCORE:
                 # (not under a wrapper that counts on a gradient for every parameter of every forward it has seen, see above)
                 with _params_take_no_grad(discriminator, epoch > 10 and ELIDE_UNUSED_D_GRADS and _unwrap(discriminator) is discriminator):
@@ -238,11 +253,12 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
             outputs = outputs.float()                                          # losses in fp32
             kld = div_reg = None
             if (args.z_type == "speaker" or args.z_type == "random") and args.loss_reg_weight > 0.0:
-                rand_vids = None
-                if args.z_type == "speaker":
-                    rand_vids = vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)]
-                with torch.no_grad():                                          # only used detached (:60,65)
-                    out_rand, z_rand, _, _ = model(in_audio, log_melspec, text_token_padded, pre_seq, rand_vids)
+                if out_rand is None:
+                    rand_vids = None
+                    if args.z_type == "speaker":
+                        rand_vids = vid_indices[_randperm(vid_indices.shape[0], vid_indices.device)]
+                    with torch.no_grad():                                      # only used detached (:60,65)
+                        out_rand, z_rand, _, _ = model(in_audio, log_melspec, text_token_padded, pre_seq, rand_vids)
                 speaker = args.z_type == "speaker"
                 if FUSED_LOSSES:
                     # train_llm.py:46-79: huber, diversity regulariser, KLD and their weighted sum, fused (ops.hop_losses)

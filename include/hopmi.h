@@ -399,6 +399,15 @@ int hopmi_gru_fwd_dt(const void* gi, int gi_dtype, const float* whh, const float
 int hopmi_gru_bwd_dt(const float* dy, const float* y, const float* gates, const float* whhT, void* dgi, int dgi_dtype,
                      float* dgh, float* ws, void* ws2, int B, int T, int H, void* stream);
 
+/* hopmi_gru_fwd_dt over TWO input-projection tensors in one launch (round 6): batch rows [0, B1) read gi1 (B1,T,2,3H), rows
+ * [B1, B) read gi2 (B - B1,T,2,3H); y (B,T,2H) and gates (B,T,2,4H) are whole.  The decoder of a train_llm step runs twice on the
+ * same weights -- the graded forward and the no-grad forward of the diversity regulariser (train_llm.py:42,58; HOP.py:248) -- and a
+ * time step of the recurrence is a hand-off round trip around very little arithmetic: the second batch rides in the same launch
+ * (persistent kernel with 32 rows per workgroup when 16-row tiles would not fit the chip).  Where no persistent form applies the
+ * call runs as two hopmi_gru_fwd_dt calls; results are those of the two calls either way (fp32 class). */
+int hopmi_gru_fwd_pair_dt(const void* gi1, const void* gi2, int B1, int gi_dtype, const float* whh, const float* bhh, float* y,
+                          float* gates, void* ws, int B, int T, int H, void* stream);
+
 /* The two operands of a layer's backward that are re-arrangements of forward tensors, in one launch: whhT (2,H,3H) = whh (2,3H,H)
  * transposed per direction (the whhT argument of hopmi_gru_bwd), and hprev (B,T,2,H) = y shifted one step along each direction's
  * processing order, zero at its first step (dW_hh = sum_{b,t} dgh^T hprev; multimodal_context_net.py:35 -> torch.nn.GRU backward). */

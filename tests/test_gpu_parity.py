@@ -1937,6 +1937,88 @@ def test_layernorm_operand_images_feed_the_lds_dma_gemm(monkeypatch):
     assert rel_err(res_d["image"][2], res_d["split"][2]) <= 2e-6
 
 
+@pytest.mark.parametrize("B,full", [(3, False), (128, True)])
+def test_forward_pair_equals_two_forwards(B, full):
+    """Model.forward_pair (round 6): the graded forward and the no-grad forward on other speaker indices with ONE decoder recurrence
+    launch per GRU layer for both batches -- against two `forward` calls on a twin: outputs, z, and every parameter gradient of a
+    loss on the graded outputs, at the 1e-5 class (fp32-class kernels on both sides; at B = 128 the joint batch of 256 rows runs
+    the 32-row persistent kernel, hopmi_gru_fwd_pair_dt), dropout off, the noise draws injected."""
+    import copy
+    import hopmi
+    from oracle import fill
+    dev = _dev()
+    if full:
+        m1, _, bcfg, inp = _full_size_setup(9, B)
+    else:
+        from transformers import BertModel
+        from oracle.golden_util import SynthTok, SynthVocab, hop_cfg, tiny_bert_config
+        bcfg = tiny_bert_config()
+        m1 = hopmi.Model(hop_cfg(9, bcfg.hidden_size), BertModel(bcfg), SynthTok(), SynthVocab(11)).float()
+        m1.reprogramming_layer.dropout.p = 0.0
+        fill.fill_state_(m1)
+        inp = fill.hot_path_inputs(B, 9, bcfg.vocab_size, 11)
+    m1 = m1.to(dev).train()
+    m2 = copy.deepcopy(m1)
+    x = {k: v.to(dev) for k, v in inp.items()}
+    pre = x["target_dir_vec"][:, :16]
+    vids2 = x["vid_indices"].flip(0)
+    eps = [torch.randn(B, 16, generator=torch.Generator().manual_seed(5 + k)).to(dev) for k in range(2)]
+
+    def draws():
+        it = iter(eps)
+        return lambda t: next(it)
+
+    m1._randn_like = draws()
+    (o1, z1, mu1, lv1), (o1r, z1r) = m1.forward_pair(x["in_audio"], x["log_melspec"], x["text"], pre, x["vid_indices"], lambda: vids2)
+    assert not o1r.requires_grad and not z1r.requires_grad
+    (o1.square().sum() + mu1.square().sum() + lv1.sum()).backward()
+    m2._randn_like = draws()
+    o2, z2, mu2, lv2 = m2(x["in_audio"], x["log_melspec"], x["text"], pre, x["vid_indices"])
+    with torch.no_grad():
+        o2r, z2r, _, _ = m2(x["in_audio"], x["log_melspec"], x["text"], pre, vids2)
+    (o2.square().sum() + mu2.square().sum() + lv2.sum()).backward()
+    tol = 2e-5
+    assert rel_err(o1, o2) <= tol and rel_err(o1r, o2r) <= tol, (rel_err(o1, o2), rel_err(o1r, o2r))
+    assert torch.equal(z1, z2) and torch.equal(z1r, z2r)
+    worst = ("", 0.0)
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None, n
+            continue
+        e = rel_err(p.grad, q.grad)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] <= 1e-4, worst
+    # BatchNorm running statistics saw the same two forwards
+    for (n, a), (_, b) in zip(m1.named_buffers(), m2.named_buffers()):
+        if a.is_floating_point() and not n.startswith("llm_model."):
+            assert rel_err(a, b) <= 1e-6, n
+
+
+def test_gru_forward_32_row_workgroups_equal_the_16_row_form():
+    """hopmi_gru_fwd at a batch whose 16-row tiling needs more workgroups than the chip holds (B = 256, H = 350: 352) runs the
+    persistent kernel with TWO row tiles per workgroup (MR = 2, round 6: the decoder of a step's two generator forwards as one
+    launch).  Same resident fragments, same order of matrix terms per element; the gate epilogue is a different instantiation of
+    the same source (the compiler contracts `(1 - z) n + z h` into fused multiply-adds as it sees fit per instantiation), so the
+    comparison with the 16-row kernel on the two halves of the batch is held to 2e-6 absolute on states bounded by 1 (34 recurrent
+    steps; measured ~1e-7), not to bit equality; ragged batch (B = 200) too; the status word stays clear."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    T, H = 34, 350
+    whh = (torch.randn(2, 3 * H, H, generator=g) / H ** 0.5).to(dev)
+    bhh = (torch.randn(2, 3 * H, generator=g) * 0.1).to(dev)
+    for B in (256, 200):
+        gi = torch.randn(B, T, 2, 3 * H, generator=g).to(dev)
+        with torch.no_grad():
+            y_all = ops.gru_layer(gi, whh, bhh)
+            halves = [ops.gru_layer(gi[a:b].contiguous(), whh, bhh) for a, b in ((0, 128), (128, B))]
+        ops.check_status_now()
+        diff = (y_all - torch.cat(halves, 0)).abs().max().item()
+        assert diff <= 2e-6, (B, diff)
+        assert bool(torch.isfinite(y_all).all())
+
+
 def test_ffn_image_path_on_vanishing_gradient_rows(monkeypatch):
     """Round 5's NaN (headline): the row 2-norms that bound the image-emitting FFN epilogue were sqrt(sum x^2); for a
     gradient row below ~1e-19 (behind a saturated GRU they are 1e-30) the squares underflow to ZERO, the zero bound scaled the tiny
