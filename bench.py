@@ -408,6 +408,9 @@ def main():
                                       if gan else
                                       "2 generator forwards (the graded one + the no-grad forward of the diversity regulariser, "
                                       "train_llm.py:58) + 1 backward + Adam on 65.7 M parameters")
+                                   + "; the pose decoder's GRU recurrences of the generator step's two forwards (same weights) run as ONE launch per "
+                                     "layer over both batches (Model.forward_pair / hopmi_gru_fwd_pair_dt; values of two separate calls at the fp32 "
+                                     "class, tests/test_gpu_parity.py::test_forward_pair_equals_two_forwards)"
                                    + "; inside one step the batch-independent prototype branch (mapping layer, K/V projections) and the "
                                      "dropout-free audio branch (beat MLP, gwnet: one persistent launch for the 8 fused layers) are computed ONCE and reused by the "
                                      "step's other forwards, whose BatchNorm running-statistics update is replayed on the same partial "

@@ -232,7 +232,7 @@ def train_llm(args, epoch, in_audio, log_melspec, text_token_padded, target_dir_
             # is drawn where the reference draws it in the random streams (between the two forwards' noise draws).
             pair_fn = getattr(_unwrap(model), "forward_pair", None) if (
                 PAIRED_FORWARDS and _ops.GRU_PAIR and args.z_type == "speaker" and args.loss_reg_weight > 0.0 and _unwrap(model) is model
-                and in_audio.is_cuda and not getattr(_unwrap(model), "_no_pair", False)) else None
+                and in_audio.is_cuda and not model._forward_hooks and not model._forward_pre_hooks) else None      # (hooks see `forward` calls)
             out_rand = z_rand = None
             if pair_fn is not None:
                 (outputs, z_context, z_mu, z_logvar), (out_rand, z_rand) = pair_fn(
