@@ -17,6 +17,18 @@
  *     returns a thread-local message for the last failure;
  *   - all tensors fp32, dense, "channels-last" activations: x[n_slabs][V][64] where a
  *     slab is one (clip b, frame t) pair, i.e. row (b*T + t)*V + v, channel c innermost.
+ *
+ * State the library holds (all of it; none of it is data-path state -- results depend on the arguments only):
+ *   - per host thread: the last error message (hopmi_last_error) and the one-shot measurement hook
+ *     (hopmi_time_next_launch: consumed by that thread's next launch of a kernel that honours it);
+ *   - per process, read-only after first use: a table of the DIAGNOSTIC environment knobs (HOPMI_* tile / form selectors,
+ *     each read once under a mutex; hopmi_reload_env() forgets the table for probes that sweep a knob) and plan caches
+ *     keyed on geometry (occupancy queries, tile plans: pure functions of their key);
+ *   - nothing else: every entry point is re-entrant across streams and threads, and workspaces (status words, launch
+ *     sequence numbers of the persistent kernels) are the caller's memory.
+ * The diagnostic build (`make dbg`: libhopmi_dbg.so, -DHOPMI_CHECK_SPLIT) additionally exports
+ * hopmi_debug_set_split_status_<file>(unsigned*): a device buffer into which every fp16 hi/lo split reports an overflow
+ * (csrc/common.h); the production library carries neither the symbols nor the checks.
  */
 #ifndef HOPMI_H
 #define HOPMI_H
