@@ -284,7 +284,9 @@ class GraphedTrainStep:
         self._built = True
 
     def _frozen_versions(self):
-        return tuple(p._version for p in self._frozen)
+        # (+ ops.CACHE_EPOCH: ops.invalidate_weight_images() / reset_all_caches("all") drops the frozen weights' images, whose
+        # addresses a recording holds -- such a recording is dropped and re-made like one whose frozen parameter changed)
+        return tuple(p._version for p in self._frozen) + (_ops.CACHE_EPOCH,)
 
     def _mark_written(self):
         """A replay updates parameters and buffers on the device behind torch's back: advance their version counters as

@@ -502,9 +502,10 @@ def reset_all_caches(scope="all"):
     _CAST_CACHE.clear()
     _F16_IMG.clear()
     if scope == "all":
+        # (graph.GraphedTrainStep keeps CACHE_EPOCH beside the frozen parameters' version counters: a recording made before this
+        # call holds the addresses of the images dropped here and is re-made on its next call.  _UNIT_RS stays: constants.)
         CACHE_EPOCH += 1
         _F16_IMG_FROZEN.clear()
-        _UNIT_RS.clear()
     else:
         for key in [k for k, v in _F16_IMG_FROZEN.items() if v[3]]:
             del _F16_IMG_FROZEN[key]
@@ -539,8 +540,9 @@ def _check_scales(what, t2d, sc):
     if not bool(((sc[0].double() * sc[1].double()) == 1.0).all()):
         _check_fail(what, "not (scale, inverse) pairs")
     ratio = fresh[0].double() / sc[0].double()
-    if not bool(((ratio >= 1.0) & (ratio <= 4096.0)).all()):
-        r = int(torch.nonzero(~((ratio >= 1.0) & (ratio <= 4096.0)))[0])
+    ok = ((ratio >= 1.0) & (ratio <= 4096.0)) | (t2d.abs().amax(dim=1) == 0)      # (an all-zero row: any scale describes it)
+    if not bool(ok.all()):
+        r = int(torch.nonzero(~ok)[0])
         _check_fail(what, f"row {r}: attached scale {float(sc[0][r]):g} against {float(fresh[0][r]):g} from the values")
 
 

@@ -208,6 +208,38 @@ def test_graphed_step_rerecords_after_a_frozen_weight_changes(monkeypatch):
     assert unchecked.n_eager == 1 and stale > 4e-4, stale       # (the stale replay is off by more than the tolerance above)
 
 
+def test_graphed_step_rerecords_after_the_caches_are_invalidated(monkeypatch):
+    """ops.invalidate_weight_images() (= reset_all_caches("all")) drops cached images of FROZEN weights too, and a recording holds
+    their addresses: the recorded step keeps ops.CACHE_EPOCH beside the frozen parameters' version counters, so the call after an
+    invalidation runs the eager step and records again instead of replaying freed memory -- and after a frozen weight was
+    rescaled through `.data` (no version counter moves) followed by the documented invalidate call, it follows an eager twin."""
+    import hopmi
+    from hopmi import ops
+    from oracle.golden_util import Accel, step_args
+    dev = _dev()
+    _deterministic_draws(monkeypatch)
+    m1, d1, inp = _pair(9, dev)
+    m2, d2 = copy.deepcopy(m1), copy.deepcopy(d1)
+    m2._randn_like = m1._randn_like
+    mk = lambda m, d: (torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999)),
+                       torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.999)))
+    g1, o1 = mk(m1, d1)
+    g2, o2 = mk(m2, d2)
+    args = step_args(9)
+    batch = (inp["in_audio"], inp["log_melspec"], inp["text"], inp["target_dir_vec"], inp["vid_indices"])
+    graphed = hopmi.GraphedTrainStep(args, m2, d2, g2, o2, eager_calls=1)
+    for it in range(6):
+        if it == 3:
+            for m in (m1, m2):
+                m.llm_model.encoder.layer[0].intermediate.dense.weight.data.mul_(2.0)      # behind every version counter's back
+            ops.invalidate_weight_images()
+        want = hopmi.train_llm(args, 0, *batch, m1, d1, g1, o1, Accel())
+        got = graphed(0, *batch)
+        for k in want:
+            assert abs(got[k] - want[k]) <= 4e-4 * max(abs(want[k]), 1e-6), (it, k, got[k], want[k])
+        assert (graphed.n_eager, graphed.n_replay) == [(1, 0), (1, 1), (1, 2), (2, 2), (2, 3), (2, 4)][it], it
+
+
 def test_graphed_step_new_batches_and_other_shapes(monkeypatch):
     """Replays read the batch from static buffers (a new batch of the recorded shape is copied in), another batch size
     falls back to the eager step, and both keep training the same model."""
