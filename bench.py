@@ -68,6 +68,9 @@ def parse():
                     help="no GPU work: every rank joins a gloo group, the ranks run the timing reduction (barrier, MAX over ranks) and rank 0 "
                          "prints a stub line with n_gpus and the group size -- what tests/test_parallel_gloo.py uses to run the launch "
                          "path of `python bench.py --gpus N` on a box without GPUs")
+    ap.add_argument("--poison", action="store_true",
+                    help="TEST HOOK (tests/test_gpu_graph.py::test_bench_refuses_to_report_a_dead_model): a NaN is written into one "
+                         "parameter behind the warm-up steps, so that the run must end with exit code 3 and no `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -330,6 +333,9 @@ def main():
         setup_calls += 1
     for _ in range(args.warmup):
         step()
+    if args.poison:
+        with torch.no_grad():
+            model.align_layer.bias[0] = float("nan")
     fence()
     t0 = time.perf_counter()
     stamps = [t0]

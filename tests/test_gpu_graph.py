@@ -645,6 +645,24 @@ def test_graphed_step_bench_regime_stays_finite():
     assert b / 10 <= a <= b * 10, (a, b)
 
 
+def test_bench_refuses_to_report_a_dead_model():
+    """bench.py must not time a dead model (round 5's headline was measured on one that had gone to NaN, printed inside `config`,
+    exit code 0): with a NaN written into a parameter behind the warm-up (`--poison`, a test hook) the run ends with exit code 3,
+    its one JSON line is strict JSON with `value: null`, an `error` and the non-finite losses as strings at the top level; the same
+    command without the hook reports a finite value with `losses` at the top level."""
+    import json
+    from conftest import ROOT, run_isolated
+    common = [os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--kernel-steps", "0", "--no-cpu-baseline"]
+    r = run_isolated(common + ["--poison"], timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1], parse_constant=lambda c: pytest.fail(f"bare {c} in the line"))
+    assert line["value"] is None and "non-finite" in line["error"] and any(isinstance(v, str) for v in line["losses"].values()), line
+    r = run_isolated(common, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1], parse_constant=lambda c: pytest.fail(f"bare {c} in the line"))
+    assert line["value"] > 0 and all(isinstance(v, float) and v == v for v in line["losses"].values()), line
+
+
 def test_bench_regime_under_the_diagnostic_library_reports_no_split_overflow():
     """The same run against libhopmi_dbg.so (`make dbg`: -DHOPMI_CHECK_SPLIT, csrc/common.h): every conversion of a scaled value to
     its fp16 hi part, in every kernel, reports into a status buffer when it produces infinity / NaN.  No site may report in the
