@@ -142,3 +142,43 @@ def test_skip_pack_gradients_equal_cat_stack_composition():
     want = torch.autograd.grad([rw, rb], ws + bs, [gw, gb])
     for a, b, p in zip(got, want, ws + bs):
         assert a.shape == p.shape and a.is_contiguous() and torch.equal(a, b)
+
+
+def test_diagnostic_library_is_the_same_abi_plus_the_split_status_setters():
+    """`make dbg` (csrc/Makefile `all`): libhopmi_dbg.so exports every symbol of hopmi.h AND hopmi_debug_set_split_status_<file> for
+    the eight translation units that split operands into fp16 hi/lo parts; the production library exports none of those."""
+    dbg = os.path.join(os.path.dirname(_lib._LIB_PATH), "libhopmi_dbg.so")
+    assert os.path.exists(dbg), f"{dbg} is missing (make -C csrc all)"
+    d, p = ctypes.CDLL(dbg), ctypes.CDLL(_lib._LIB_PATH)
+    for s in header_symbols():
+        assert hasattr(d, s), s
+    for name in ("gemm", "gemm_tn", "elementwise", "attn", "bert_attn", "gru", "wavenet", "wavenet_stack"):
+        assert hasattr(d, "hopmi_debug_set_split_status_" + name), name
+        assert not hasattr(p, "hopmi_debug_set_split_status_" + name), name
+
+
+def test_one_invalidation_point_for_the_derived_operand_caches():
+    """ops.reset_all_caches is the only place the cache tables are cleared: scope "recording" keeps the epoch and the frozen images made
+    by eager calls, scope "all" (= invalidate_weight_images) moves CACHE_EPOCH and clears the frozen table; registered resetters see
+    the scope; the constants table survives both."""
+    from hopmi import ops
+    seen = []
+    ops.register_cache_resetter(seen.append)
+    try:
+        ops._CAST_CACHE["x"] = 1
+        ops._F16_IMG["x"] = 1
+        ops._F16_IMG_FROZEN["eager"] = (None, None, None, False)
+        ops._F16_IMG_FROZEN["captured"] = (None, None, None, True)
+        ops._UNIT_RS["c"] = 1
+        e0 = ops.CACHE_EPOCH
+        ops.cast_cache_reset()
+        assert ops.CACHE_EPOCH == e0 and not ops._CAST_CACHE and not ops._F16_IMG
+        assert "eager" in ops._F16_IMG_FROZEN and "captured" not in ops._F16_IMG_FROZEN and "c" in ops._UNIT_RS
+        ops.invalidate_weight_images()
+        assert ops.CACHE_EPOCH == e0 + 1 and not ops._F16_IMG_FROZEN and "c" in ops._UNIT_RS
+        assert seen == ["recording", "all"]
+        with pytest.raises(ValueError):
+            ops.reset_all_caches("some")
+    finally:
+        ops._EXTRA_RESETTERS.remove(seen.append) if seen.append in ops._EXTRA_RESETTERS else ops._EXTRA_RESETTERS.pop()
+        ops._UNIT_RS.pop("c", None)
