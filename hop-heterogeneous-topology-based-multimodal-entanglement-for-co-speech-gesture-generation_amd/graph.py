@@ -203,6 +203,49 @@ class _Capture:
         self.owner._after_backward(self, is_disc)
 
 
+class _AdamMultiStep:
+    """While a step is being recorded, `opt.step()` of a plain torch.optim.Adam runs as ONE hopmi_adam_multi launch per parameter
+    group (csrc/adam.hip: the arithmetic of torch's fused Adam at the rate of a copy -- torch's multi-tensor launch serves the
+    generator's 172 small tensors badly, tools/probes/adam_floor.py) instead of torch's multi_tensor_apply launches.  The
+    optimizer's own state tensors are what is updated (exp_avg, exp_avg_sq, the device-side step counters: state_dict() and later
+    eager steps see nothing unusual) and its step hooks run as they would (the row-sharded mapping layer's among them).  Eager
+    steps keep torch's own step.  `plans`: {group index: ops.AdamPlan}, made before the recording (GraphedTrainStep._build)."""
+
+    def __init__(self, opt, plans):
+        self.opt, self.plans = opt, plans
+        self.active = bool(plans)
+
+    def __enter__(self):
+        if self.active:
+            self.opt.step = self._step                   # (instance attribute: shadows the class's hooked step for the recording)
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.opt.__dict__.pop("step", None)
+        return False
+
+    @torch.no_grad()
+    def _step(self, closure=None):
+        opt = self.opt
+        for hook in list(getattr(opt, "_optimizer_step_pre_hooks", {}).values()):
+            hook(opt, (), {})
+        for gi, group in enumerate(opt.param_groups):
+            plan = self.plans.get(gi)
+            if plan is None:
+                continue
+            live = [p for p in plan.params if p.grad is not None]
+            if not live:
+                continue
+            steps = [opt.state[p]["step"] for p in live]
+            torch._foreach_add_(steps, 1)
+            st = [opt.state[p] for p in plan.params]
+            plan.bind([p.grad for p in plan.params], [s_["exp_avg"] for s_ in st], [s_["exp_avg_sq"] for s_ in st])
+            plan.step(group["lr"], group["betas"][0], group["betas"][1], group["eps"], steps[0])
+        for hook in list(getattr(opt, "_optimizer_step_post_hooks", {}).values()):
+            hook(opt, (), {})
+
+
 class GraphedTrainStep:
     def __init__(self, args, model, discriminator, model_optim, dis_optimizer, accelerator=None, group=None,
                  eager_calls=2, grad_dtype=None, enabled=True, force_exchange=False, debug=False, overlap=True, inplace=False):
@@ -263,6 +306,14 @@ class GraphedTrainStep:
             self._bg = torch.zeros_like(m.mapping_layer.bias)
         for opt in (self.g_opt, self.d_opt):
             _make_capturable(opt)
+        # the generator's optimizer step of a recording as one launch per parameter group (see _AdamMultiStep)
+        self._adam_plans = {}
+        if _ops.adam_multi_supported(self.g_opt):
+            for gi, group in enumerate(self.g_opt.param_groups):
+                ps = [p for p in group["params"] if p.requires_grad]
+                if ps:
+                    st = [self.g_opt.state[p] for p in ps]
+                    self._adam_plans[gi] = _ops.AdamPlan(ps, [s_["exp_avg"] for s_ in st], [s_["exp_avg_sq"] for s_ in st])
         # more than one rank: every rank steps Adam on its own rows of the mapping layer only (see _after_backward)
         self._rows_adam = bool(self._has_proto and self.world > 1 and isinstance(self.g_opt, torch.optim.Adam)
                                and not isinstance(self.g_opt, torch.optim.AdamW))
@@ -462,7 +513,8 @@ class GraphedTrainStep:
                 cap.begin()
                 try:
                     self._prototype_segment(cap, amp_factory())
-                    _steps.train_llm(self.args, epoch, *static, m, self.disc, self.g_opt, self.d_opt, cap)
+                    with _AdamMultiStep(self.g_opt, self._adam_plans):
+                        _steps.train_llm(self.args, epoch, *static, m, self.disc, self.g_opt, self.d_opt, cap)
                     # tail of the last segment: the backward launches' status words, read by the NEXT replay's fetch
                     if cap.status:
                         self._bwd_status.copy_(torch.stack([w.float().reshape(()) for w in cap.status]).sum())

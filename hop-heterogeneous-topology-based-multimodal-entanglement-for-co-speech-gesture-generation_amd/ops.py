@@ -99,6 +99,73 @@ def time_noop_launch():
     _lib.check(_timed("noop", 0, 0, lambda: L.hopmi_noop_launch(st), exact=True), "hopmi_noop_launch")
 
 
+# ------------------------------------------------------- Adam over a parameter list in one launch (csrc/adam.hip)
+FUSED_ADAM = __import__("os").environ.get("HOPMI_FUSED_ADAM", "1") != "0"
+
+
+def adam_multi_supported(opt) -> bool:
+    """Can hopmi_adam_multi stand in for `opt.step()`?  Plain torch.optim.Adam (not AdamW), no weight decay, amsgrad, maximize or
+    differentiable mode, scalar hyper-parameters, fp32 parameters on one ROCm device with device-side step counters."""
+    if not FUSED_ADAM or type(opt) is not torch.optim.Adam:
+        return False
+    for g in opt.param_groups:
+        if (g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False) or g.get("differentiable", False)
+                or g.get("decoupled_weight_decay", False) or torch.is_tensor(g["lr"]) or any(torch.is_tensor(b) for b in g["betas"])):
+            return False
+        for p in g["params"]:
+            if p.requires_grad and not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                return False
+    return True
+
+
+class AdamPlan:
+    """The device tables of one hopmi_adam_multi launch over `params`: (p, g, m, v, n) per tensor and the (tensor, chunk) work
+    items.  Made BEFORE a recording (pinned host buffers and device tables are allocated here, outside any capture); `bind(grads)`
+    is called where the gradients' addresses are final -- inside the recording, at the optimizer's step -- and enqueues one small
+    host -> device copy of the tensor table (a copy node of the recording; the pinned buffer lives as long as the plan).  A
+    parameter without a gradient in that step gets n = 0 (its work items do nothing)."""
+
+    def __init__(self, params, exp_avgs, exp_avg_sqs):
+        import numpy as np
+        L = _lib.lib()
+        chunk = L.hopmi_adam_chunk()
+        self.params = list(params)
+        n = len(self.params)
+        self._tab_host = torch.zeros(n, 5, dtype=torch.int64).pin_memory()
+        items = []
+        for i, (p, m, v) in enumerate(zip(self.params, exp_avgs, exp_avg_sqs)):
+            for t, nm in ((p, "parameter"), (m, "exp_avg"), (v, "exp_avg_sq")):
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()):
+                    raise _lib.HopmiError(f"hopmi AdamPlan: {nm} {i} is not a contiguous fp32 device tensor of the parameter's size")
+            self._tab_host[i, 0], self._tab_host[i, 2], self._tab_host[i, 3] = p.data_ptr(), m.data_ptr(), v.data_ptr()
+            items += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
+        dev = self.params[0].device
+        self.tensors = torch.zeros(n, 5, dtype=torch.int64, device=dev)
+        self.items = torch.from_numpy(np.asarray(items, dtype=np.int32).reshape(-1, 2)).to(dev)
+        self.n_items = int(self.items.shape[0])
+        self.keep = (self.params, list(exp_avgs), list(exp_avg_sqs))
+        self._grads = None
+
+    def bind(self, grads, exp_avgs, exp_avg_sqs):
+        """grads[i]: the gradient of params[i] (contiguous fp32, its size) or None; the moments as the optimizer holds them NOW
+        (every address is written again: a parameter re-packed or a state loaded since the plan was made is followed)."""
+        for i, (p, g, m, v) in enumerate(zip(self.params, grads, exp_avgs, exp_avg_sqs)):
+            if g is None:
+                self._tab_host[i, 1], self._tab_host[i, 4] = 0, 0
+                continue
+            for t, nm in ((g, "gradient"), (m, "exp_avg"), (v, "exp_avg_sq")):
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()):
+                    raise _lib.HopmiError(f"hopmi AdamPlan: {nm} {i} is not a contiguous fp32 device tensor of the parameter's size")
+            self._tab_host[i, 0], self._tab_host[i, 1], self._tab_host[i, 2], self._tab_host[i, 3] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            self._tab_host[i, 4] = p.numel()
+        self.keep = (self.params, list(grads), list(exp_avgs), list(exp_avg_sqs))      # (the table holds their addresses)
+        self.tensors.copy_(self._tab_host, non_blocking=True)
+
+    def step(self, lr, beta1, beta2, eps, step_tensor):
+        _lib.check(_lib.lib().hopmi_adam_multi(self.tensors.data_ptr(), self.items.data_ptr(), self.n_items, float(lr), float(beta1),
+                                               float(beta2), float(eps), step_tensor.data_ptr(), _stream()), "hopmi_adam_multi")
+
+
 # ------------------------------------------------------- diagnostic build: the fp16-split status word (csrc/common.h, split_check)
 _SPLIT_FILES = {1: "gemm.hip", 2: "gemm_tn.hip", 3: "elementwise.hip", 4: "attn.hip", 5: "bert_attn.hip", 6: "gru.hip", 7: "wavenet.hip",
                 8: "wavenet_stack.hip"}

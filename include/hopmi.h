@@ -420,6 +420,15 @@ int hopmi_gru_bwd_dt(const float* dy, const float* y, const float* gates, const 
 int hopmi_gru_fwd_pair_dt(const void* gi1, const void* gi2, int B1, int gi_dtype, const float* whh, const float* bhh, float* y,
                           float* gates, void* ws, int B, int T, int H, void* stream);
 
+/* Adam over a list of fp32 tensors in ONE launch (csrc/adam.hip; train_llm.py:86 `model_optim.step()`; arithmetic of torch's
+ * _fused_adam_ without weight decay / amsgrad / maximize).  `tensors`: device array of {float* p; const float* g; float* m;
+ * float* v; long long n} (40 bytes each); `items`: device array of n_items (tensor index, chunk index) int pairs, chunk =
+ * hopmi_adam_chunk() elements; `step`: the optimizer's device-side step counter, ALREADY advanced for this step (bias corrections
+ * 1 - beta^step).  p, m, v are updated in place. */
+int hopmi_adam_chunk(void);
+int hopmi_adam_multi(const void* tensors, const void* items, int n_items, float lr, float beta1, float beta2, float eps,
+                     const float* step, void* stream);
+
 /* The two operands of a layer's backward that are re-arrangements of forward tensors, in one launch: whhT (2,H,3H) = whh (2,3H,H)
  * transposed per direction (the whhT argument of hopmi_gru_bwd), and hprev (B,T,2,H) = y shifted one step along each direction's
  * processing order, zero at its first step (dW_hh = sum_{b,t} dgh^T hprev; multimodal_context_net.py:35 -> torch.nn.GRU backward). */

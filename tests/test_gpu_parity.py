@@ -1999,6 +1999,53 @@ def test_forward_pair_equals_two_forwards(B, full):
             assert rel_err(a, b) <= 1e-6, n
 
 
+def test_adam_multi_equals_torch_fused_adam():
+    """hopmi_adam_multi (csrc/adam.hip; the recorded step's optimizer launch): against torch.optim.Adam(fused=True, capturable=True)
+    over the same list -- sizes from 1 to 3 M elements, odd sizes, a parameter that is a misaligned view into a packed buffer (the
+    scalar path), a parameter without a gradient (n = 0 in the table) -- five steps with fresh gradients: parameters and both
+    moments agree to 2e-6 relative (same formula, fp32; torch's kernel contracts differently), the step counters advance."""
+    from hopmi import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 7, 64, 175, 1050, 8192, 8193, 65537, 350 * 1050, 3_000_001]
+    pack = torch.randn(5000 + 3, generator=g).to(dev)
+    mk = lambda: [torch.nn.Parameter(torch.randn(n, generator=torch.Generator().manual_seed(n)).to(dev)) for n in sizes]
+    ps_a, ps_b = mk(), mk()
+    va, vb = torch.nn.Parameter(torch.zeros(5000, device=dev)), torch.nn.Parameter(torch.zeros(5000, device=dev))
+    va.data = pack.clone()[3:]                                # 12-byte offset: not 16-byte aligned
+    vb.data = pack.clone()[3:]
+    assert va.data_ptr() % 16 != 0
+    idle_a, idle_b = torch.nn.Parameter(torch.ones(33, device=dev)), torch.nn.Parameter(torch.ones(33, device=dev))
+    ps_a += [va, idle_a]
+    ps_b += [vb, idle_b]
+    kw = dict(lr=1e-2, betas=(0.5, 0.999), eps=1e-8)
+    oa = torch.optim.Adam(ps_a, fused=True, capturable=True, **kw)
+    ob = torch.optim.Adam(ps_b, fused=True, capturable=True, **kw)
+    assert ops.adam_multi_supported(ob)
+    from hopmi.graph import _make_capturable
+    _make_capturable(ob)
+    st = [ob.state[p] for p in ps_b]
+    plan = ops.AdamPlan(ps_b, [s_["exp_avg"] for s_ in st], [s_["exp_avg_sq"] for s_ in st])
+    for it in range(5):
+        for a, b in zip(ps_a[:-1], ps_b[:-1]):
+            gr = torch.randn(a.numel(), generator=g).to(dev) * (10.0 ** (it - 3))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        live = [p for p in ps_b if p.grad is not None]
+        steps = [ob.state[p]["step"] for p in live]
+        torch._foreach_add_(steps, 1)
+        plan.bind([p.grad for p in ps_b], [s_["exp_avg"] for s_ in st], [s_["exp_avg_sq"] for s_ in st])
+        plan.step(kw["lr"], 0.5, 0.999, kw["eps"], steps[0])
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(ps_a, ps_b)):
+        assert rel_err(b, a) <= 2e-6, (k, rel_err(b, a))
+        if k < len(ps_a) - 1:
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert rel_err(ob.state[b][key], oa.state[a][key]) <= 2e-6, (k, key)
+            assert float(ob.state[b]["step"]) == 5.0
+    assert torch.equal(idle_b, torch.ones(33, device=dev)) and float(ob.state[idle_b]["step"]) == 0.0
+
+
 def test_gru_forward_32_row_workgroups_equal_the_16_row_form():
     """hopmi_gru_fwd at a batch whose 16-row tiling needs more workgroups than the chip holds (B = 256, H = 350: 352) runs the
     persistent kernel with TWO row tiles per workgroup (MR = 2, round 6: the decoder of a step's two generator forwards as one
