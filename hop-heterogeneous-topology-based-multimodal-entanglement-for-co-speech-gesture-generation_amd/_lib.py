@@ -110,7 +110,7 @@ SIGNATURES = {
     "hopmi_gru_bwd_ws_floats": (ctypes.c_size_t, [_I, _I]),
     "hopmi_gru_bwd": (_I, [_VP] * 8 + [_I, _I, _I, _VP]),
     "hopmi_adam_chunk": (_I, []),
-    "hopmi_adam_multi": (_I, [_VP, _VP, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _VP, _VP]),
+    "hopmi_adam_multi": (_I, [_VP, _VP, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _VP, _VP]),
 }
 
 

@@ -424,9 +424,9 @@ int hopmi_gru_fwd_pair_dt(const void* gi1, const void* gi2, int B1, int gi_dtype
  * _fused_adam_ without weight decay / amsgrad / maximize).  `tensors`: device array of {float* p; const float* g; float* m;
  * float* v; long long n} (40 bytes each); `items`: device array of n_items (tensor index, chunk index) int pairs, chunk =
  * hopmi_adam_chunk() elements; `step`: the optimizer's device-side step counter, ALREADY advanced for this step (bias corrections
- * 1 - beta^step).  p, m, v are updated in place. */
+ * 1 - beta^step, taken in double like 1 - beta: in fp32 1 - 0.999f is off by 1.3e-5).  p, m, v are updated in place. */
 int hopmi_adam_chunk(void);
-int hopmi_adam_multi(const void* tensors, const void* items, int n_items, float lr, float beta1, float beta2, float eps,
+int hopmi_adam_multi(const void* tensors, const void* items, int n_items, double lr, double beta1, double beta2, double eps,
                      const float* step, void* stream);
 
 /* The two operands of a layer's backward that are re-arrangements of forward tensors, in one launch: whhT (2,H,3H) = whh (2,3H,H)
