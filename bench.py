@@ -413,7 +413,9 @@ def main():
                                       "backward, Adam) + generator step (2 generator forwards, 1 discriminator forward, backward, Adam)"
                                       if gan else
                                       "2 generator forwards (the graded one + the no-grad forward of the diversity regulariser, "
-                                      "train_llm.py:58) + 1 backward + Adam on 65.7 M parameters")
+                                      "train_llm.py:58) + 1 backward + Adam on 65.7 M parameters (in the recorded step: the caller's "
+                                      "torch.optim.Adam state updated by one hopmi_adam_multi launch, torch's fused-Adam arithmetic, "
+                                      "tests/test_gpu_parity.py::test_adam_multi_equals_torch_fused_adam)")
                                    + "; the pose decoder's GRU recurrences of the generator step's two forwards (same weights) run as ONE launch per "
                                      "layer over both batches (Model.forward_pair / hopmi_gru_fwd_pair_dt; values of two separate calls at the fp32 "
                                      "class, tests/test_gpu_parity.py::test_forward_pair_equals_two_forwards)"
