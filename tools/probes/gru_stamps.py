@@ -22,7 +22,7 @@ def main():
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     names = ["gi prefetch + load h_{t-1} rows until written", "split + LDS commit + sync", "MFMA (+ operand reads)",
              "partials -> LDS + sync", "gates + stores"]
-    for B, T, H in ((128, 34, 350), (128, 28, 64)):
+    for B, T, H in ((128, 34, 350), (256, 34, 350)):
         gi = torch.randn(B, T, 2, 3 * H, device=dev) * 0.3
         whh = torch.randn(2, 3 * H, H, device=dev) / H ** 0.5
         bhh = torch.randn(2, 3 * H, device=dev) * 0.1
