@@ -37,7 +37,8 @@ def build_stamps():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--V", type=int, default=9)
-    ap.add_argument("--B", type=int, default=128)
+    ap.add_argument("--B", default="128", help="batch, or a comma-separated list (--B 128,256,512,1024: the sweep of DESIGN.md 7.1 -- the "
+                                               "batch-independent exchange floor and the per-clip streaming rate as separate numbers)")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--warm", type=float, default=1.5)
     ap.add_argument("--stamps", action="store_true")
@@ -45,6 +46,26 @@ def main():
     ap.add_argument("--lib", default=None, help="alternative libhopmi.so (timing experiments)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="storage type of x0, the saved y_l and the skip tails")
     a = ap.parse_args()
+    batches = [int(x) for x in str(a.B).split(",")]
+    if len(batches) > 1 and not (a.stamps or a.build_stamps):
+        # one child per batch (fresh workspaces and plans), then the two-parameter fit: time = floor + per_clip * B
+        import re
+        rows = []
+        for b in batches:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--V", str(a.V), "--B", str(b), "--iters", str(a.iters), "--dtype", a.dtype]
+                               + (["--lib", a.lib] if a.lib else []), capture_output=True, text=True)
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith("one launch")), None)
+            print(f"B={b}: {line}", flush=True)
+            m = re.search(r"kernel\s+([0-9.]+) us", line or "")
+            if m:
+                rows.append((b, float(m.group(1))))
+        if len(rows) >= 2:
+            n = len(rows); sx = sum(b for b, _ in rows); sy = sum(t for _, t in rows)
+            sxx = sum(b * b for b, _ in rows); sxy = sum(b * t for b, t in rows)
+            slope = (n * sxy - sx * sy) / (n * sxx - sx * sx)
+            print(f"least-squares fit over {[b for b, _ in rows]}: {(sy - slope * sx) / n:.1f} us batch-independent + {slope:.3f} us per clip")
+        return
+    a.B = batches[0]
     if a.build_stamps:
         build_stamps()
         return
